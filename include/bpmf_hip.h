@@ -1,0 +1,129 @@
+/*
+ * bpmf_hip.h -- C ABI of libbpmf_hip.so, the MI355X (gfx950) implementation of the two
+ * data-parallel hot paths of the Seismic_BPMF workflow.
+ *
+ * Conventions (mirroring the reference's own ctypes layer, BPMF/clib.py:14-84 and
+ * BPMF/libc.h:1-11): plain C symbols, C-contiguous float32 / int32 arrays, sizes as
+ * size_t, the caller allocates every output.  Unlike the reference (all functions
+ * return void and report problems with printf) every entry point returns an int status:
+ * 0 = ok, -1 = bad argument, -2 = HIP runtime error; bpmf_last_error() gives the text.
+ *
+ * Two flavours per path:
+ *   *_run      host pointers in / host pointers out (what a ctypes wrapper of the
+ *              reference's third-party back-ends binds; does H2D, kernels, D2H);
+ *   *_run_dev  device pointers, asynchronous on the given HIP stream, caller-provided
+ *              workspace (what the resident / multi-GPU / benchmark path uses).
+ *
+ * The hot-path arithmetic itself is NOT in the reference tree: BPMF calls the external
+ * packages fast_matched_filter and beampower (pyproject.toml:28-29).  Each entry point
+ * cites the reference call site it serves.
+ */
+#ifndef BPMF_HIP_H
+#define BPMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *bpmf_stream_t; /* a hipStream_t; NULL = the default stream */
+
+/* ---------------------------------------------------------------- diagnostics --- */
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *bpmf_last_error(void);
+
+/* Number of visible HIP devices (<0 on runtime error).
+ * Replaces the device query of BPMF/GPU.cu:8-24 (caract_GPU). */
+int bpmf_device_count(void);
+
+/* Name, memory and compute-unit count of one device.  BPMF/GPU.cu:14-22. */
+int bpmf_device_info(int device, char *name, size_t name_len, size_t *total_mem_bytes,
+                     int *compute_units);
+
+/* ------------------------------------------------------------ matched filter --- */
+/*
+ * Serves fast_matched_filter.matched_filter(templates, moveouts, weights, data, step,
+ * arch="gpu", network_sum=...) as called at BPMF/similarity_search.py:526-533 and
+ * BPMF/dataset.py:4818-4827.
+ *   templates (T,S,C,L) f32   moveouts (T,S,C) i32   weights (T,S,C) f32
+ *   data (S,C,N) f32          n_corr = (N-L)/step + 1
+ *   network_sum != 0 -> cc_out (T, n_corr)          weighted network sum
+ *   network_sum == 0 -> cc_out (T, n_corr, S, C)    per-channel CC (unweighted)
+ */
+
+/* flags of bpmf_mf_run_dev */
+#define BPMF_MF_DATA_PREPARED 1 /* workspace already holds this data's window energies */
+#define BPMF_MF_FORCE_DIRECT 2  /* use the generic (non-MFMA) kernel */
+
+size_t bpmf_mf_workspace_bytes(size_t L, size_t N, size_t T, size_t S, size_t C);
+
+/* Per-day, template-independent preparation (window energies of `data` for length L).
+ * Implied by bpmf_mf_run_dev unless BPMF_MF_DATA_PREPARED is set. */
+int bpmf_mf_prepare_data_dev(const float *d_data, size_t L, size_t N, size_t S, size_t C,
+                             void *d_workspace, size_t workspace_bytes, bpmf_stream_t stream);
+
+int bpmf_mf_run_dev(const float *d_templates, const int32_t *d_moveouts,
+                    const float *d_weights, const float *d_data, size_t step, size_t L,
+                    size_t N, size_t T, size_t S, size_t C, size_t n_corr, int network_sum,
+                    int flags, void *d_workspace, size_t workspace_bytes,
+                    bpmf_stream_t stream, float *d_cc_out);
+
+int bpmf_mf_run(const float *templates, const int32_t *moveouts, const float *weights,
+                const float *data, size_t step, size_t L, size_t N, size_t T, size_t S,
+                size_t C, size_t n_corr, int network_sum, int flags, int device,
+                float *cc_out);
+
+/* ------------------------------------------------------------ backprojection --- */
+/*
+ * Serves beampower.beampower.beamform(waveform_features, moveouts, weights_phases,
+ * weights_sources, device="gpu", out_of_bounds=, reduce=) as called at
+ * BPMF/template_search.py:549-558 (reduce="max") and :560-569 (reduce="none").
+ *   features (S,C,N) f32     moveouts (K,S,P) i32 (samples)
+ *   w_phases (S,C,P) f32     w_sources (K,S) f32
+ *   reduce max  -> beam_out (N) f32 + arg_out (N) i32   (lowest source index on ties)
+ *   reduce none -> beam_out (K,N) f32, arg_out unused (may be NULL)
+ */
+#define BPMF_BP_STRICT 0
+#define BPMF_BP_FLEXIBLE 1
+#define BPMF_BP_REDUCE_MAX 0
+#define BPMF_BP_REDUCE_NONE 1
+
+typedef struct bpmf_bp_plan bpmf_bp_plan; /* opaque: device-resident moveout table */
+
+/* Build the device-resident plan of one moveout table + source weights (host arrays).
+ * The reference rebuilds this table on every access (template_search.py:444-454); the
+ * plan is what lets it stay resident across days.  `source_id_offset` is added to the
+ * arg-max indices (global ids when the grid is sharded across GPUs). */
+int bpmf_bp_plan_create(const int32_t *moveouts, const float *w_sources, size_t K, size_t S,
+                        size_t P, int device, int32_t source_id_offset, bpmf_bp_plan **plan);
+void bpmf_bp_plan_destroy(bpmf_bp_plan *plan);
+
+size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan *plan, size_t N, size_t C);
+
+int bpmf_bp_run_dev(const bpmf_bp_plan *plan, const float *d_features,
+                    const float *d_w_phases, size_t N, size_t C, int out_of_bounds,
+                    int reduce, void *d_workspace, size_t workspace_bytes,
+                    bpmf_stream_t stream, float *d_beam_out, int32_t *d_arg_out);
+
+int bpmf_bp_run(const float *features, const int32_t *moveouts, const float *w_phases,
+                const float *w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
+                int out_of_bounds, int reduce, int device, float *beam_out, int32_t *arg_out);
+
+/* Multi-GPU exchange step of reduce="max": pack (beam, source id) into one uint64 whose
+ * unsigned order is (beam ascending, then source id DEscending), so that an RCCL
+ * all-reduce with ncclMax over uint64 (or int64 after the bias below) yields the global
+ * maximum with the lowest source id on ties; unpack restores the two vectors.
+ * `as_signed` != 0 flips the top bit so that the order also holds for int64 (torch has
+ * no uint64 reductions). */
+int bpmf_bp_pack_max_dev(const float *d_beam, const int32_t *d_arg, size_t N, int as_signed,
+                         bpmf_stream_t stream, uint64_t *d_packed);
+int bpmf_bp_unpack_max_dev(const uint64_t *d_packed, size_t N, int as_signed,
+                           bpmf_stream_t stream, float *d_beam, int32_t *d_arg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPMF_HIP_H */

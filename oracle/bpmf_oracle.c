@@ -1,0 +1,359 @@
+/*
+ * bpmf_oracle.c -- CPU restatement (C99 + OpenMP) of the two BPMF hot paths.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  It is the parity oracle and the
+ * "cpu_baseline" leg of bench.py.  Nothing under seismic_bpmf_amd/ may import,
+ * link or call it; the product path is the HIP library only.
+ *
+ * PARITY STATUS: "parity unpinned" for mf_* and bp_*.  The arithmetic of both
+ * hot paths lives in two un-vendored, un-pinned third-party packages
+ * (FastMatchedFilter -> import name fast_matched_filter, and beampower; bare
+ * names in /root/reference/pyproject.toml:28-29) that are absent from
+ * /root/reference and from this image, and the reference has no tests or golden
+ * vectors at that boundary.  The functions below therefore restate the
+ * *published* algorithm of those packages as far as the reference's own call
+ * sites, doc-strings and notebooks pin it:
+ *   MF : BPMF/similarity_search.py:526-533 (call), :540 (NaN scrub), :275,667,682
+ *        (cc index i <-> data sample i*step), BPMF/dataset.py:4818-4830
+ *        (network_sum=False layout (T, n_corr, S, C), unweighted CCs).
+ *   BP : BPMF/template_search.py:549-569 (call), :529-537 (strict / flexible),
+ *        tutorial/notebooks/5_backprojection.ipynb cells 27/30/32 (beam
+ *        definition), BPMF/dataset.py:2193-2196 (beam (K, N) layout).
+ * Every convention that the call sites do not pin (summation order, the
+ * stability threshold, the tie rule of the arg-max) is fixed HERE, written in
+ * DESIGN.md, and the HIP kernels are held to it bit for bit.
+ *
+ * All float arithmetic is written with explicit fmaf()/single operations and the
+ * file must be compiled with -ffp-contract=off so that the association order
+ * below is the one executed.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BPMF_CSUM_CHUNK 1024          /* hierarchical prefix-sum chunk (spec constant) */
+#define BPMF_STABILITY_THRESHOLD 1e-6f /* den <= this -> CC = 0 (no Inf/NaN)           */
+#define LAGV 16                        /* lags evaluated side by side (vector lanes)     */
+
+static void set_threads(int num_threads)
+{
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#else
+    (void)num_threads;
+#endif
+}
+
+int bpmf_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/*                            MATCHED FILTER                                  */
+/* ------------------------------------------------------------------------- */
+
+/* E_t[t,s,c] = sum_l tmpl^2, float32 fmaf chain, l ascending. */
+void mf_template_energy(const float *templates, size_t n_channels_total, size_t L,
+                        float *energy)
+{
+    for (size_t ch = 0; ch < n_channels_total; ch++) {
+        const float *x = templates + ch * L;
+        float acc = 0.0f;
+        for (size_t l = 0; l < L; l++) acc = fmaf(x[l], x[l], acc);
+        energy[ch] = acc;
+    }
+}
+
+/* csum[ch, n], n in [0, N]: prefix sum of data^2 in double, built hierarchically:
+ *   local[n]  = sequential sum inside the chunk of BPMF_CSUM_CHUNK samples that
+ *               holds sample n-1 (restarting from 0 at every chunk boundary),
+ *   off[q]    = sequential sum of the chunk totals 0..q-1,
+ *   csum[n]   = off[q(n)] + local[n]           (one rounding)
+ * The hierarchy (rather than one N-long sequential chain) is what makes the
+ * definition reproducible by a parallel device scan.  The squares are exact in
+ * double. */
+void mf_data_csum(const float *data, size_t n_channels, size_t N, double *csum)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t ch = 0; ch < n_channels; ch++) {
+        const float *d = data + ch * N;
+        double *cs = csum + ch * (N + 1);
+        double off = 0.0;
+        cs[0] = 0.0;
+        for (size_t q0 = 0; q0 < N; q0 += BPMF_CSUM_CHUNK) {
+            size_t q1 = q0 + BPMF_CSUM_CHUNK < N ? q0 + BPMF_CSUM_CHUNK : N;
+            double local = 0.0;
+            for (size_t n = q0; n < q1; n++) {
+                local += (double)d[n] * (double)d[n];
+                cs[n + 1] = off + local;
+            }
+            off += local;
+        }
+    }
+}
+
+/* E_d[ch, j] = (float)(csum[j+L] - csum[j]),  j in [0, N-L]. */
+void mf_window_energy(const double *csum, size_t n_channels, size_t N, size_t L,
+                      float *energy)
+{
+    if (N < L) return;
+    size_t nwin = N - L + 1;
+#pragma omp parallel for schedule(static)
+    for (size_t ch = 0; ch < n_channels; ch++) {
+        const double *cs = csum + ch * (N + 1);
+        float *e = energy + ch * nwin;
+        for (size_t j = 0; j < nwin; j++) e[j] = (float)(cs[j + L] - cs[j]);
+    }
+}
+
+/* Valid lag range of one template: every channel with w != 0 must have its
+ * whole window inside the data.  Returns 0 when the range is empty. */
+static int mf_valid_range(const int32_t *mv, const float *w, size_t n_ch, size_t step,
+                          size_t L, size_t N, size_t n_corr, size_t *i_first,
+                          size_t *i_last)
+{
+    int64_t mv_min = 0, mv_max = 0;
+    int any = 0;
+    for (size_t ch = 0; ch < n_ch; ch++) {
+        if (w[ch] == 0.0f) continue;
+        if (!any || mv[ch] < mv_min) mv_min = mv[ch];
+        if (!any || mv[ch] > mv_max) mv_max = mv[ch];
+        any = 1;
+    }
+    if (!any || N < L) return 0;
+    int64_t first = 0;
+    if (mv_min < 0) first = (-mv_min + (int64_t)step - 1) / (int64_t)step;
+    int64_t room = (int64_t)N - (int64_t)L - mv_max;
+    if (room < 0) return 0;
+    int64_t last = room / (int64_t)step;
+    if (last > (int64_t)n_corr - 1) last = (int64_t)n_corr - 1;
+    if (first > last) return 0;
+    *i_first = (size_t)first;
+    *i_last = (size_t)last;
+    return 1;
+}
+
+/*
+ * mf_cpu: sliding normalised cross-correlation, weighted network sum.
+ *   templates (T,S,C,L) f32, moveouts (T,S,C) i32, weights (T,S,C) f32,
+ *   data (S,C,N) f32, n_corr = (N-L)/step + 1
+ *   network_sum != 0 : out (T, n_corr)            cc_sum = sum_{s,c} w * cc
+ *   network_sum == 0 : out (T, n_corr, S, C)      cc (unweighted), 0 where w == 0
+ * Per valid (t, i) and channel with w != 0:
+ *   num = fmaf chain over l ascending of tmpl[l] * data[i*step + mv + l], from 0
+ *   den = E_t * E_d         (float multiply)
+ *   cc  = den > 1e-6f ? num / sqrtf(den) : 0
+ *   cc_sum = fmaf(w, cc, cc_sum)   channels in (s outer, c inner) order
+ * Lags outside the template's valid range stay exactly 0.
+ * Returns 0, or -1 on bad sizes / allocation failure.
+ */
+int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights,
+           const float *data, size_t step, size_t L, size_t N, size_t T, size_t S,
+           size_t C, size_t n_corr, int network_sum, int num_threads, float *out)
+{
+    if (step == 0 || L == 0 || N < L) return -1;
+    set_threads(num_threads);
+    const size_t n_ch = S * C;
+    const size_t nwin = N - L + 1;
+    float *e_t = (float *)malloc(T * n_ch * sizeof(float));
+    double *csum = (double *)malloc(n_ch * (N + 1) * sizeof(double));
+    float *e_d = (float *)malloc(n_ch * nwin * sizeof(float));
+    if (!e_t || !csum || !e_d) {
+        free(e_t); free(csum); free(e_d);
+        return -1;
+    }
+    mf_template_energy(templates, T * n_ch, L, e_t);
+    mf_data_csum(data, n_ch, N, csum);
+    mf_window_energy(csum, n_ch, N, L, e_d);
+    free(csum);
+
+    const size_t out_per_t = network_sum ? n_corr : n_corr * n_ch;
+    memset(out, 0, T * out_per_t * sizeof(float));
+
+    const size_t n_blocks = (n_corr + LAGV - 1) / LAGV;
+#pragma omp parallel for collapse(2) schedule(dynamic, 64)
+    for (size_t t = 0; t < T; t++) {
+        for (size_t blk = 0; blk < n_blocks; blk++) {
+            const int32_t *mv = moveouts + t * n_ch;
+            const float *w = weights + t * n_ch;
+            size_t i_first, i_last;
+            if (!mf_valid_range(mv, w, n_ch, step, L, N, n_corr, &i_first, &i_last))
+                continue;
+            size_t i0 = blk * LAGV;
+            if (i0 > i_last || i0 + LAGV <= i_first) continue;
+            float cc_sum[LAGV];
+            int ok[LAGV];
+            for (int v = 0; v < LAGV; v++) {
+                cc_sum[v] = 0.0f;
+                ok[v] = (i0 + v >= i_first) && (i0 + v <= i_last);
+            }
+            for (size_t ch = 0; ch < n_ch; ch++) {
+                if (w[ch] == 0.0f) continue;
+                const float *tp = templates + (t * n_ch + ch) * L;
+                const float *d = data + ch * N;
+                const float *ed = e_d + ch * nwin;
+                const float et = e_t[t * n_ch + ch];
+                float num[LAGV];
+                /* offsets of the LAGV windows; invalid lags are parked on a safe one */
+                size_t off[LAGV];
+                for (int v = 0; v < LAGV; v++) {
+                    size_t i = ok[v] ? i0 + v : i_first;
+                    off[v] = (size_t)((int64_t)(i * step) + mv[ch]);
+                    num[v] = 0.0f;
+                }
+                if (step == 1 && ok[0] && ok[LAGV - 1]) {
+                    const float *dw = d + off[0];
+                    for (size_t l = 0; l < L; l++) {
+                        const float tl = tp[l];
+                        for (int v = 0; v < LAGV; v++)
+                            num[v] = fmaf(tl, dw[l + v], num[v]);
+                    }
+                } else {
+                    for (size_t l = 0; l < L; l++) {
+                        const float tl = tp[l];
+                        for (int v = 0; v < LAGV; v++)
+                            num[v] = fmaf(tl, d[off[v] + l], num[v]);
+                    }
+                }
+                for (int v = 0; v < LAGV; v++) {
+                    if (!ok[v]) continue;
+                    float den = et * ed[off[v]];
+                    float cc = 0.0f;
+                    if (den > BPMF_STABILITY_THRESHOLD) cc = num[v] / sqrtf(den);
+                    if (network_sum)
+                        cc_sum[v] = fmaf(w[ch], cc, cc_sum[v]);
+                    else
+                        out[(t * n_corr + i0 + v) * n_ch + ch] = cc;
+                }
+            }
+            if (network_sum)
+                for (int v = 0; v < LAGV; v++)
+                    if (ok[v]) out[t * n_corr + i0 + v] = cc_sum[v];
+        }
+    }
+    free(e_t);
+    free(e_d);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/*                             BACKPROJECTION                                 */
+/* ------------------------------------------------------------------------- */
+
+/* Prestack U[s,p,t] = fmaf chain over c ascending of alpha[s,c,p] * feat[s,c,t]. */
+void bp_prestack(const float *features, const float *w_phases, size_t N, size_t S,
+                 size_t C, size_t P, float *prestack)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (size_t s = 0; s < S; s++) {
+        for (size_t p = 0; p < P; p++) {
+            float *u = prestack + (s * P + p) * N;
+            for (size_t t = 0; t < N; t++) {
+                float acc = 0.0f;
+                for (size_t c = 0; c < C; c++)
+                    acc = fmaf(w_phases[(s * C + c) * P + p],
+                               features[(s * C + c) * N + t], acc);
+                u[t] = acc;
+            }
+        }
+    }
+}
+
+/*
+ * bp_cpu: shift-and-stack beam power.
+ *   features (S,C,N) f32, moveouts (K,S,P) i32, w_phases (S,C,P) f32,
+ *   w_sources (K,S) f32
+ *   b_k(t) = fmaf chain, (s outer, p inner), of beta[k,s] * U[s,p,t+tau[k,s,p]],
+ *            stations with beta == 0 skipped.
+ *   out_of_bounds 0 = strict  : b_k(t) computed only if every used term has
+ *                               0 <= t+tau < N
+ *                 1 = flexible: out-of-range terms contribute nothing
+ *   reduce 0 = max : out_beam (N), out_arg (N): scan k ascending from (0, k=0),
+ *                    replace on strictly greater -> lowest k wins ties; samples
+ *                    where no beam is computed return (0, 0)
+ *          1 = none: out_beam (K,N); not-computed beams are 0; out_arg unused
+ */
+int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases,
+           const float *w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
+           int out_of_bounds, int reduce, int num_threads, float *out_beam,
+           int32_t *out_arg)
+{
+    if (N == 0 || K == 0) return -1;
+    set_threads(num_threads);
+    float *U = (float *)malloc(S * P * N * sizeof(float));
+    int64_t *tmin = (int64_t *)malloc(K * sizeof(int64_t));
+    int64_t *tmax = (int64_t *)malloc(K * sizeof(int64_t));
+    unsigned char *active = (unsigned char *)malloc(K);
+    if (!U || !tmin || !tmax || !active) {
+        free(U); free(tmin); free(tmax); free(active);
+        return -1;
+    }
+    bp_prestack(features, w_phases, N, S, C, P, U);
+    /* per source: is any station used, and the extreme moveouts of the used terms */
+    for (size_t k = 0; k < K; k++) {
+        int any = 0;
+        int64_t lo = 0, hi = 0;
+        for (size_t s = 0; s < S; s++) {
+            if (w_sources[k * S + s] == 0.0f) continue;
+            for (size_t p = 0; p < P; p++) {
+                int64_t tau = moveouts[(k * S + s) * P + p];
+                if (!any || tau < lo) lo = tau;
+                if (!any || tau > hi) hi = tau;
+                any = 1;
+            }
+        }
+        active[k] = (unsigned char)any;
+        tmin[k] = lo;
+        tmax[k] = hi;
+    }
+    const size_t TB = 512;
+    const size_t n_tb = (N + TB - 1) / TB;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (size_t tb = 0; tb < n_tb; tb++) {
+        const size_t t0 = tb * TB;
+        const size_t t1 = t0 + TB < N ? t0 + TB : N;
+        float best[512];
+        int32_t arg[512];
+        for (size_t j = 0; j < t1 - t0; j++) { best[j] = 0.0f; arg[j] = 0; }
+        for (size_t k = 0; k < K; k++) {
+            const float *beta = w_sources + k * S;
+            const int32_t *tau = moveouts + k * S * P;
+            for (size_t t = t0; t < t1; t++) {
+                int computed = active[k];
+                if (out_of_bounds == 0)
+                    computed = computed && ((int64_t)t + tmin[k] >= 0) &&
+                               ((int64_t)t + tmax[k] < (int64_t)N);
+                float b = 0.0f;
+                if (computed) {
+                    for (size_t s = 0; s < S; s++) {
+                        if (beta[s] == 0.0f) continue;
+                        for (size_t p = 0; p < P; p++) {
+                            int64_t x = (int64_t)t + tau[s * P + p];
+                            if (x < 0 || x >= (int64_t)N) continue; /* flexible only */
+                            b = fmaf(beta[s], U[(s * P + p) * N + (size_t)x], b);
+                        }
+                    }
+                }
+                if (reduce == 0) {
+                    if (computed && b > best[t - t0]) { best[t - t0] = b; arg[t - t0] = (int32_t)k; }
+                } else {
+                    out_beam[k * N + t] = computed ? b : 0.0f;
+                }
+            }
+        }
+        if (reduce == 0)
+            for (size_t t = t0; t < t1; t++) { out_beam[t] = best[t - t0]; out_arg[t] = arg[t - t0]; }
+    }
+    free(U); free(tmin); free(tmax); free(active);
+    return 0;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libbpmf_hip.so (the C ABI declared in include/bpmf_hip.h).
+
+Follows the reference's own binding style (BPMF/clib.py:14-84: CDLL + explicit argtypes,
+caller-allocated outputs) with one deliberate difference: a missing library is an ERROR
+here, not a printed warning -- this package has no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "lib", "libbpmf_hip.so")
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+_u64 = C.POINTER(C.c_uint64)
+_sz = C.c_size_t
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/bpmf_hip.h
+SIGNATURES = {
+    "bpmf_last_error": (C.c_char_p, []),
+    "bpmf_device_count": (C.c_int, []),
+    "bpmf_device_info": (C.c_int, [C.c_int, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "bpmf_mf_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _sz]),
+    "bpmf_mf_prepare_data_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp]),
+    "bpmf_mf_run_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int,
+                                  C.c_int, _vp, _sz, _vp, _vp]),
+    "bpmf_mf_run": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int,
+                              C.c_int, _f]),
+    "bpmf_bp_plan_create": (C.c_int, [_i, _f, _sz, _sz, _sz, C.c_int, C.c_int32, C.POINTER(_vp)]),
+    "bpmf_bp_plan_destroy": (None, [_vp]),
+    "bpmf_bp_workspace_bytes": (_sz, [_vp, _sz, _sz]),
+    "bpmf_bp_run_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "bpmf_bp_run": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int, C.c_int,
+                              _f, _i]),
+    "bpmf_bp_pack_max_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
+    "bpmf_bp_unpack_max_dev": (C.c_int, [_vp, _sz, C.c_int, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class BpmfHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise BpmfHipError(
+            f"{LIBPATH} is missing: build it with `python -m seismic_bpmf_amd.build` "
+            "(needs hipcc).  There is no CPU fallback in this package.")
+    # torch ships its own libamdhip64 (same SONAME); importing it first makes the
+    # dynamic loader bind this library to the runtime torch already uses, so that
+    # torch streams / device pointers are valid in our launches.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the host-pointer API
+        pass
+    handle = C.CDLL(LIBPATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().bpmf_last_error().decode("utf-8", "replace")
+        raise BpmfHipError(f"{what} failed (status {rc}): {msg}")
+
+
+def device_count():
+    n = lib().bpmf_device_count()
+    if n < 0:
+        check(n, "bpmf_device_count")
+    return n
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    mem = _sz(0)
+    cus = C.c_int(0)
+    check(lib().bpmf_device_info(device, name, 256, C.byref(mem), C.byref(cus)), "bpmf_device_info")
+    return {"name": name.value.decode(), "total_mem_bytes": mem.value, "compute_units": cus.value}
