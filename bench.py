@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Benchmark of the two BPMF hot paths on MI355X (contract: see the task brief / DESIGN.md s6).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM:
+  * headline (``value``): matched filter, BASELINE.json configs[1]
+    (500 templates x 20 stations x 3 components, 256-sample templates, 1 day @ 100 Hz,
+    step 1): one step = data preparation (window energies) + CC of all templates; the
+    (T, n_corr) CC matrix stays in HBM.  metric = million network-CC-samples/s.
+  * secondary (``bp`` object): backprojection, configs[2] (50 000 sources x 20 stations x 3
+    components x 2 phases, 1 day @ 50 Hz, 10-closest-station weights, reduce="max", strict).
+N > 1 is weak scaling: every rank owns its own shard of templates (MF) / of the source grid
+(BP) against a replicated day of data; MF has no data-path collective, BP ends each step with
+the packed (max, arg-max) all-reduce over RCCL.
+
+The JSON line also carries ``roofline`` (dominant kernel, HIP events recorded on the launch
+stream inside the timed region) and ``cpu_baseline`` (the CPU oracle timed on this box's host
+cores on a bounded sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+LDS_B32_PEAK_TBS = 256 * 128 * 2.4e9 / 1e12   # ds_read_b32: 128 B/clk/CU x 256 CU x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mf-config", default="cfg2")
+    ap.add_argument("--bp-config", default="cfg3")
+    ap.add_argument("--skip-bp", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target duration of the cpu_baseline sample")
+    ap.add_argument("--templates", type=int, default=0, help="override T (debug)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------ synthetic inputs ---
+def mf_inputs_device(cfg, device, seed):
+    """Device-side equivalent of synthetic.make_mf_inputs (same conditioning, torch RNG)."""
+    T, S, C, L, N = cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"]
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    data = torch.randn((S, C, N), device=device, generator=g)
+    raw = torch.randn((T, S, C, L + 4), device=device, generator=g)
+    tmpl = sum(raw[..., k:k + L] for k in range(5))
+    tmpl = tmpl - tmpl.mean(dim=-1, keepdim=True)
+    tmpl = (tmpl / tmpl.std(dim=-1, keepdim=True)).contiguous()
+    mv_p = torch.randint(0, 1501, (T, S), device=device, generator=g)
+    mv_s = mv_p + torch.randint(0, 1501, (T, S), device=device, generator=g)
+    mv = torch.empty((T, S, C), dtype=torch.int32, device=device)
+    mv[:, :, 0] = mv_p
+    mv[:, :, 1:] = mv_s[:, :, None]
+    w = torch.full((T, S, C), 1.0 / (S * C), device=device)
+    # plant 5 scaled copies of every template (events) before the per-channel normalisation
+    n_ev = 5
+    slots = torch.randint(0, (N - L - 3002) // (4 * L), (T, n_ev), device=device, generator=g)
+    amps = 1.5 + 2.5 * torch.rand((T, n_ev), device=device, generator=g)
+    ar = torch.arange(L, device=device)
+    for t in range(T):
+        for e in range(n_ev):
+            j = (slots[t, e] * 4 * L + mv[t].long())[..., None] + ar        # (S, C, L)
+            data.scatter_add_(2, j, amps[t, e] * tmpl[t])
+    data /= data.std(dim=-1, keepdim=True)
+    return tmpl, mv, w, data
+
+
+def bp_inputs(cfg, device, seed, rank, world):
+    from seismic_bpmf_amd import synthetic as syn
+    geo = syn.make_bp_geometry(cfg["grid"], cfg["S"], cfg["P"], cfg["sr"], seed=seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1)
+    S, C, N = cfg["S"], cfg["C"], cfg["N"]
+    feat = torch.randn((S, C, N), device=device, generator=g).abs_()
+    wp = torch.as_tensor(syn.phase_weights(S, C, cfg["P"]), device=device)
+    # 20 planted events: Gaussian bumps along the moveouts of random sources
+    rng = np.random.default_rng(seed + 2)
+    sig = 0.2 * cfg["sr"]
+    half = int(4 * sig)
+    bump = torch.as_tensor(8.0 * np.exp(-0.5 * (np.arange(-half, half + 1) / sig) ** 2),
+                           dtype=torch.float32, device=device)
+    tau = geo["moveouts"]
+    for _ in range(20):
+        k0 = int(rng.integers(0, tau.shape[0]))
+        t0 = int(rng.integers(half, N - int(tau.max()) - 2 * half))
+        for s in range(S):
+            for c in range(C):
+                x = t0 + int(tau[k0, s, 0 if c == 0 else 1])
+                feat[s, c, x - half:x + half + 1] += bump
+    return geo, feat, wp
+
+
+# ----------------------------------------------------------------------- CPU baseline ---
+def cpu_baseline(cfg, target_seconds):
+    """Time the CPU oracle (rebuilt -march=native for this host) on a bounded MF sample."""
+    from oracle import oracle
+    from seismic_bpmf_amd import synthetic as syn
+    try:
+        lib = oracle.load(oracle.build(march="native", out_dir="/tmp/bpmf_oracle_native"))
+        march = "native"
+    except Exception:
+        lib = oracle.load()
+        march = "x86-64-v3"
+    cores = lib.bpmf_oracle_max_threads()
+    S, C, L = cfg["S"], cfg["C"], cfg["L"]
+    # calibrate on a tiny sample, then size N (whole hours of the same day) for ~target seconds
+    T = min(cfg["T"], 8)
+    probe = syn.make_mf_inputs(T, S, C, L, 60_000, seed=7, n_events=0)
+    t0 = time.perf_counter()
+    oracle.matched_filter(probe["templates"], probe["moveouts"], probe["weights"], probe["data"], 1,
+                          lib=lib)
+    dt = time.perf_counter() - t0
+    rate = T * (60_000 - L + 1) / dt
+    n = int(min(cfg["N"], max(120_000, rate * target_seconds / T)))
+    n -= n % 1000
+    smp = syn.make_mf_inputs(T, S, C, L, n, seed=8, n_events=0)
+    t0 = time.perf_counter()
+    oracle.matched_filter(smp["templates"], smp["moveouts"], smp["weights"], smp["data"], 1, lib=lib)
+    dt = time.perf_counter() - t0
+    value = T * (n - L + 1) / dt / 1e6
+    return {"value": round(value, 4), "unit": "million network-CC-samples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n} samples of the "
+                      f"{cfg['N']}-sample day, step 1; oracle/bpmf_oracle.c mf_cpu (C99+OpenMP, "
+                      f"gcc -O3 -march={march}), {dt:.1f} s wall"}
+
+
+# ------------------------------------------------------------------------------- main ---
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import seismic_bpmf_amd as sb
+    from seismic_bpmf_amd import _lib, synthetic as syn
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn, steps, warmup):
+        for _ in range(warmup):
+            step_fn()
+        barrier()
+        _lib.profile_enable(True)          # clears the launch log
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        _lib.profile_enable(False)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # ---------------------------------------------------------------- matched filter
+    cfg = dict(syn.MF_CONFIGS[args.mf_config])
+    if args.templates:
+        cfg["T"] = args.templates
+    T, S, C, L, N = cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"]
+    n_corr = N - L + 1
+    tmpl, mv, w, data = mf_inputs_device(cfg, device, 20260928 + 1000 * rank)
+    mf = sb.MatchedFilterGPU(device=local_rank)
+    mf.set_data(data)
+    cc = torch.empty((T, n_corr), dtype=torch.float32, device=device)
+
+    def mf_step():
+        mf._prepared_for = None            # a step includes the per-day data preparation
+        mf.run(tmpl, mv, w, 1, out=cc)
+
+    mf_dt = timed(mf_step, args.steps, args.warmup)
+    mf_kernel_ms = _lib.profile_times_ms(_lib.KERNEL_MF_MAIN)
+    mf_value = world * T * n_corr * args.steps / mf_dt / 1e6
+    flop_per_launch = 2.0 * L * S * C * T * n_corr          # direct-form, all channels weighted
+    k_ms = float(np.mean(mf_kernel_ms)) if mf_kernel_ms else float("nan")
+    achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "mf_main_pmc.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "mf_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
+                "traffic": traffic, "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
+                "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",
+                "hbm_frac_informational": round(
+                    4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    # sanity inside the bench: planted events must be the row maxima region (cheap check)
+    peak = float(cc[0].max().item())
+    del cc, mf
+    torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- backprojection
+    bp_obj = None
+    if not args.skip_bp:
+        bcfg = dict(syn.BP_CONFIGS[args.bp_config])
+        geo, feat, wp = bp_inputs(bcfg, device, 20260928, rank, world)
+        K_all = geo["moveouts"].shape[0]
+        # weak scaling: every rank owns a full cfg3-sized tile of the (world x larger) grid
+        bf = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"], device=local_rank,
+                              source_id_offset=rank * K_all)
+        Nb = bcfg["N"]
+        beam = torch.empty(Nb, dtype=torch.float32, device=device)
+        arg = torch.empty(Nb, dtype=torch.int32, device=device)
+
+        def bp_step():
+            bf.run(feat, wp, "max", "strict", out=(beam, arg))
+            if dist is not None:            # the path's one real exchange step
+                packed = bf.pack_max(beam, arg)
+                dist.all_reduce(packed, op=dist.ReduceOp.MAX)
+                bf.unpack_max(packed)
+
+        bp_dt = timed(bp_step, args.steps, args.warmup)
+        bp_ms = _lib.profile_times_ms(_lib.KERNEL_BP_BEAM)
+        s_act = float((geo["weights_sources"] != 0).sum(axis=1).mean())
+        bk = float(np.mean(bp_ms)) if bp_ms else float("nan")
+        gather_tbs = 4.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12
+        bp_obj = {"metric": "grid-points x samples / s", "value": world * K_all * Nb * args.steps / bp_dt,
+                  "ms_per_step": round(bp_dt / args.steps * 1e3, 3),
+                  "config": {"workload": f"BASELINE configs[2]: {K_all} sources x {bcfg['S']} stations x "
+                                         f"{bcfg['C']} comp x {bcfg['P']} phases, N={Nb} (1 day @ {bcfg['sr']:g} Hz), "
+                                         f"{s_act:.1f} active stations/source, reduce=max, strict"},
+                  "roofline": {"kernel": "bp_beam_kernel", "bound": "lds-gather", "achieved": round(gather_tbs, 2),
+                               "peak": round(LDS_B32_PEAK_TBS, 1), "unit": "TB/s",
+                               "frac": round(gather_tbs / LDS_B32_PEAK_TBS, 4), "avg_launch_ms": round(bk, 3),
+                               "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
+                               "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+        bf.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        cpu = cpu_baseline(cfg, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "million network-CC-samples/s (matched filter)",
+            "value": round(mf_value, 2), "unit": "M CC-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(mf_dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {T} templates x {S} stations x {C} comp, "
+                                   f"L={L}, N={N} (1 day @ 100 Hz), step 1, per GPU",
+                       "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
+                       "parallelism": f"templates sharded x{world}" if world > 1 else "single GPU",
+                       "row0_peak_cc": round(peak, 4)},
+            "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,17 @@ int bpmf_device_count(void);
 int bpmf_device_info(int device, char *name, size_t name_len, size_t *total_mem_bytes,
                      int *compute_units);
 
+/* Optional timing of the dominant kernel of each path with HIP events recorded on the
+ * caller's stream (used by bench.py for the roofline figure; off by default).
+ * Each launch of the kernel logs its own event pair; read them after synchronising.
+ * (The reference only has wall-clock prints: BPMF/similarity_search.py:789-806.) */
+#define BPMF_KERNEL_MF_MAIN 0
+#define BPMF_KERNEL_BP_BEAM 1
+#define BPMF_KERNEL_COUNT 2
+void bpmf_profile_enable(int enable); /* also clears the log */
+int bpmf_profile_count(int which_kernel); /* launches logged since enable */
+int bpmf_profile_get_ms(int which_kernel, int launch_index, float *milliseconds);
+
 /* ------------------------------------------------------------ matched filter --- */
 /*
  * Serves fast_matched_filter.matched_filter(templates, moveouts, weights, data, step,

@@ -21,6 +21,9 @@ SIGNATURES = {
     "bpmf_last_error": (C.c_char_p, []),
     "bpmf_device_count": (C.c_int, []),
     "bpmf_device_info": (C.c_int, [C.c_int, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "bpmf_profile_enable": (None, [C.c_int]),
+    "bpmf_profile_count": (C.c_int, [C.c_int]),
+    "bpmf_profile_get_ms": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "bpmf_mf_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _sz]),
     "bpmf_mf_prepare_data_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp]),
     "bpmf_mf_run_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int,
@@ -88,3 +91,20 @@ def device_info(device=0):
     cus = C.c_int(0)
     check(lib().bpmf_device_info(device, name, 256, C.byref(mem), C.byref(cus)), "bpmf_device_info")
     return {"name": name.value.decode(), "total_mem_bytes": mem.value, "compute_units": cus.value}
+
+
+KERNEL_MF_MAIN, KERNEL_BP_BEAM = 0, 1
+
+
+def profile_enable(on=True):
+    lib().bpmf_profile_enable(1 if on else 0)
+
+
+def profile_times_ms(which):
+    """Durations (ms) of every logged launch of dominant kernel `which` since profile_enable."""
+    out = []
+    for i in range(lib().bpmf_profile_count(which)):
+        ms = C.c_float(0.0)
+        check(lib().bpmf_profile_get_ms(which, i, C.byref(ms)), "bpmf_profile_get_ms")
+        out.append(ms.value)
+    return out

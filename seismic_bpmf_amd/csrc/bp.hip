@@ -411,10 +411,12 @@ int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t st
                                            (int)BP_LDS_MAX));
     const size_t tile = (size_t)BP_THREADS * TPT;
     dim3 grid((unsigned)((N + tile - 1) / tile));
+    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, pl->d_wins, pl->d_srcs, pl->d_beta, pl->d_off,
         pl->A, (int)pl->P, pl->default_arg, beam, arg);
     BPMF_LAUNCH_CHECK();
+    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 

@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...);
 constexpr int CSUM_CHUNK = 1024;             // spec constant, see oracle/bpmf_oracle.c
 constexpr float STABILITY_THRESHOLD = 1e-6f; // den <= this -> CC = 0
 
+// bench hook: events around the dominant kernels (util.hip)
+void profile_mark(int which, int edge, hipStream_t stream);
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace bpmf

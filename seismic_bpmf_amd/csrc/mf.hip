@@ -393,6 +393,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     if (!network_sum)
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
 
+    profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     const size_t lds = mf_lds_bytes((int)L);
     const size_t n_lag_blocks = (n_corr + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
     const bool use_mfma = step == 1 && !(flags & BPMF_MF_FORCE_DIRECT) && lds <= 64 * 1024 &&
@@ -423,6 +424,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                 (long long)step, (int)L, (long long)N, (int)n_ch, (long long)n_corr, d_cc_out);
     }
     BPMF_LAUNCH_CHECK();
+    profile_mark(BPMF_KERNEL_MF_MAIN, 1, stream);
     return 0;
 }
 

@@ -22,6 +22,65 @@ void set_error(const char* fmt, ...)
 
 }  // namespace bpmf
 
+// ---- optional per-kernel timing (bench.py's roofline leg) -------------------------
+// Every launch of a dominant kernel gets its own start/stop event pair, recorded on the
+// launch stream without synchronising; the pairs are read back after the timed region.
+namespace bpmf {
+constexpr int PROFILE_MAX_LAUNCHES = 512;
+struct ProfileLog {
+    hipEvent_t ev[PROFILE_MAX_LAUNCHES][2];
+    int created = 0;  // event pairs that exist
+    int count = 0;    // launches recorded since the last reset
+    bool open = false;
+};
+static bool g_profile = false;
+static ProfileLog g_log[BPMF_KERNEL_COUNT];
+
+void profile_mark(int which, int edge, hipStream_t stream)
+{
+    if (!g_profile || which < 0 || which >= BPMF_KERNEL_COUNT) return;
+    ProfileLog& lg = g_log[which];
+    if (edge == 0) {
+        lg.open = false;
+        if (lg.count >= PROFILE_MAX_LAUNCHES) return;
+        if (lg.count >= lg.created) {
+            if (hipEventCreate(&lg.ev[lg.created][0]) != hipSuccess) return;
+            if (hipEventCreate(&lg.ev[lg.created][1]) != hipSuccess) return;
+            lg.created++;
+        }
+        lg.open = hipEventRecord(lg.ev[lg.count][0], stream) == hipSuccess;
+    } else if (lg.open) {
+        if (hipEventRecord(lg.ev[lg.count][1], stream) == hipSuccess) lg.count++;
+        lg.open = false;
+    }
+}
+}  // namespace bpmf
+
+extern "C" void bpmf_profile_enable(int enable)
+{
+    bpmf::g_profile = enable != 0;
+    for (int k = 0; k < BPMF_KERNEL_COUNT; ++k) { bpmf::g_log[k].count = 0; bpmf::g_log[k].open = false; }
+}
+
+extern "C" int bpmf_profile_count(int which)
+{
+    if (which < 0 || which >= BPMF_KERNEL_COUNT) return -1;
+    return bpmf::g_log[which].count;
+}
+
+extern "C" int bpmf_profile_get_ms(int which, int index, float* ms)
+{
+    if (which < 0 || which >= BPMF_KERNEL_COUNT || !ms || index < 0 ||
+        index >= bpmf::g_log[which].count) {
+        bpmf::set_error("bpmf_profile_get_ms: no launch %d recorded for kernel %d", index, which);
+        return -1;
+    }
+    BPMF_HIP_CHECK(hipEventSynchronize(bpmf::g_log[which].ev[index][1]));
+    BPMF_HIP_CHECK(hipEventElapsedTime(ms, bpmf::g_log[which].ev[index][0],
+                                       bpmf::g_log[which].ev[index][1]));
+    return 0;
+}
+
 extern "C" const char* bpmf_last_error(void) { return bpmf::last_error_buf(); }
 
 // HIP analogue of the reference's device probe (BPMF/GPU.cu:8-24).

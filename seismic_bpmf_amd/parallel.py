@@ -1,0 +1,131 @@
+"""Multi-GPU sharding of the two hot paths: one process per GPU, torch.distributed (RCCL).
+
+Neither path has a collective in the reference (there is no distributed code in BPMF at all;
+its back-ends split work across GPUs inside one process).  Both shard embarrassingly
+(SURVEY.md section 8e):
+
+* matched filter -- templates are independent (the reference itself chunks them sequentially,
+  BPMF/similarity_search.py:773-790): rank r owns a contiguous block of templates and the whole
+  day of data.  No data-path collective; the only exchange is an all-gather of fixed-capacity
+  peak records (KBs), because the CC matrix itself (17-170 GB) must never cross xGMI.
+* backprojection -- sources are independent except for the per-sample max / arg-max: rank r
+  owns a contiguous tile of the source grid (global ids via ``source_id_offset``) and the whole
+  feature array; one all-reduce(MAX) of packed 64-bit keys (8 bytes per time sample) merges the
+  per-rank maxima.  The key order is (beam ascending, source id descending) so that ties resolve
+  to the lowest source id -- the same rule as a sequential scan over the full grid.
+
+The key packing is written with plain torch integer ops so that exactly the same code runs on
+HIP tensors over RCCL and on CPU tensors over gloo (tests/test_dist_gloo.py).
+"""
+import torch
+
+_SIGN = -0x8000000000000000  # int64 with only the top bit set
+
+
+def shard_bounds(n, world):
+    """Balanced contiguous partition of range(n): list of (start, stop), len == world."""
+    base, rem = divmod(int(n), int(world))
+    out, start = [], 0
+    for r in range(world):
+        stop = start + base + (1 if r < rem else 0)
+        out.append((start, stop))
+        start = stop
+    return out
+
+
+def pack_max_keys(beam, arg):
+    """(float32 beam, int32 source id) -> int64 keys, ordered by (beam asc, id desc)."""
+    bits = beam.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    neg = (bits & 0x80000000) != 0
+    ordered = torch.where(neg, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
+    low = 0xFFFFFFFF - (arg.to(torch.int64) & 0xFFFFFFFF)
+    key = (ordered << 32) | low          # unsigned order, stored in int64 bit pattern
+    return key ^ _SIGN                    # flip the top bit: unsigned order == signed order
+
+
+def unpack_max_keys(packed):
+    key = packed ^ _SIGN
+    ordered = (key >> 32) & 0xFFFFFFFF
+    pos = (ordered & 0x80000000) != 0
+    bits = torch.where(pos, ordered & 0x7FFFFFFF, (~ordered) & 0xFFFFFFFF)
+    bits32 = torch.where(bits >= 0x80000000, bits - 0x100000000, bits).to(torch.int32)
+    beam = bits32.view(torch.float32)
+    arg = (0xFFFFFFFF - (key & 0xFFFFFFFF)).to(torch.int32)
+    return beam, arg
+
+
+def allreduce_max(beam, arg, group=None):
+    """Global (max beam, lowest arg-max id) across ranks; returns new tensors on every rank."""
+    import torch.distributed as dist
+    packed = pack_max_keys(beam, arg)
+    dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
+    return unpack_max_keys(packed)
+
+
+def allgather_records(records, count, group=None):
+    """All-gather of fixed-capacity record buffers.
+
+    records: (capacity, width) tensor, the first `count` rows valid.  Returns the list of
+    per-rank valid slices (every rank gets all of them).
+    """
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([int(count)], dtype=torch.int64, device=records.device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    bufs = [torch.empty_like(records) for _ in range(world)]
+    dist.all_gather(bufs, records.contiguous(), group=group)
+    return [b[: int(c.item())] for b, c in zip(bufs, counts)]
+
+
+class ShardedBeamformer:
+    """Backprojection with the source grid tiled across the ranks of a process group."""
+
+    def __init__(self, moveouts, weights_sources, group=None, device=None):
+        import torch.distributed as dist
+        from .beampower import BeamformerGPU
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.K = moveouts.shape[0]
+        self.k0, self.k1 = shard_bounds(self.K, self.world)[self.rank]
+        self.local = BeamformerGPU(moveouts[self.k0:self.k1], weights_sources[self.k0:self.k1],
+                                   device=device, source_id_offset=self.k0)
+
+    def run(self, features, weights_phases, reduce="max", out_of_bounds="strict"):
+        if reduce == "none":
+            # no exchange: every rank returns its own (K_local, N) slab
+            return self.local.run(features, weights_phases, "none", out_of_bounds)
+        beam, arg = self.local.run(features, weights_phases, "max", out_of_bounds)
+        if self.world == 1:
+            return beam, arg
+        return allreduce_max(beam, arg, self.group)
+
+    def close(self):
+        self.local.close()
+
+
+class ShardedMatchedFilter:
+    """Matched filter with the templates block-partitioned across the ranks of a group."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        from .matched_filter import MatchedFilterGPU
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.local = MatchedFilterGPU(device=device)
+
+    def set_data(self, data):
+        self.local.set_data(data)
+
+    def template_range(self, n_templates):
+        return shard_bounds(n_templates, self.world)[self.rank]
+
+    def run(self, templates, moveouts, weights, step=1, network_sum=True):
+        """CC of this rank's block of templates; returns (t0, t1, cc_local)."""
+        t0, t1 = self.template_range(templates.shape[0])
+        if t1 == t0:
+            return t0, t1, None
+        cc = self.local.run(templates[t0:t1], moveouts[t0:t1], weights[t0:t1], step, network_sum)
+        return t0, t1, cc

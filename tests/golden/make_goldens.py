@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (runs only in the build container).
+
+What is pinned here: the native helpers of BPMF/libc.c and the
+NumPy-only Python functions adjacent to the hot paths.  The two hot paths themselves cannot
+be pinned -- their arithmetic lives in third-party packages that are not in /root/reference.
+
+How: (1) the reference's own BPMF/libc.c is compiled where it lies by oracle/Makefile
+(`make ref` -> oracle/_ref/libc.so) and driven through the reference's own ctypes wrappers
+(BPMF/clib.py) -- always with num_threads=1, because its OpenMP loops race; (2) the reference
+Python package is imported with stub modules for the dependencies this image lacks
+(h5py, obspy, fast_matched_filter, beampower), from a scratch directory that holds a copy of
+the tutorial's parameter file, because BPMF reads BPMF_parameters.cfg from the CWD at import.
+
+Only inputs and outputs are stored (data, not source).  Usage: python tests/golden/make_goldens.py
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def import_reference():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True,
+                   capture_output=True)
+    scratch = tempfile.mkdtemp(prefix="bpmf_gold_")
+    shutil.copy(os.path.join(REF, "tutorial/notebooks/BPMF_parameters.cfg"), scratch)
+    os.chdir(scratch)
+    for m in ["h5py", "obspy", "obspy.core", "obspy.signal", "obspy.signal.filter",
+              "fast_matched_filter", "beampower", "matplotlib", "matplotlib.pyplot",
+              "matplotlib.colors", "matplotlib.cm", "matplotlib.dates", "matplotlib.ticker",
+              "mpl_toolkits", "mpl_toolkits.axes_grid1", "mpl_toolkits.axes_grid1.inset_locator",
+              "matplotlib.colorbar", "matplotlib.gridspec", "matplotlib.patches"]:
+        try:
+            __import__(m)
+        except Exception:
+            sys.modules[m] = MagicMock()
+    sys.path.insert(0, REF)
+    import BPMF
+    from BPMF import clib
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libc.so"))
+    f, i = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.kurtosis.argtypes = [f, C.c_int, C.c_int, C.c_int, C.c_int, f]
+    lib.select_cc_indexes.argtypes = [f, f, C.c_size_t, C.c_size_t, i]
+    lib.time_dependent_threshold.argtypes = [f, f, C.c_float, C.c_size_t, C.c_size_t, C.c_size_t,
+                                             C.c_int, f]
+    for fn in ("find_similar_moveouts", "find_similar_moveouts2"):
+        getattr(lib, fn).argtypes = [f] * 5 + [C.c_float] + [C.c_size_t] * 5 + [C.c_int, i]
+    clib._libc = lib
+    clib.cpu_loaded = True
+    return BPMF, clib
+
+
+def cc_like_series(rng, n, gaps=True):
+    """Something shaped like a network CC series: small Gaussian values, a few spikes, zeros."""
+    x = (0.02 * rng.standard_normal(n)).astype(np.float32)
+    for p in rng.integers(100, n - 100, 12):
+        x[p - 2:p + 3] += np.float32(rng.uniform(0.2, 0.8)) * np.array([.3, .7, 1, .7, .3], np.float32)
+    if gaps:
+        a = int(n * 0.4)
+        x[a:a + n // 20] = 0.0
+        x[:50] = 0.0
+    return x
+
+
+def main():
+    BPMF, clib = import_reference()
+    from BPMF import similarity_search, template_search, utils
+    rng = np.random.default_rng(20260928)
+    out = {}
+
+    # ---- libc.c: time_dependent_threshold (rms) ------------------------------------
+    cases = []
+    for n, window, overlap, gaps in [(200_000, 18_000, 0.0, True), (200_000, 18_000, 0.25, True),
+                                     (150_000, 9_000, 0.0, False), (120_000, 12_000, 0.5, True),
+                                     (86_400, 4_500, 0.2, False)]:
+        shift = int((1.0 - overlap) * window)
+        nsw = (n - (window - shift)) // shift
+        assert (n - shift - 1) // shift <= nsw - 1, "case would read out of bounds in the reference"
+        x = cc_like_series(rng, n, gaps)
+        wn = rng.standard_normal(500).astype(np.float32)
+        thr = clib.time_dependent_threshold(x, window, 8.0, overlap=overlap, white_noise=wn,
+                                            num_threads=1)
+        cases.append(dict(x=x, white_noise=wn, window=window, overlap=overlap, num_dev=8.0, thr=thr))
+    np.savez_compressed(os.path.join(HERE, "tdt_rms.npz"),
+                        **{f"{k}_{j}": np.asarray(v) for j, c in enumerate(cases) for k, v in c.items()},
+                        n_cases=len(cases))
+
+    # ---- libc.c: select_cc_indexes ---------------------------------------------------
+    cases = []
+    for n, win in [(50_000, 500), (50_000, 37), (20_000, 5_000), (3_000, 1)]:
+        x = cc_like_series(rng, n, gaps=False)
+        thr = (0.1 + 0.02 * rng.random(n)).astype(np.float32)
+        sel = clib.select_cc_indexes(x, thr, win)
+        cases.append(dict(x=x, thr=thr, win=win, sel=sel))
+    x = cc_like_series(rng, 10_000, gaps=False)
+    cases.append(dict(x=x, thr=np.float32(0.15) * np.ones(10_000, np.float32), win=200,
+                      sel=clib.select_cc_indexes(x, 0.15, 200)))
+    np.savez_compressed(os.path.join(HERE, "select_cc_indexes_c.npz"),
+                        **{f"{k}_{j}": np.asarray(v) for j, c in enumerate(cases) for k, v in c.items()},
+                        n_cases=len(cases))
+
+    # ---- libc.c: kurtosis --------------------------------------------------------------
+    sig = rng.standard_normal((2, 3, 3000)).astype(np.float32)
+    sig[1, 0, 1000:1400] = 0.0
+    sig[0, 2, 500:520] *= 15.0
+    np.savez_compressed(os.path.join(HERE, "kurtosis.npz"), signal=sig, W=200,
+                        kurto=clib.kurtosis(sig, 200))
+
+    # ---- libc.c: find_similar_moveouts / find_similar_moveouts2 ----------------------------
+    nx, ny, nz, S = 12, 10, 5, 9
+    lon, lat, dep = np.meshgrid(np.linspace(30.0, 30.6, nx), np.linspace(40.0, 40.5, ny),
+                                np.linspace(0, 20, nz), indexing="ij")
+    lon, lat, dep = lon.ravel(), lat.ravel(), dep.ravel()
+    sta = np.stack([rng.uniform(30.0, 30.6, S), rng.uniform(40.0, 40.5, S)], 1)
+    dist = np.sqrt(((lon[:, None] - sta[None, :, 0]) * 85.0) ** 2 +
+                   ((lat[:, None] - sta[None, :, 1]) * 111.0) ** 2 + dep[:, None] ** 2)
+    mv = (dist / 6.0).astype(np.float32)
+    cell_lon = np.linspace(29.99, 30.61, 4).astype(np.float32)
+    cell_lat = np.linspace(39.99, 40.51, 3).astype(np.float32)
+    res = {}
+    for method in ("closest", "smallest"):
+        for thr, ndiff in [(0.25, 5), (0.6, 9)]:
+            red = clib.find_similar_sources(mv, lon.astype(np.float32), lat.astype(np.float32),
+                                            cell_lon, cell_lat, thr, num_threads=1,
+                                            num_stations_for_diff=ndiff, method=method)
+            res[f"red_{method}_{ndiff}"] = np.asarray(red)
+            res[f"thr_{method}_{ndiff}"] = thr
+    np.savez_compressed(os.path.join(HERE, "similar_sources.npz"), moveouts=mv,
+                        lon=lon.astype(np.float32), lat=lat.astype(np.float32), cell_lon=cell_lon,
+                        cell_lat=cell_lat, **res)
+
+    # ---- utils.sec_to_samp, utils._detect_peaks --------------------------------------------
+    t = np.concatenate([np.linspace(-30, 30, 601), rng.uniform(-100, 100, 400),
+                        np.array([0.0, 0.04, -0.04, 7.96, 7.999999, 12.0 / 25.0])])
+    s2s = {f"sr_{sr}": utils.sec_to_samp(t, sr=float(sr)) for sr in (25, 50, 100)}
+    peaks = {}
+    series = [np.array([0, 1, 0, 2, 0, 3, 0, 2, 0, 1, 0], dtype=np.float64),
+              np.abs(rng.standard_normal(5000)) + 5 * (rng.random(5000) > 0.995),
+              np.round(np.abs(rng.standard_normal(4000)), 1),  # plateaus and exact ties
+              cc_like_series(rng, 20_000, gaps=True).astype(np.float64)]
+    for j, x in enumerate(series):
+        peaks[f"x_{j}"] = x
+        for mpd in (1, 2, 25, 300):
+            peaks[f"ind_{j}_{mpd}"] = utils._detect_peaks(x, mpd=mpd)
+    np.savez_compressed(os.path.join(HERE, "host_helpers.npz"), t=t, **s2s, **peaks,
+                        n_series=len(series))
+
+    # ---- Beamformer.find_detections peak logic (template_search.py:604-627) -----------------
+    # dataset.Event needs obspy, so the index logic is replayed here from the reference's
+    # own _detect_peaks plus a NumPy transliteration of the regrouping lines.
+    det = {}
+    for j, (n, mpd) in enumerate([(20_000, 250), (20_000, 40), (5_000, 1000)]):
+        mb = (np.abs(rng.standard_normal(n)) + 6 * (rng.random(n) > 0.998) *
+              rng.random(n)).astype(np.float32)
+        src = rng.integers(0, 5000, n).astype(np.int32)
+        thr = np.full(n, 3.0, dtype=np.float32)
+        pk = utils._detect_peaks(mb, mpd=mpd)
+        pk = pk[mb[pk] > thr[pk]]
+        for i in range(len(pk)):
+            idx = np.int32(np.arange(max(0, pk[i] - mpd / 2), min(pk[i] + mpd / 2, len(mb))))
+            upd = np.where(pk == pk[i])[0]
+            pk[upd] = np.argmax(mb[idx]) + idx[0]
+        pk = np.unique(pk)
+        det.update({f"maxbeam_{j}": mb, f"sources_{j}": src, f"thr_{j}": thr, f"mpd_{j}": mpd,
+                    f"peaks_{j}": np.asarray(pk), f"peak_sources_{j}": src[pk]})
+    np.savez_compressed(os.path.join(HERE, "bp_find_detections.npz"), n_cases=3, **det)
+
+    # ---- MatchedFilter.select_cc_indexes (Python variant, similarity_search.py:187-286) -----
+    class _Data:
+        sr = 25.0
+        duration = 2000.0
+    sel = {}
+    for j, (n, win, step, remove_edges, acdf) in enumerate([(80_000, 250, 1, True, 0.0),
+                                                             (80_000, 250, 1, True, 0.5),
+                                                             (40_000, 60, 2, False, 0.5),
+                                                             (30_000, 1000, 1, False, 0.0)]):
+        fake = MagicMock()
+        fake.data = _Data()
+        fake.step = step
+        fake.threshold_type = "rms"
+        fake.remove_edges = remove_edges
+        x = cc_like_series(rng, n, gaps=False)
+        thr = (0.16 + 0.0 * x).astype(np.float32)
+        idx = similarity_search.MatchedFilter.select_cc_indexes(
+            fake, x, thr, win, anomalous_cdf_at_mean_plus_1sig=acdf)
+        sel.update({f"x_{j}": x, f"thr_{j}": thr, f"win_{j}": win, f"step_{j}": step,
+                    f"remove_edges_{j}": remove_edges, f"acdf_{j}": acdf,
+                    f"idx_{j}": np.asarray(idx, dtype=np.int64)})
+    np.savez_compressed(os.path.join(HERE, "select_cc_indexes_py.npz"), n_cases=4, sr=25.0,
+                        duration=2000.0, min_freq_hz=2.0, n_dev=8.0, data_buffer_sec=500.0, **sel)
+
+    # ---- similarity_search.time_dependent_threshold, 'mad' (NumPy) --------------------------
+    x = cc_like_series(rng, 60_000, gaps=True)
+    wn = rng.standard_normal(int((x == 0).sum())).astype(np.float32)
+    thr = similarity_search.time_dependent_threshold(x, 6000, overlap=0.5, threshold_type="mad",
+                                                     white_noise=wn)
+    np.savez_compressed(os.path.join(HERE, "tdt_mad.npz"), x=x, white_noise=wn, window=6000,
+                        overlap=0.5, n_dev=8.0, thr=np.asarray(thr))
+    print("goldens written to", HERE)
+    for fn in sorted(os.listdir(HERE)):
+        if fn.endswith(".npz"):
+            print(f"  {fn}: {os.path.getsize(os.path.join(HERE, fn)) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""CPU, world_size = 2 over gloo: the multi-GPU exchange logic of seismic_bpmf_amd.parallel.
+
+The same packing / all-reduce / all-gather code runs over RCCL on HIP tensors; here the per-rank
+partial results come from the CPU oracle (the checker standing in for the kernels), and the merged
+result must equal the oracle run on the whole grid -- including the lowest-index tie rule.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    rng = np.random.default_rng(77)
+    S, C, P, K, N = 5, 3, 2, 91, 1500
+    f = np.abs(rng.standard_normal((S, C, N))).astype(np.float32)
+    tau = rng.integers(0, 120, (K, S, P)).astype(np.int32)
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = rng.random((K, S)).astype(np.float32)
+    ws[rng.random((K, S)) < 0.3] = 0
+    tau[60:70] = tau[5:15]   # duplicates straddling the shard boundary -> cross-rank ties
+    ws[60:70] = ws[5:15]
+    return f, tau, wp, ws
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from seismic_bpmf_amd import parallel
+    f, tau, wp, ws = _case()
+    k0, k1 = parallel.shard_bounds(tau.shape[0], world)[rank]
+    lb, la = oracle.beamform(f, tau[k0:k1], wp, ws[k0:k1], "strict", "max", num_threads=1)
+    la = la + k0                                  # global ids, as source_id_offset does on device
+    la[lb == 0] = k0                              # kernel default: (0, first id of the shard)
+    beam, arg = parallel.allreduce_max(torch.from_numpy(lb), torch.from_numpy(la.astype(np.int32)))
+    # all-gather of fixed-capacity peak records
+    rec = torch.zeros((8, 3), dtype=torch.float32)
+    n_valid = rank + 2
+    rec[:n_valid] = torch.arange(n_valid * 3, dtype=torch.float32).reshape(n_valid, 3) + 100 * rank
+    parts = parallel.allgather_records(rec, n_valid)
+    q.put((rank, beam.numpy(), arg.numpy(), [p.numpy() for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from seismic_bpmf_amd.parallel import shard_bounds
+    assert shard_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    for n, w in [(5000, 8), (1_000_000, 8), (7, 7)]:
+        b = shard_bounds(n, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
+def test_pack_unpack_keys_roundtrip_and_order():
+    from seismic_bpmf_amd.parallel import pack_max_keys, unpack_max_keys
+    rng = np.random.default_rng(1)
+    beam = torch.from_numpy(np.concatenate([rng.standard_normal(1000) * 5,
+                                            [0.0, -0.0, 1e-38, -1e-38, 3.4e38, -3.4e38]]).astype(np.float32))
+    arg = torch.from_numpy(rng.integers(0, 2**31 - 1, beam.numel()).astype(np.int32))
+    p = pack_max_keys(beam, arg)
+    b2, a2 = unpack_max_keys(p)
+    assert torch.equal(b2.view(torch.int32), beam.view(torch.int32)) and torch.equal(a2, arg)
+    # order: larger beam wins; on equal beams the LOWER id wins
+    order = torch.argsort(p)
+    bs = beam[order].numpy()
+    assert (np.diff(bs) >= 0).all()
+    x = pack_max_keys(torch.tensor([2.0, 2.0]), torch.tensor([7, 3], dtype=torch.int32))
+    assert x[1] > x[0]
+
+
+def test_two_rank_merge_equals_single_pass(oracle_lib):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f, tau, wp, ws = _case()
+    ob, oa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    for rank, beam, arg, parts in results:
+        assert np.array_equal(beam, ob), f"rank {rank}"
+        assert np.array_equal(arg, oa), f"rank {rank}: {(arg != oa).sum()} arg-max differ"
+        assert [len(p) for p in parts] == [2, 3]
+        assert parts[1][0, 0] == 100.0 and parts[0][1, 2] == 5.0
