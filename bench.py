@@ -281,7 +281,13 @@ def main():
                        "row0_peak_cc": round(peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj,
         }
-        print(json.dumps(line))
+        def _clean(o):  # NaN is not JSON
+            if isinstance(o, float) and not math.isfinite(o):
+                return None
+            if isinstance(o, dict):
+                return {k: _clean(v) for k, v in o.items()}
+            return o
+        print(json.dumps(_clean(line)))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -50,7 +50,7 @@ int bpmf_device_info(int device, char *name, size_t name_len, size_t *total_mem_
 #define BPMF_KERNEL_MF_MAIN 0
 #define BPMF_KERNEL_BP_BEAM 1
 #define BPMF_KERNEL_COUNT 2
-void bpmf_profile_enable(int enable); /* also clears the log */
+void bpmf_profile_enable(int enable); /* enabling clears the log; disabling keeps it */
 int bpmf_profile_count(int which_kernel); /* launches logged since enable */
 int bpmf_profile_get_ms(int which_kernel, int launch_index, float *milliseconds);
 

@@ -69,73 +69,176 @@ __global__ void bp_prestack_any_kernel(const float* __restrict__ feat,
 }
 
 // ----------------------------------------------------------------------- beam ---
-struct BpGroup {  // one LDS residency
-    int first_src, n_src, first_win, n_win;
+struct BpGroup {  // one LDS residency: a run of sources and the staging work they need
+    int first_src, n_src, first_chunk, n_chunk;
 };
-struct BpWindow {  // one staged (station, phase) trace window
-    int sp, tau0, len, base;  // U row, first moveout, floats staged, LDS float offset
+struct BpChunk {  // <= BP_THREADS consecutive floats of one prestacked (station, phase) row
+    int row;   // row of U (s * P + p)
+    int gofs;  // first sample, relative to the tile start t0 (window moveout origin + x0)
+    int dst;   // LDS float offset
+    int n;     // floats in this chunk
 };
 struct BpSource {
-    int n_act, id, tmin, tmax;  // used stations, global id, extreme used moveouts
+    int id, tmin, tmax, nterm;  // global id, extreme used moveouts, terms padded to the chunk (0 = unused)
 };
 
-template <int TPT, int OOB, int REDUCE>
+template <int NBLK>
+struct BpMeta {  // one source's wave-uniform metadata, spread over the lanes of a wave
+    int hd;
+    int mo[NBLK];
+    float mb[NBLK];
+    __device__ __forceinline__ void load(const int* __restrict__ srcs,
+                                         const int* __restrict__ term_off,
+                                         const float* __restrict__ term_beta, int NT, int k,
+                                         int lane)
+    {
+        hd = srcs[(size_t)k * 4 + (lane & 3)];
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q) {
+            const int l = lane + 64 * q;
+            mo[q] = l < NT ? term_off[(size_t)k * NT + l] : 0;
+            mb[q] = l < NT ? term_beta[(size_t)k * NT + l] : 0.0f;
+        }
+    }
+};
+
+__device__ __forceinline__ int lane_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float lane_bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// LDS layout of a group: [0, tile) is a slab of zeros that padded terms point at, then one
+// window per used (station, phase) row: lds[base + x] = U[row][t0 + tau_min(row) + x].
+//
+// All per-source / per-chunk metadata is wave-uniform.  It is fetched with ONE coalesced
+// vector load per wave (lane l <- entry l) one source ahead of its use and broadcast with
+// v_readlane: no scalar-memory round trip sits between the LDS gathers (SMEM and LDS share
+// the lgkm counter, so an s_load in the gather loop would serialise it).
+template <int TPT, int CHUNK, int NBLK, int OOB, int REDUCE>
 __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
-    const BpWindow* __restrict__ wins, const BpSource* __restrict__ srcs,
-    const float* __restrict__ term_beta, const int* __restrict__ term_off, int A, int P,
-    int default_arg, float* __restrict__ out_beam, int* __restrict__ out_arg)
+    const int4* __restrict__ chunks, const int* __restrict__ srcs,
+    const int* __restrict__ term_off, const float* __restrict__ term_beta, int NT,
+    int id_offset, float* __restrict__ out_beam, int* __restrict__ out_arg)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
-    const long long t0 = (long long)blockIdx.x * (BP_THREADS * TPT);
+    const int lane = tid & 63;
+    constexpr int TILE = BP_THREADS * TPT;
+    const long long t0 = (long long)blockIdx.x * TILE;
 
     float best[TPT];
     int arg[TPT];
 #pragma unroll
-    for (int j = 0; j < TPT; ++j) { best[j] = 0.0f; arg[j] = default_arg; }
+    for (int j = 0; j < TPT; ++j) {
+        best[j] = 0.0f;
+        arg[j] = id_offset;
+        lds[tid + j * BP_THREADS] = 0.0f;  // the zero slab (never overwritten)
+    }
 
     for (int g = 0; g < n_groups; ++g) {
         const BpGroup grp = groups[g];
-        __syncthreads();
-        for (int wi = 0; wi < grp.n_win; ++wi) {
-            const BpWindow w = wins[grp.first_win + wi];
-            const float* src = U + (size_t)w.sp * (size_t)N;
-            const long long g0 = t0 + w.tau0;
-            for (int x = tid; x < w.len; x += BP_THREADS) {
-                const long long gi = g0 + x;
-                lds[w.base + x] = (gi >= 0 && gi < N) ? src[gi] : 0.0f;
+        // Per-source metadata (header word l&3, term offsets, term weights: lane l <- entry l).
+        // Three register sets rotate through the source loop (unrolled x3, no copies), so a
+        // set is loaded two sources before it is consumed.  The first two are issued before
+        // the staging.
+        const int k_last = grp.first_src + grp.n_src - 1;
+        BpMeta<NBLK> m0, m1, m2;
+        m0.load(srcs, term_off, term_beta, NT, grp.first_src, lane);
+        m1.load(srcs, term_off, term_beta, NT, min(grp.first_src + 1, k_last), lane);
+        __syncthreads();  // previous group's gathers are done
+        // ---- stage the group's windows: descriptors by readlane, 4 loads in flight per thread
+        for (int cb = 0; cb < grp.n_chunk; cb += 64) {
+            const int nb = min(64, grp.n_chunk - cb);
+            int4 d = make_int4(0, 0, 0, 0);
+            if (lane < nb) d = chunks[grp.first_chunk + cb + lane];
+            for (int c = 0; c < nb; c += 4) {
+                // descriptors first (readlane), then 4 unconditional loads from clamped
+                // addresses (no branch between them, so all four stay in flight), then the
+                // LDS writes with the out-of-range samples zeroed
+                int row[4], dd[4], n[4];
+                long long gi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = min(c + u, nb - 1);
+                    row[u] = lane_bcast(d.x, cc);
+                    gi[u] = t0 + lane_bcast(d.y, cc) + tid;
+                    dd[u] = lane_bcast(d.z, cc);
+                    n[u] = c + u < nb ? lane_bcast(d.w, cc) : 0;
+                }
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long gc = gi[u] < 0 ? 0 : (gi[u] >= N ? N - 1 : gi[u]);
+                    v[u] = U[(size_t)row[u] * (size_t)N + gc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (tid < n[u]) lds[dd[u] + tid] = (gi[u] >= 0 && gi[u] < N) ? v[u] : 0.0f;
             }
         }
         __syncthreads();
-        for (int ks = 0; ks < grp.n_src; ++ks) {
-            const int k = grp.first_src + ks;
-            const BpSource sc = srcs[k];
+        // ---- walk the sources of the group, three per trip.  Past the end of the group the
+        // clamped index re-processes the last source, which changes nothing (same id, same
+        // value), so the trip needs no branch between its loads and their waits.
+        auto process = [&](const BpMeta<NBLK>& m) {
+            const int sid = lane_bcast(m.hd, 0), tmin = lane_bcast(m.hd, 1), tmax = lane_bcast(m.hd, 2);
+            const int nterm = lane_bcast(m.hd, 3);  // terms padded to CHUNK; 0 = unused source
             float acc[TPT];
 #pragma unroll
             for (int j = 0; j < TPT; ++j) acc[j] = 0.0f;
-            const float* tb = term_beta + (size_t)k * A;
-            const int* to = term_off + (size_t)k * A * P;
-            for (int ai = 0; ai < sc.n_act; ++ai) {
-                const float beta = tb[ai];
-                for (int p = 0; p < P; ++p) {
-                    const float* lp = lds + to[ai * P + p] + tid;
+
+#define BP_LOAD(X, B, Q, C0)                                                          \
+    _Pragma("unroll") for (int i = 0; i < CHUNK; ++i) {                               \
+        const float* lp = lds + lane_bcast(m.mo[Q], (C0) + i) + tid;                  \
+        B[i] = lane_bcast(m.mb[Q], (C0) + i);                                         \
+        _Pragma("unroll") for (int j = 0; j < TPT; ++j) X[i][j] = lp[j * BP_THREADS]; \
+    }
+#define BP_FMA(X, B)                                                                  \
+    _Pragma("unroll") for (int i = 0; i < CHUNK; ++i)                                 \
+        _Pragma("unroll") for (int j = 0; j < TPT; ++j) acc[j] = __fmaf_rn(B[i], X[i][j], acc[j]);
+
 #pragma unroll
-                    for (int j = 0; j < TPT; ++j)
-                        acc[j] = __fmaf_rn(beta, lp[j * BP_THREADS], acc[j]);
+            for (int q = 0; q < NBLK; ++q) {
+                // chunks of block q, software-pipelined: the gathers of chunk i+1 are in
+                // flight while chunk i is accumulated (same ascending fmaf order)
+                const int nc = (min(64, nterm - 64 * q)) / CHUNK;
+                if (nc <= 0) continue;
+                float xa[CHUNK][TPT], xb[CHUNK][TPT], ba[CHUNK], bb[CHUNK];
+                BP_LOAD(xa, ba, q, 0)
+                for (int i2 = 1; i2 < nc; i2 += 2) {
+                    BP_LOAD(xb, bb, q, i2 * CHUNK)
+                    BP_FMA(xa, ba)
+                    if (i2 + 1 < nc) { BP_LOAD(xa, ba, q, (i2 + 1) * CHUNK) }
+                    BP_FMA(xb, bb)
                 }
+                if (nc & 1) { BP_FMA(xa, ba) }
             }
+#undef BP_LOAD
+#undef BP_FMA
 #pragma unroll
             for (int j = 0; j < TPT; ++j) {
                 const long long t = t0 + tid + j * BP_THREADS;
-                bool computed = sc.n_act > 0;
-                if (OOB == BPMF_BP_STRICT) computed = computed && (t + sc.tmin >= 0) && (t + sc.tmax < N);
+                bool computed = nterm > 0;
+                if (OOB == BPMF_BP_STRICT) computed = computed && (t + tmin >= 0) && (t + tmax < N);
                 if (REDUCE == BPMF_BP_REDUCE_MAX) {
-                    if (computed && acc[j] > best[j]) { best[j] = acc[j]; arg[j] = sc.id; }
+                    // sources arrive in plan order, not index order: ties go to the lower id
+                    const bool better = acc[j] > best[j] || (acc[j] == best[j] && sid < arg[j]);
+                    if (computed && better) { best[j] = acc[j]; arg[j] = sid; }
                 } else {
-                    if (t < N) out_beam[(size_t)k * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                    if (t < N)
+                        out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
                 }
             }
+        };
+        for (int k = grp.first_src; k <= k_last; k += 3) {
+            m2.load(srcs, term_off, term_beta, NT, min(k + 2, k_last), lane);
+            process(m0);
+            m0.load(srcs, term_off, term_beta, NT, min(k + 3, k_last), lane);
+            process(m1);
+            m1.load(srcs, term_off, term_beta, NT, min(k + 4, k_last), lane);
+            process(m2);
         }
     }
     if (REDUCE == BPMF_BP_REDUCE_MAX) {
@@ -143,6 +246,292 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
         for (int j = 0; j < TPT; ++j) {
             const long long t = t0 + tid + j * BP_THREADS;
             if (t < N) { out_beam[t] = best[j]; out_arg[t] = arg[j]; }
+        }
+    }
+}
+
+// ------------------------------------------------ beam, uniform-VGPR metadata ---
+// Fast path for sources with at most NTV (station, phase) terms (NTV <= 32).  The per-term
+// metadata {LDS byte offset, weight} is loaded with VECTOR loads from a wave-uniform address
+// (every lane receives the same value), two sources ahead, so that the gather loop is three
+// instructions per term: v_add (address) / ds_read2st64_b32 (TPT = 2 gathers) / v_pk_fma.
+// Scalar loads cannot be used here (SMEM shares the lgkm counter with the LDS gathers) and
+// v_readlane broadcasting costs two more VALU issues per term (see bp_beam_kernel).
+struct BpTermV {
+    int off_bytes;  // LDS byte offset of the term's window origin (+ moveout)
+    float beta;     // source weight of the term's station
+};
+
+template <int NTV>
+struct BpMetaV {
+    int4 hd;  // id, tmin, tmax, nterm (padded to 4)
+    int4 t[NTV / 2];  // two BpTermV per int4
+    __device__ __forceinline__ void load(const int4* __restrict__ srcs4,
+                                         const int4* __restrict__ terms, int k, int vzero)
+    {
+        // `vzero` is 0 held in a VGPR the compiler cannot see through: it keeps these loads on
+        // the vector-memory path although their address is wave-uniform
+        const size_t kk = (size_t)(k + vzero);
+        hd = srcs4[kk];
+#pragma unroll
+        for (int i = 0; i < NTV / 2; ++i) t[i] = terms[kk * (NTV / 2) + i];
+    }
+};
+
+template <int TPT, int NTV, int OOB, int REDUCE>
+__global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
+    const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
+    const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
+    const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
+    int* __restrict__ out_arg)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    constexpr int TILE = BP_THREADS * TPT;
+    const long long t0 = (long long)blockIdx.x * TILE;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const char* lds_t = (const char*)lds + tid * 4;
+
+    float best[TPT];
+    int arg[TPT];
+#pragma unroll
+    for (int j = 0; j < TPT; ++j) {
+        best[j] = 0.0f;
+        arg[j] = id_offset;
+        lds[tid + j * BP_THREADS] = 0.0f;  // the zero slab (never overwritten)
+    }
+
+    for (int g = 0; g < n_groups; ++g) {
+        const BpGroup grp = groups[g];
+        const int k_last = grp.first_src + grp.n_src - 1;
+        BpMetaV<NTV> m0, m1, m2;
+        m0.load(srcs4, terms, grp.first_src, vzero);
+        m1.load(srcs4, terms, min(grp.first_src + 1, k_last), vzero);
+        __syncthreads();  // previous group's gathers are done
+        for (int cb = 0; cb < grp.n_chunk; cb += 64) {
+            const int nb = min(64, grp.n_chunk - cb);
+            int4 d = make_int4(0, 0, 0, 0);
+            if (lane < nb) d = chunks[grp.first_chunk + cb + lane];
+            for (int c = 0; c < nb; c += 4) {
+                int row[4], dd[4], n[4];
+                long long gi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = min(c + u, nb - 1);
+                    row[u] = lane_bcast(d.x, cc);
+                    gi[u] = t0 + lane_bcast(d.y, cc) + tid;
+                    dd[u] = lane_bcast(d.z, cc);
+                    n[u] = c + u < nb ? lane_bcast(d.w, cc) : 0;
+                }
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long gc = gi[u] < 0 ? 0 : (gi[u] >= N ? N - 1 : gi[u]);
+                    v[u] = U[(size_t)row[u] * (size_t)N + gc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (tid < n[u]) lds[dd[u] + tid] = (gi[u] >= 0 && gi[u] < N) ? v[u] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        auto process = [&](const BpMetaV<NTV>& m) {
+            const int nterm = __builtin_amdgcn_readfirstlane(m.hd.w);
+            float acc[TPT];
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NTV / 4; ++c) {
+                if (c * 4 < nterm) {  // wave-uniform
+                    float x[4][TPT];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int4 tt = m.t[(c * 4 + i) / 2];
+                        const int ob = (i & 1) ? tt.z : tt.x;
+                        const float* lp = (const float*)(lds_t + ob);
+#pragma unroll
+                        for (int j = 0; j < TPT; ++j) x[i][j] = lp[j * BP_THREADS];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int4 tt = m.t[(c * 4 + i) / 2];
+                        const float beta = __int_as_float((i & 1) ? tt.w : tt.y);
+#pragma unroll
+                        for (int j = 0; j < TPT; ++j) acc[j] = __fmaf_rn(beta, x[i][j], acc[j]);
+                    }
+                }
+            }
+            const int sid = m.hd.x;
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) {
+                const long long t = t0 + tid + j * BP_THREADS;
+                bool computed = nterm > 0;
+                if (OOB == BPMF_BP_STRICT) computed = computed && (t + m.hd.y >= 0) && (t + m.hd.z < N);
+                if (REDUCE == BPMF_BP_REDUCE_MAX) {
+                    const bool better = acc[j] > best[j] || (acc[j] == best[j] && sid < arg[j]);
+                    if (computed && better) { best[j] = acc[j]; arg[j] = sid; }
+                } else {
+                    if (t < N)
+                        out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                }
+            }
+        };
+        for (int k = grp.first_src; k <= k_last; k += 3) {
+            m2.load(srcs4, terms, min(k + 2, k_last), vzero);
+            process(m0);
+            m0.load(srcs4, terms, min(k + 3, k_last), vzero);
+            process(m1);
+            m1.load(srcs4, terms, min(k + 4, k_last), vzero);
+            process(m2);
+        }
+    }
+    if (REDUCE == BPMF_BP_REDUCE_MAX) {
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const long long t = t0 + tid + j * BP_THREADS;
+            if (t < N) { out_beam[t] = best[j]; out_arg[t] = arg[j]; }
+        }
+    }
+}
+
+// ------------------------------------------------ beam, one wave per source ---
+// Same data flow as bp_beam_uvgpr_kernel, but inside a workgroup the four waves take
+// DIFFERENT sources (k, k+1, k+2, k+3, then +4 ...) and each wave covers the whole time tile
+// (TPW samples per lane, tile = 64 * TPW).  The wave-uniform metadata of a source is then
+// fetched by one wave only, which divides the vector-memory return traffic of the metadata
+// broadcast (the limiter of the time-split kernel: 13 x 1 KiB per source per wave) by four,
+// and one address add serves TPW gathers.  Every wave keeps its own running (max, arg-max)
+// for the tile; they are merged through LDS at the end with the same (value, lowest id) order.
+template <int TPW, int NTV, int OOB, int REDUCE>
+__global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
+    const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
+    const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
+    const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
+    int* __restrict__ out_arg)
+{
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    constexpr int NW = BP_THREADS / 64;
+    constexpr int TILE = 64 * TPW;
+    const long long t0 = (long long)blockIdx.x * TILE;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const char* lds_l = (const char*)lds + lane * 4;
+
+    float best[TPW];
+    int arg[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
+    for (int x = tid; x < TILE; x += BP_THREADS) lds[x] = 0.0f;  // the zero slab
+
+    for (int g = 0; g < n_groups; ++g) {
+        const BpGroup grp = groups[g];
+        const int k_last = grp.first_src + grp.n_src - 1;
+        const int k_first = grp.first_src + wv;  // this wave's first source (may be > k_last)
+        BpMetaV<NTV> m0, m1, m2;
+        m0.load(srcs4, terms, min(k_first, k_last), vzero);
+        m1.load(srcs4, terms, min(k_first + NW, k_last), vzero);
+        __syncthreads();  // previous group's gathers are done
+        for (int cb = 0; cb < grp.n_chunk; cb += 64) {
+            const int nb = min(64, grp.n_chunk - cb);
+            int4 d = make_int4(0, 0, 0, 0);
+            if (lane < nb) d = chunks[grp.first_chunk + cb + lane];
+            for (int c = 0; c < nb; c += 4) {
+                int row[4], dd[4], n[4];
+                long long gi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = min(c + u, nb - 1);
+                    row[u] = lane_bcast(d.x, cc);
+                    gi[u] = t0 + lane_bcast(d.y, cc) + tid;
+                    dd[u] = lane_bcast(d.z, cc);
+                    n[u] = c + u < nb ? lane_bcast(d.w, cc) : 0;
+                }
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long gc = gi[u] < 0 ? 0 : (gi[u] >= N ? N - 1 : gi[u]);
+                    v[u] = U[(size_t)row[u] * (size_t)N + gc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (tid < n[u]) lds[dd[u] + tid] = (gi[u] >= 0 && gi[u] < N) ? v[u] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        auto process = [&](const BpMetaV<NTV>& m, bool live) {
+            const int nterm = live ? __builtin_amdgcn_readfirstlane(m.hd.w) : 0;
+            float acc[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NTV / 2; ++c) {
+                if (c * 2 < nterm) {  // wave-uniform
+                    const int4 tt = m.t[c];
+                    const float* lp0 = (const float*)(lds_l + tt.x);
+                    const float* lp1 = (const float*)(lds_l + tt.z);
+                    float x0[TPW], x1[TPW];
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
+                    const float b0 = __int_as_float(tt.y), b1 = __int_as_float(tt.w);
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(b0, x0[j], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(b1, x1[j], acc[j]);
+                }
+            }
+            const int sid = m.hd.x;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const long long t = t0 + lane + j * 64;
+                bool computed = nterm > 0;
+                if (OOB == BPMF_BP_STRICT) computed = computed && (t + m.hd.y >= 0) && (t + m.hd.z < N);
+                if (REDUCE == BPMF_BP_REDUCE_MAX) {
+                    const bool better = acc[j] > best[j] || (acc[j] == best[j] && sid < arg[j]);
+                    if (computed && better) { best[j] = acc[j]; arg[j] = sid; }
+                } else {
+                    if (live && t < N)
+                        out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                }
+            }
+        };
+        for (int k = k_first; k <= k_last; k += 3 * NW) {
+            m2.load(srcs4, terms, min(k + 2 * NW, k_last), vzero);
+            process(m0, true);
+            m0.load(srcs4, terms, min(k + 3 * NW, k_last), vzero);
+            process(m1, k + NW <= k_last);
+            m1.load(srcs4, terms, min(k + 4 * NW, k_last), vzero);
+            process(m2, k + 2 * NW <= k_last);
+        }
+    }
+    if (REDUCE == BPMF_BP_REDUCE_MAX) {
+        // merge the four waves' running maxima through LDS (window area is free now)
+        __syncthreads();
+        float* mb = lds;                       // [NW][TILE]
+        int* ma = (int*)(lds + NW * TILE);     // [NW][TILE]
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            mb[wv * TILE + lane + 64 * j] = best[j];
+            ma[wv * TILE + lane + 64 * j] = arg[j];
+        }
+        __syncthreads();
+        for (int x = tid; x < TILE; x += BP_THREADS) {
+            float b = mb[x];
+            int a = ma[x];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float bw = mb[w * TILE + x];
+                const int aw = ma[w * TILE + x];
+                if (bw > b || (bw == b && aw < a)) { b = bw; a = aw; }
+            }
+            const long long t = t0 + x;
+            if (t < N) { out_beam[t] = b; out_arg[t] = a; }
         }
     }
 }
@@ -187,60 +576,100 @@ using namespace bpmf;
 struct bpmf_bp_plan {
     int device = 0;
     size_t K = 0, S = 0, P = 0;
-    int tpt = 2;          // time samples per thread -> tile = BP_THREADS * tpt
-    int A = 1;            // padded number of used stations per source
+    int tpt = 2;           // time samples per thread -> tile = BP_THREADS * tpt
+    int chunk = 4;         // terms gathered side by side
+    int NT = 4;            // padded number of (station, phase) terms per source
     int n_groups = 0;
-    size_t lds_bytes = 0; // largest group
-    int default_arg = 0;
+    size_t lds_bytes = 0;  // largest group
+    int id_offset = 0;
+    double mean_group = 0; // diagnostics
     BpGroup* d_groups = nullptr;
-    BpWindow* d_wins = nullptr;
+    BpChunk* d_chunks = nullptr;
     BpSource* d_srcs = nullptr;
-    float* d_beta = nullptr;
     int* d_off = nullptr;
+    float* d_beta = nullptr;
+    int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
+    int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
+    BpTermV* d_termsv = nullptr; // [K, ntv]
 };
 
 namespace {
 
 struct PlanHost {
     std::vector<BpGroup> groups;
-    std::vector<BpWindow> wins;
-    std::vector<BpSource> srcs;
-    std::vector<float> beta;
+    std::vector<BpChunk> chunks;
+    std::vector<BpSource> srcs;   // in processing order
     std::vector<int> off;
+    std::vector<float> beta;
     size_t lds_floats = 0;
-    int A = 1;
+    int NT = 4;
 };
 
-// Greedy grouping of consecutive sources: a group is closed when adding the next source
-// would push the LDS need (sum over used (s,p) rows of tile + moveout spread) past budget.
-// Returns false if a single source cannot fit in `hard_floats`.
+// Processing order: recursive median bisection of the sources on the moveout column with
+// the largest spread (a kd-tree walk), so that consecutive sources have similar moveouts
+// on every station and a group's LDS windows stay short.
+void bisect_order(const int32_t* mv, size_t SP, std::vector<int>& idx, size_t lo, size_t hi,
+                  size_t leaf)
+{
+    if (hi - lo <= leaf) return;
+    size_t best_col = 0;
+    long long best_range = -1;
+    for (size_t c = 0; c < SP; ++c) {
+        int mn = mv[(size_t)idx[lo] * SP + c], mx = mn;
+        for (size_t i = lo + 1; i < hi; ++i) {
+            const int v = mv[(size_t)idx[i] * SP + c];
+            mn = std::min(mn, v);
+            mx = std::max(mx, v);
+        }
+        if ((long long)mx - mn > best_range) { best_range = (long long)mx - mn; best_col = c; }
+    }
+    if (best_range <= 0) return;
+    const size_t mid = lo + (hi - lo) / 2;
+    std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int a, int b) {
+        const int va = mv[(size_t)a * SP + best_col], vb = mv[(size_t)b * SP + best_col];
+        return va < vb || (va == vb && a < b);
+    });
+    bisect_order(mv, SP, idx, lo, mid, leaf);
+    bisect_order(mv, SP, idx, mid, hi, leaf);
+}
+
+// Greedy grouping of consecutive sources (in processing order): a group is closed when the
+// next source would push the LDS need (zero slab + sum over used rows of tile + moveout
+// spread) past the soft budget.  Returns false if one source alone exceeds `hard_floats`.
 bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P, int tile,
-                size_t soft_floats, size_t hard_floats, int max_group, int32_t id_offset,
-                PlanHost& ph)
+                int chunk, size_t soft_floats, size_t hard_floats, int max_group, bool reorder,
+                int32_t id_offset, PlanHost& ph)
 {
     const size_t SP = S * P;
-    int A = 1;
+    std::vector<int> order(K);
+    for (size_t k = 0; k < K; ++k) order[k] = (int)k;
+    if (reorder) bisect_order(mv, SP, order, 0, K, 16);
+
+    size_t max_terms = 1;
     ph.srcs.resize(K);
-    for (size_t k = 0; k < K; ++k) {
+    for (size_t q = 0; q < K; ++q) {
+        const size_t k = (size_t)order[q];
         int n = 0;
         long long lo = 0, hi = 0;
         for (size_t s = 0; s < S; ++s) {
             if (ws[k * S + s] == 0.0f) continue;
             for (size_t p = 0; p < P; ++p) {
-                long long tau = mv[(k * S + s) * P + p];
-                if ((n == 0 && p == 0) || tau < lo) lo = tau;
-                if ((n == 0 && p == 0) || tau > hi) hi = tau;
+                const long long tau = mv[(k * S + s) * P + p];
+                if (n == 0 || tau < lo) lo = tau;
+                if (n == 0 || tau > hi) hi = tau;
+                ++n;
             }
-            ++n;
         }
-        ph.srcs[k] = BpSource{n, (int)((long long)k + id_offset), (int)lo, (int)hi};
-        A = std::max(A, n);
+        ph.srcs[q] = BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi,
+                              (n + chunk - 1) / chunk * chunk};
+        max_terms = std::max(max_terms, (size_t)n);
     }
-    ph.A = A;
-    ph.beta.assign(K * (size_t)A, 0.0f);
-    ph.off.assign(K * (size_t)A * P, 0);
+    const int NT = (int)((max_terms + chunk - 1) / chunk * chunk);
+    ph.NT = NT;
+    ph.off.assign(K * (size_t)NT, 0);       // padded terms read the zero slab at offset 0
+    ph.beta.assign(K * (size_t)NT, 0.0f);
 
-    std::vector<int> gmin(SP), gmax(SP);
+    std::vector<int> gmin(SP), gmax(SP), base(SP);
     std::vector<char> used(SP);
     struct RowUpdate { size_t row; int lo, hi; };
     std::vector<RowUpdate> upd;
@@ -248,10 +677,10 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     size_t first = 0;
     while (first < K) {
         std::fill(used.begin(), used.end(), 0);
-        size_t need = 0, k = first;
-        for (; k < K && (int)(k - first) < max_group; ++k) {
+        size_t need = (size_t)tile, q = first;  // the zero slab
+        for (; q < K && (int)(q - first) < max_group; ++q) {
+            const size_t k = (size_t)order[q];
             size_t need2 = need;
-            // tentative extension of every row the source uses
             upd.clear();
             for (size_t s = 0; s < S; ++s) {
                 if (ws[k * S + s] == 0.0f) continue;
@@ -269,9 +698,9 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                     upd.push_back(RowUpdate{r, lo, hi});
                 }
             }
-            const size_t limit = (k == first) ? hard_floats : soft_floats;
+            const size_t limit = (q == first) ? hard_floats : soft_floats;
             if (need2 > limit) {
-                if (k == first) return false;
+                if (q == first) return false;
                 break;
             }
             for (const RowUpdate& u : upd) {
@@ -281,33 +710,35 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
             }
             need = need2;
         }
-        // close group [first, k)
-        BpGroup g{(int)first, (int)(k - first), (int)ph.wins.size(), 0};
-        std::vector<int> base(SP, -1);
-        size_t o = 0;
+        // close group [first, q): lay the windows out after the zero slab, cut them in chunks
+        BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
+        size_t o = (size_t)tile;
         for (size_t r = 0; r < SP; ++r) {
+            base[r] = -1;
             if (!used[r]) continue;
             const int len = tile + (gmax[r] - gmin[r]);
-            ph.wins.push_back(BpWindow{(int)r, gmin[r], len, (int)o});
             base[r] = (int)o;
+            for (int x0 = 0; x0 < len; x0 += BP_THREADS)
+                ph.chunks.push_back(BpChunk{(int)r, gmin[r] + x0, (int)o + x0,
+                                            std::min(BP_THREADS, len - x0)});
             o += (size_t)len;
-            ++g.n_win;
         }
+        g.n_chunk = (int)ph.chunks.size() - g.first_chunk;
         ph.lds_floats = std::max(ph.lds_floats, o);
-        for (size_t kk = first; kk < k; ++kk) {
-            int ai = 0;
+        for (size_t qq = first; qq < q; ++qq) {
+            const size_t k = (size_t)order[qq];
+            size_t j = 0;
             for (size_t s = 0; s < S; ++s) {
-                if (ws[kk * S + s] == 0.0f) continue;
-                ph.beta[kk * A + ai] = ws[kk * S + s];
-                for (size_t p = 0; p < P; ++p) {
+                if (ws[k * S + s] == 0.0f) continue;
+                for (size_t p = 0; p < P; ++p, ++j) {
                     const size_t r = s * P + p;
-                    ph.off[(kk * A + ai) * P + p] = base[r] + (mv[(kk * S + s) * P + p] - gmin[r]);
+                    ph.off[qq * NT + j] = base[r] + (mv[(k * S + s) * P + p] - gmin[r]);
+                    ph.beta[qq * NT + j] = ws[k * S + s];
                 }
-                ++ai;
             }
         }
         ph.groups.push_back(g);
-        first = k;
+        first = q;
     }
     return true;
 }
@@ -319,6 +750,12 @@ int upload(const std::vector<Tv>& v, Tv** d)
     BPMF_HIP_CHECK(hipMalloc((void**)d, b));
     if (!v.empty()) BPMF_HIP_CHECK(hipMemcpy(*d, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
     return 0;
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 }  // namespace
@@ -335,12 +772,13 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         set_error("bpmf_bp_plan_create: grid too large");
         return -1;
     }
-    size_t soft_kb = 64;
-    if (const char* e = getenv("BPMF_BP_LDS_KB")) soft_kb = (size_t)std::max(8, atoi(e));
-    int max_group = 1024;
-    if (const char* e = getenv("BPMF_BP_MAX_GROUP")) max_group = std::max(1, atoi(e));
-    int tpt_first = 2;
-    if (const char* e = getenv("BPMF_BP_TPT")) tpt_first = atoi(e);
+    // tuning knobs (defaults chosen on MI355X)
+    const size_t soft_kb = (size_t)std::max(8, env_int("BPMF_BP_LDS_KB", 80));
+    const int max_group = std::max(1, env_int("BPMF_BP_MAX_GROUP", 4096));
+    const int tpt_first = env_int("BPMF_BP_TPT", 2);
+    int chunk = env_int("BPMF_BP_CHUNK", 4);
+    if (chunk != 4 && chunk != 8) chunk = 4;
+    const bool reorder = env_int("BPMF_BP_REORDER", 1) != 0;
     const size_t hard = BP_LDS_MAX / sizeof(float);
     const size_t soft = std::min(hard, soft_kb * 1024 / sizeof(float));
 
@@ -351,8 +789,8 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         const int cand = candidates[c];
         if (cand != 1 && cand != 2 && cand != 4) continue;
         ph = PlanHost();
-        if (build_plan(moveouts, w_sources, K, S, P, BP_THREADS * cand, soft, hard, max_group,
-                       source_id_offset, ph))
+        if (build_plan(moveouts, w_sources, K, S, P, BP_THREADS * cand, chunk, soft, hard,
+                       max_group, reorder, source_id_offset, ph))
             tpt = cand;
     }
     if (!tpt) {
@@ -360,19 +798,42 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                   S * P);
         return -1;
     }
+    if (ph.NT > 256) {
+        set_error("bpmf_bp_plan_create: %d station-phase terms per source (max 256)", ph.NT);
+        return -1;
+    }
     BPMF_HIP_CHECK(hipSetDevice(device));
     bpmf_bp_plan* pl = new bpmf_bp_plan();
     pl->device = device;
     pl->K = K; pl->S = S; pl->P = P;
     pl->tpt = tpt;
-    pl->A = ph.A;
+    pl->chunk = chunk;
+    pl->NT = ph.NT;
     pl->n_groups = (int)ph.groups.size();
     pl->lds_bytes = ph.lds_floats * sizeof(float);
-    pl->default_arg = source_id_offset;
+    pl->id_offset = source_id_offset;
+    pl->mean_group = (double)K / (double)ph.groups.size();
+    if (env_int("BPMF_BP_VERBOSE", 0))
+        fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B\n",
+                K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes);
     int rc = 0;
-    if ((rc = upload(ph.groups, &pl->d_groups)) || (rc = upload(ph.wins, &pl->d_wins)) ||
-        (rc = upload(ph.srcs, &pl->d_srcs)) || (rc = upload(ph.beta, &pl->d_beta)) ||
-        (rc = upload(ph.off, &pl->d_off))) {
+    // fast-path copy of the term table: {byte offset, weight} pairs padded to ntv per source
+    const int ntv_opts[4] = {8, 16, 24, 32};
+    const bool want_uv = env_int("BPMF_BP_UVGPR", 1) != 0;
+    pl->wps = env_int("BPMF_BP_WPS", 1);
+    std::vector<BpTermV> tv;
+    for (int o = 0; o < 4 && want_uv && !pl->ntv; ++o)
+        if (ph.NT <= ntv_opts[o]) pl->ntv = ntv_opts[o];
+    if (pl->ntv) {
+        tv.assign(K * (size_t)pl->ntv, BpTermV{0, 0.0f});
+        for (size_t q = 0; q < K; ++q)
+            for (int j = 0; j < ph.NT; ++j)
+                tv[q * pl->ntv + j] = BpTermV{ph.off[q * ph.NT + j] * 4, ph.beta[q * ph.NT + j]};
+        if ((rc = upload(tv, &pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
+    }
+    if ((rc = upload(ph.groups, &pl->d_groups)) || (rc = upload(ph.chunks, &pl->d_chunks)) ||
+        (rc = upload(ph.srcs, &pl->d_srcs)) || (rc = upload(ph.off, &pl->d_off)) ||
+        (rc = upload(ph.beta, &pl->d_beta))) {
         bpmf_bp_plan_destroy(pl);
         return rc;
     }
@@ -384,10 +845,11 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
 {
     if (!pl) return;
     (void)hipFree(pl->d_groups);
-    (void)hipFree(pl->d_wins);
+    (void)hipFree(pl->d_chunks);
     (void)hipFree(pl->d_srcs);
-    (void)hipFree(pl->d_beta);
     (void)hipFree(pl->d_off);
+    (void)hipFree(pl->d_beta);
+    (void)hipFree(pl->d_termsv);
     delete pl;
 }
 
@@ -400,11 +862,11 @@ extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size
 
 namespace {
 
-template <int TPT, int OOB, int REDUCE>
+template <int TPT, int CHUNK, int NBLK, int OOB, int REDUCE>
 int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream, float* beam,
                 int32_t* arg)
 {
-    auto kern = bp_beam_kernel<TPT, OOB, REDUCE>;
+    auto kern = bp_beam_kernel<TPT, CHUNK, NBLK, OOB, REDUCE>;
     if (pl->lds_bytes > 64 * 1024)
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -413,24 +875,125 @@ int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t st
     dim3 grid((unsigned)((N + tile - 1) / tile));
     profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
-        U, (long long)N, pl->d_groups, pl->n_groups, pl->d_wins, pl->d_srcs, pl->d_beta, pl->d_off,
-        pl->A, (int)pl->P, pl->default_arg, beam, arg);
+        U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
+        (const int*)pl->d_srcs, pl->d_off, pl->d_beta, pl->NT, pl->id_offset, beam, arg);
     BPMF_LAUNCH_CHECK();
     profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
+}
+
+template <int TPT, int CHUNK, int NBLK>
+int dispatch_beam3(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                   hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam<TPT, CHUNK, NBLK, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam<TPT, CHUNK, NBLK, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam<TPT, CHUNK, NBLK, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    return launch_beam<TPT, CHUNK, NBLK, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+}
+
+template <int TPT, int CHUNK>
+int dispatch_beam2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                   hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (pl->NT <= 64) return dispatch_beam3<TPT, CHUNK, 1>(pl, U, N, oob, reduce, stream, beam, arg);
+    if (pl->NT <= 128) return dispatch_beam3<TPT, CHUNK, 2>(pl, U, N, oob, reduce, stream, beam, arg);
+    return dispatch_beam3<TPT, CHUNK, 4>(pl, U, N, oob, reduce, stream, beam, arg);
+}
+
+template <int TPT, int NTV, int OOB, int REDUCE>
+int launch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
+                   float* beam, int32_t* arg)
+{
+    auto kern = bp_beam_uvgpr_kernel<TPT, NTV, OOB, REDUCE>;
+    if (pl->lds_bytes > 64 * 1024)
+        BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)BP_LDS_MAX));
+    const size_t tile = (size_t)BP_THREADS * TPT;
+    dim3 grid((unsigned)((N + tile - 1) / tile));
+    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
+        U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg);
+    BPMF_LAUNCH_CHECK();
+    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    return 0;
+}
+
+template <int TPT, int NTV>
+int dispatch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                     hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_uv<TPT, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_uv<TPT, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam_uv<TPT, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    return launch_beam_uv<TPT, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+}
+
+template <int TPW, int NTV, int OOB, int REDUCE>
+int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
+                    float* beam, int32_t* arg)
+{
+    auto kern = bp_beam_wps_kernel<TPW, NTV, OOB, REDUCE>;
+    // the end-of-kernel merge needs 2 * 4 * tile floats of LDS
+    const size_t lds = std::max(pl->lds_bytes, (size_t)8 * 64 * TPW * sizeof(float));
+    if (lds > 64 * 1024)
+        BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)BP_LDS_MAX));
+    const size_t tile = (size_t)64 * TPW;
+    dim3 grid((unsigned)((N + tile - 1) / tile));
+    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    kern<<<grid, dim3(BP_THREADS), lds, stream>>>(
+        U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg);
+    BPMF_LAUNCH_CHECK();
+    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    return 0;
+}
+
+template <int TPW, int NTV>
+int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                      hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
 template <int TPT>
 int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                   hipStream_t stream, float* beam, int32_t* arg)
 {
-    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam<TPT, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam<TPT, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_STRICT)
-        return launch_beam<TPT, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
-    return launch_beam<TPT, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    if (pl->wps && pl->ntv && TPT == 2) {  // wave-per-source layout: tile 512 = 64 lanes x 8
+        switch (pl->ntv) {
+            case 8: return dispatch_beam_wps<8, 8>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 16: return dispatch_beam_wps<8, 16>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 24: return dispatch_beam_wps<8, 24>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 32: return dispatch_beam_wps<8, 32>(pl, U, N, oob, reduce, stream, beam, arg);
+            default: break;
+        }
+    }
+    switch (pl->ntv) {  // uniform-VGPR fast path when every source has <= 32 terms
+        case 8: return dispatch_beam_uv<TPT, 8>(pl, U, N, oob, reduce, stream, beam, arg);
+        case 16: return dispatch_beam_uv<TPT, 16>(pl, U, N, oob, reduce, stream, beam, arg);
+        case 24: return dispatch_beam_uv<TPT, 24>(pl, U, N, oob, reduce, stream, beam, arg);
+        case 32: return dispatch_beam_uv<TPT, 32>(pl, U, N, oob, reduce, stream, beam, arg);
+        default: break;
+    }
+    if (pl->chunk == 8) return dispatch_beam2<TPT, 8>(pl, U, N, oob, reduce, stream, beam, arg);
+    return dispatch_beam2<TPT, 4>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
 }  // namespace

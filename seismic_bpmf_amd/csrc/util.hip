@@ -59,6 +59,7 @@ void profile_mark(int which, int edge, hipStream_t stream)
 extern "C" void bpmf_profile_enable(int enable)
 {
     bpmf::g_profile = enable != 0;
+    if (!enable) return;  // the log stays readable after the timed region is closed
     for (int k = 0; k < BPMF_KERNEL_COUNT; ++k) { bpmf::g_log[k].count = 0; bpmf::g_log[k].open = false; }
 }
 
