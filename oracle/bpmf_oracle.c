@@ -37,7 +37,7 @@
 #endif
 
 #define BPMF_CSUM_CHUNK 1024          /* hierarchical prefix-sum chunk (spec constant) */
-#define BPMF_STABILITY_THRESHOLD 1e-6f /* den <= this -> CC = 0 (no Inf/NaN)           */
+#define BPMF_MAX_NORM 1000.0f /* 1/sqrt(E_t*E_d) >= this (E_t*E_d <~ 1e-6) -> CC = 0, no Inf/NaN */
 #define LAGV 16                        /* lags evaluated side by side (vector lanes)     */
 
 static void set_threads(int num_threads)
@@ -116,6 +116,17 @@ void mf_window_energy(const double *csum, size_t n_channels, size_t N, size_t L,
     }
 }
 
+/* Reciprocal norm r[i] = 1 / sqrtf(e[i]) (IEEE sqrt, then IEEE divide; e == 0 -> +Inf).
+ * Both the template energies and the window energies go through this; the CC is then
+ * num * (r_t * r_d): the normalisation costs three multiplies per (template, channel, lag)
+ * instead of a divide and a square root, and differs from num / sqrtf(E_t * E_d) only in
+ * rounding (a few ulp).  SURVEY.md App. A recollects the upstream form as num/sqrt(den). */
+void mf_reciprocal_norm(const float *energy, size_t n, float *rnorm)
+{
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++) rnorm[i] = 1.0f / sqrtf(energy[i]);
+}
+
 /* Valid lag range of one template: every channel with w != 0 must have its
  * whole window inside the data.  Returns 0 when the range is empty. */
 static int mf_valid_range(const int32_t *mv, const float *w, size_t n_ch, size_t step,
@@ -151,8 +162,8 @@ static int mf_valid_range(const int32_t *mv, const float *w, size_t n_ch, size_t
  *   network_sum == 0 : out (T, n_corr, S, C)      cc (unweighted), 0 where w == 0
  * Per valid (t, i) and channel with w != 0:
  *   num = fmaf chain over l ascending of tmpl[l] * data[i*step + mv + l], from 0
- *   den = E_t * E_d         (float multiply)
- *   cc  = den > 1e-6f ? num / sqrtf(den) : 0
+ *   nrm = r_t * r_d         (float multiply of the reciprocal norms, see mf_reciprocal_norm)
+ *   cc  = nrm < 1000 ? num * nrm : 0     (zero-energy template or window -> nrm = Inf -> 0)
  *   cc_sum = fmaf(w, cc, cc_sum)   channels in (s outer, c inner) order
  * Lags outside the template's valid range stay exactly 0.
  * Returns 0, or -1 on bad sizes / allocation failure.
@@ -176,6 +187,8 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
     mf_data_csum(data, n_ch, N, csum);
     mf_window_energy(csum, n_ch, N, L, e_d);
     free(csum);
+    mf_reciprocal_norm(e_t, T * n_ch, e_t);   /* in place: e_t, e_d now hold r_t, r_d */
+    mf_reciprocal_norm(e_d, n_ch * nwin, e_d);
 
     const size_t out_per_t = network_sum ? n_corr : n_corr * n_ch;
     memset(out, 0, T * out_per_t * sizeof(float));
@@ -227,9 +240,9 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
                 }
                 for (int v = 0; v < LAGV; v++) {
                     if (!ok[v]) continue;
-                    float den = et * ed[off[v]];
+                    float nrm = et * ed[off[v]];
                     float cc = 0.0f;
-                    if (den > BPMF_STABILITY_THRESHOLD) cc = num[v] / sqrtf(den);
+                    if (nrm < BPMF_MAX_NORM) cc = num[v] * nrm;
                     if (network_sum)
                         cc_sum[v] = fmaf(w[ch], cc, cc_sum[v]);
                     else

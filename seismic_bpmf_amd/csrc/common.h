@@ -12,7 +12,7 @@ char* last_error_buf();
 void set_error(const char* fmt, ...);
 
 constexpr int CSUM_CHUNK = 1024;             // spec constant, see oracle/bpmf_oracle.c
-constexpr float STABILITY_THRESHOLD = 1e-6f; // den <= this -> CC = 0
+constexpr float MAX_NORM = 1000.0f;          // r_t * r_d >= this (E_t*E_d <~ 1e-6) -> CC = 0
 
 // bench hook: events around the dominant kernels (util.hip)
 void profile_mark(int which, int edge, hipStream_t stream);

@@ -5,19 +5,15 @@
 // BPMF/similarity_search.py:526-533 and BPMF/dataset.py:4818-4827 (the arithmetic itself
 // is not in the reference tree).  Conventions = oracle/bpmf_oracle.c:mf_cpu, bit for bit.
 //
-// Kernel design (see DESIGN.md section "MF"):
-//   For one (template, channel) the numerators of 1024 consecutive lags are ONE 32x32
-//   MFMA tile:  Out[b][a] = sum_m A[b][m] * D[m][a],  lag = 32a + b,
-//     A[b][m] = tmpl[m - b]          (32 x (L+31) Toeplitz band of the template)
-//     D[m][a] = data[x0 + 32a + m]   (strided view of the contiguous data window)
-//   evaluated with v_mfma_f32_32x32x2_f32, which is an exact, k-ordered fp32 fmaf chain;
-//   the band's zeros add exact zeros, so every numerator equals the scalar chain
-//   fmaf(tmpl[l], data[i+mv+l], acc) for l = 0..L-1.  The per-channel moveout only moves
-//   x0, so no alignment between templates or channels is needed.  A workgroup of 4 waves
-//   owns (one template) x (4096 consecutive lags) and walks the S*C channels with the
-//   weighted CC sum in registers; data window and Toeplitz band live in LDS.
+// Kernel design: DESIGN.md section "MF" and the comment above mf_mfma_kernel.  In short: for
+// one (template, channel) the numerators of 256 consecutive lags are one 16x16 MFMA tile of a
+// Toeplitz band of the template against a strided view of the contiguous data window,
+// evaluated with the exact-fp32 v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain; the band's
+// zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
 #include "../../include/bpmf_hip.h"
+
+#include <cstdlib>
 
 namespace bpmf {
 
@@ -25,7 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ preparation ---
 
-// E_t[t,s,c]: fmaf chain over l ascending.
+// r_t[t,s,c] = 1 / sqrtf(E_t),  E_t = fmaf chain of tmpl^2 over l ascending.
 __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t n_rows, int L,
                                           float* __restrict__ e_t)
 {
@@ -34,7 +30,7 @@ __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t
     const float* x = tmpl + i * (size_t)L;
     float acc = 0.0f;
     for (int l = 0; l < L; ++l) acc = __fmaf_rn(x[l], x[l], acc);
-    e_t[i] = acc;
+    e_t[i] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
 }
 
 // Valid lag range [first, last] of each template (first > last = empty).
@@ -101,7 +97,8 @@ __global__ void mf_csum_offsets_kernel(const double* __restrict__ tot, size_t n_
     }
 }
 
-// E_d[ch, j] = (float)(csum[j+L] - csum[j]),  csum[n] = off[chunk(n-1)] + local[n-1].
+// r_d[ch, j] = 1 / sqrtf(E_d),  E_d = (float)(csum[j+L] - csum[j]),
+// csum[n] = off[chunk(n-1)] + local[n-1].
 __global__ void mf_window_energy_kernel(const double* __restrict__ local,
                                         const double* __restrict__ off, size_t n_ch, size_t N,
                                         size_t nq, size_t L, size_t nwin,
@@ -116,112 +113,226 @@ __global__ void mf_window_energy_kernel(const double* __restrict__ local,
     double hi = of[nh / CSUM_CHUNK] + lo[nh];
     double low = 0.0;
     if (j > 0) low = of[(j - 1) / CSUM_CHUNK] + lo[j - 1];
-    e_d[ch * nwin + j] = (float)(hi - low);
+    e_d[ch * nwin + j] = 1.0f / sqrtf((float)(hi - low));  // reciprocal norm r_d
 }
 
 // --------------------------------------------------------------- MFMA main kernel ---
+//
+// Tile algebra (v_mfma_f32_16x16x4_f32, exact fp32, k-ordered fmaf chain):
+//   one 16x16 tile = 256 consecutive lags of one (template, channel):
+//       Out[b][a] = sum_m A[b][m] * D[m][a],   lag = 16 a + b
+//       A[b][m] = tmpl[m - b]   (16 x (L+15) Toeplitz band; zeros outside 0 <= m-b < L)
+//       D[m][a] = data[x0 + 16 a + m]
+//   A wave owns 4 such tiles (1024 lags) with 4 INDEPENDENT accumulators that share every A
+//   operand: the matrix pipe always has an independent MFMA to issue (the 16x16x4 form has a
+//   40-cycle dependent latency against a 32-cycle issue interval), and 5 LDS reads feed 4
+//   MFMAs.  The band's zero rows cost (L+15)/L extra matrix work (6 % at L = 256).
+//   A workgroup = 4 waves = 4096 consecutive lags of ONE template; it walks the S*C channels
+//   with the weighted CC sums in registers.  Per channel: the next channel's data window and
+//   band travel global -> registers during the MFMA loop, registers -> LDS (other buffer)
+//   after it, one barrier per channel.
+// LDS data layout: dw[x + (x >> 4)] = data[g0 + x]  (one pad float per 16) so that the 16
+// tile columns of a B read (stride 16 floats) fall on 16 different banks.
 
 constexpr int MF_THREADS = 256;
 constexpr int MF_LAGS_PER_WAVE = 1024;
 constexpr int MF_LAGS_PER_WG = 4096;
 
-__device__ __forceinline__ int mf_pad(int x) { return x + (x >> 5); }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned vector
 
-__host__ __device__ inline int mf_kpad(int L) { return (L + 31 + 31) / 32 * 32; }
-// LDS floats: Toeplitz band (Kpad + 32) + padded data window.
-__host__ __device__ inline int mf_window_len(int L) { return MF_LAGS_PER_WG - 32 + mf_kpad(L); }
-__host__ inline size_t mf_lds_bytes(int L)
+__device__ __forceinline__ int mf_pad(int x) { return x + (x >> 4); }
+
+__host__ __device__ inline int mf_kpad(int L) { return (L + 15 + 15) / 16 * 16; }
+__host__ __device__ inline int mf_band_len(int L) { return mf_kpad(L) + 16; }
+__host__ __device__ inline int mf_window_len(int L) { return MF_LAGS_PER_WG - 16 + mf_kpad(L); }
+// one LDS buffer = Toeplitz band + padded data window
+__host__ __device__ inline int mf_buf_floats(int L)
 {
-    int W = mf_window_len(L);
-    return (size_t)(mf_kpad(L) + 32 + (W + (W >> 5) + 1)) * sizeof(float);
+    const int W = mf_window_len(L);
+    return mf_band_len(L) + (W + (W >> 4) + 1);
 }
+// two buffers + slack for the operand prefetch that runs one trip past the end
+__host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L) + 64) * sizeof(float); }
 
-template <bool NETWORK_SUM>
+// MAXR / MAXT: per-thread staging registers for the data window / the Toeplitz band
+// (window <= 256 * MAXR floats, band <= 256 * MAXT floats).
+template <bool NETWORK_SUM, int MAXR, int MAXT>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int* __restrict__ mv, const float* __restrict__ wgt,
     const float* __restrict__ data, const float* __restrict__ e_t,
     const float* __restrict__ e_d, const int2* __restrict__ range, int L, long long N, int T,
-    int n_ch, long long n_corr, float* __restrict__ out)
+    int n_ch, long long n_corr, float* __restrict__ out, int ablate)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
-    const int tp_len = Kpad + 32;
+    const int tp_len = mf_band_len(L);
     const int W = mf_window_len(L);
-    float* tp = smem;          // tp[31 + l] = tmpl[l], zeros around
-    float* dw = smem + tp_len; // dw[pad(x)] = data[g0 + x]
+    const int buf_floats = mf_buf_floats(L);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = tid >> 6;
-    const int a = lane & 31;
-    const int hi = lane >> 5;
+    const int a = lane & 15;   // tile column (and band row for the A operand)
+    const int kq = lane >> 4;  // k index of the operands / row group of the results
 
     const int t = blockIdx.x % T;
     const long long lag0 = (long long)(blockIdx.x / T) * MF_LAGS_PER_WG;
     const int2 rg = range[t];
     const long long nwin = N - L + 1;
 
-    float sum[16];
+    f32x4 sum[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sum[r] = 0.0f;
+    for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     const bool wg_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WG - 1 < rg.x);
-    const long long lag_w = lag0 + (long long)wv * MF_LAGS_PER_WAVE + 32 * a + 4 * hi;
+    // result (tile u, register r) of this lane is lag  lag_w + 256 u + r
+    const long long lag_w = lag0 + (long long)wv * MF_LAGS_PER_WAVE + 16 * a + 4 * kq;
 
     if (wg_valid) {
-        const int a_base = 31 - a + hi;
-        const int b_base = 1056 * wv + 33 * a + hi;
-        for (int ch = 0; ch < n_ch; ++ch) {
-            const float w = wgt[(size_t)t * n_ch + ch];
-            if (w == 0.0f) continue;
-            const int mvc = mv[(size_t)t * n_ch + ch];
-            const float et = e_t[(size_t)t * n_ch + ch];
-            __syncthreads();  // everyone is done reading the previous channel's LDS
-            const float* tsrc = tmpl + ((size_t)t * n_ch + ch) * (size_t)L;
-            for (int x = tid; x < tp_len; x += MF_THREADS) {
-                int l = x - 31;
-                tp[x] = (l >= 0 && l < L) ? tsrc[l] : 0.0f;
+        const int a_base = 15 - a + kq;
+        const int b_base = 1088 * wv + 17 * a + kq;
+        const float* wrow = wgt + (size_t)t * n_ch;
+        const int* mrow = mv + (size_t)t * n_ch;
+
+        float rd[MAXR], rt[MAXT];
+        // Staging loads go through buffer descriptors: an offset outside [0, bytes) -- a
+        // window sample before the start / past the end of the trace, or a band row outside
+        // the template -- returns 0 from the hardware bounds check, so the zero padding costs
+        // no address clamping or select.
+        auto issue_stage = [&](int ch) {
+            const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
+            const int o_d = (int)((lag0 + mrow[ch] + tid) * 4);  // wraps like the hardware's u32 offset
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r)
+                rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_d, o_d + MF_THREADS * 4 * r, 0, 0));
+            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < MAXT; ++r)
+                rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_t, (tid + MF_THREADS * r - 15) * 4, 0, 0));
+        };
+        auto write_stage = [&](float* tp, float* dw) {
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int x = tid + MF_THREADS * r;
+                if (x < W) dw[mf_pad(x)] = rd[r];
             }
-            const float* dsrc = data + (size_t)ch * (size_t)N;
-            const long long g0 = lag0 + mvc;
-            for (int x = tid; x < W; x += MF_THREADS) {
-                long long g = g0 + x;
-                dw[mf_pad(x)] = (g >= 0 && g < N) ? dsrc[g] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < MAXT; ++r) {
+                const int x = tid + MF_THREADS * r;
+                if (x < tp_len) tp[x] = rt[r];
             }
+        };
+        auto next_active = [&](int ch) {
+            while (ch < n_ch && wrow[ch] == 0.0f) ++ch;
+            return ch;
+        };
+
+        int ch = next_active(0);
+        if (ch < n_ch) issue_stage(ch);
+        int buf = 0;
+        while (ch < n_ch) {
+            float* tp = smem + buf * buf_floats;  // tp[15 + l] = tmpl[l], zeros around
+            float* dw = tp + tp_len;              // dw[pad(x)] = data[g0 + x]
+            write_stage(tp, dw);
+            // One barrier per channel: the other buffer is only rewritten after every wave
+            // has passed this point, i.e. after it finished reading it.
             __syncthreads();
-
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const int nq = Kpad >> 5;
-            for (int q = 0; q < nq; ++q) {
-                const float* ap = tp + a_base + 32 * q;
-                const float* bp = dw + b_base + 33 * q;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * j], bp[2 * j], acc, 0, 0, 0);
-            }
-
+            const float w = wrow[ch];
+            const int mvc = mrow[ch];
+            const float et = e_t[(size_t)t * n_ch + ch];
+            // window energies of this lane's 4 x 4 lags: in flight during the MFMA loop
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
+            f32x4 ed[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long lag = lag_w + (r & 3) + 8 * (r >> 2);
-                const bool ok = lag >= rg.x && lag <= rg.y;
-                float cc = 0.0f;
-                if (ok) {
-                    const float den = et * edc[lag + mvc];
-                    if (den > STABILITY_THRESHOLD) cc = acc[r] / sqrtf(den);
-                    if (!NETWORK_SUM) out[((size_t)t * n_corr + lag) * n_ch + ch] = cc;
+            for (int u = 0; u < 4; ++u) {
+                const long long lag = lag_w + 256 * u;
+                // all four lags of the group inside the valid range -> one 16-byte load
+                if (ablate & 8) {
+                    ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+                } else if (lag >= rg.x && lag + 3 <= rg.y) {
+                    ed[u] = *(const f32x4u*)(edc + lag + mvc);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = lag + r >= rg.x && lag + r <= rg.y;
+                        ed[u][r] = ok ? edc[lag + r + mvc] : 0.0f;
+                    }
                 }
-                if (NETWORK_SUM) sum[r] = __fmaf_rn(w, cc, sum[r]);
             }
+            const int ch_next = next_active(ch + 1);
+            if (ch_next < n_ch && !(ablate & 2)) issue_stage(ch_next);
+
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            // K loop: 16 band rows = 4 k-steps per trip; the operands of k-step j+2 are
+            // requested before the MFMAs of k-step j issue (4 rotating register slots).
+            const int nq = (ablate & 4) ? 0 : Kpad >> 4;
+            const float* ap = tp + a_base;
+            const float* bp = dw + b_base;
+            float sa[4], sb[4][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sa[j] = ap[4 * j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sb[j][u] = bp[4 * j + 272 * u];
+            }
+            for (int q = 0; q < nq; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jn = j + 2;  // k-step to request now
+                    const float* apn = jn < 4 ? ap : ap + 16;
+                    const float* bpn = jn < 4 ? bp : bp + 17;  // past the last trip: slack, unused
+                    sa[jn & 3] = apn[4 * (jn & 3)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sb[jn & 3][u] = bpn[4 * (jn & 3) + 272 * u];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[j], sb[j][u], acc[u], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ap += 16;
+                bp += 17;
+            }
+
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long lag = lag_w + 256 * u + r;
+                    const bool ok = lag >= rg.x && lag <= rg.y;
+                    float cc = 0.0f;
+                    if (ablate & 1) cc = acc[u][r] * ed[u][r];
+                    else if (ok) {
+                        const float nrm = et * ed[u][r];  // r_t * r_d
+                        if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
+                        if (!NETWORK_SUM) out[((size_t)t * n_corr + lag) * n_ch + ch] = cc;
+                    }
+                    if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
+                }
+            }
+            ch = ch_next;
+            buf ^= 1;
         }
     }
     if (NETWORK_SUM) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long lag = lag_w + (r & 3) + 8 * (r >> 2);
-            if (lag < n_corr) out[(size_t)t * n_corr + lag] = sum[r];
+        for (int u = 0; u < 4; ++u) {
+            const long long lag = lag_w + 256 * u;
+            float* dst = out + (size_t)t * n_corr + lag;
+            if (lag + 3 < n_corr) {
+                *(f32x4u*)dst = sum[u];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (lag + r < n_corr) dst[r] = sum[u][r];
+            }
         }
     }
 }
@@ -252,9 +363,9 @@ __global__ __launch_bounds__(256) void mf_direct_kernel(
             const float* d = data + (size_t)ch * (size_t)N + j;
             float num = 0.0f;
             for (int l = 0; l < L; ++l) num = __fmaf_rn(tp[l], d[l], num);
-            const float den = e_t[(size_t)t * n_ch + ch] * e_d[(size_t)ch * nwin + j];
+            const float nrm = e_t[(size_t)t * n_ch + ch] * e_d[(size_t)ch * nwin + j];  // r_t * r_d
             float cc = 0.0f;
-            if (den > STABILITY_THRESHOLD) cc = num / sqrtf(den);
+            if (nrm < MAX_NORM) cc = num * nrm;
             if (NETWORK_SUM)
                 sum = __fmaf_rn(w, cc, sum);
             else
@@ -396,18 +507,27 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     const size_t lds = mf_lds_bytes((int)L);
     const size_t n_lag_blocks = (n_corr + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
-    const bool use_mfma = step == 1 && !(flags & BPMF_MF_FORCE_DIRECT) && lds <= 64 * 1024 &&
-                          T * n_lag_blocks < 0x7fffffffull;
+    // staging registers needed per thread (window / band), rounded to a compiled variant
+    const int need_r = (mf_window_len((int)L) + MF_THREADS - 1) / MF_THREADS;
+    const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
+    const bool use_mfma = step == 1 && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
+                          need_t <= 9 && T * n_lag_blocks < 0x7fffffffull;
     if (use_mfma) {
         dim3 grid((unsigned)(T * n_lag_blocks));
-        if (network_sum)
-            mf_mfma_kernel<true><<<grid, dim3(MF_THREADS), lds, stream>>>(
-                d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (int)L,
-                (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out);
-        else
-            mf_mfma_kernel<false><<<grid, dim3(MF_THREADS), lds, stream>>>(
-                d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (int)L,
-                (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out);
+        const char* abl = getenv("BPMF_MF_ABLATE");  // kernel-phase ablation, profiling only
+        const int ablate = abl ? atoi(abl) : 0;
+#define BPMF_MF_LAUNCH(NS, R, TT)                                                            \
+    mf_mfma_kernel<NS, R, TT><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
+        d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (int)L,        \
+        (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out, ablate)
+        if (need_r <= 17 && need_t <= 2) {          // L <= 273
+            if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
+        } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
+            if (network_sum) BPMF_MF_LAUNCH(true, 20, 5); else BPMF_MF_LAUNCH(false, 20, 5);
+        } else {                                    // L <= 2065
+            if (network_sum) BPMF_MF_LAUNCH(true, 24, 9); else BPMF_MF_LAUNCH(false, 24, 9);
+        }
+#undef BPMF_MF_LAUNCH
     } else {
         dim3 grid((unsigned)((n_corr + 255) / 256), (unsigned)T);
         if (T > 65535) {
