@@ -1,0 +1,33 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into the small files kept under profiles/."""
+import csv, collections, json, os, sys
+
+def kernel_stats(path, out):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as f:
+        f.write("name,calls,total_ms,avg_ms,pct\n")
+        for r in rows:
+            if float(r["Percentage"]) < 0.01:
+                continue
+            name = r["Name"].split("(")[0].replace("void ", "")
+            f.write(f'{name},{r["Calls"]},{float(r["TotalDurationNs"])/1e6:.3f},{float(r["AverageNs"])/1e6:.4f},{r["Percentage"]}\n')
+
+def pmc(paths, kernels, out):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for p in paths:
+        for r in csv.DictReader(open(p)):
+            for k in kernels:
+                if k in r["Kernel_Name"]:
+                    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {k: {c: {"launches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()} for k, cs in agg.items()}
+    json.dump(res, open(out, "w"), indent=1)
+    return res
+
+if __name__ == "__main__":
+    d, tag = sys.argv[1], sys.argv[2]
+    os.makedirs("profiles", exist_ok=True)
+    ks = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("kernel_stats.csv")]
+    if ks:
+        kernel_stats(ks[0], f"profiles/{tag}_kernel_stats.csv")
+    pm = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+    if pm:
+        print(json.dumps(pmc(pm, ["mf_mfma_kernel", "bp_beam", "mf_csum_local", "bp_prestack"], f"profiles/{tag}_pmc.json"), indent=1))
