@@ -1,0 +1,200 @@
+"""Host-side steps right before / after the two hot paths (SURVEY.md section 8a rows
+MF-4, MF-5, MF-6, BP-3, BP-4, BP-6), restated from the reference so that detection *indices*
+come out identical.  Every function is pinned against golden vectors produced by the reference
+itself (tests/golden/, tests/test_postprocess.py).
+
+These are small integer / NumPy routines in the reference too (Python loops in
+BPMF/similarity_search.py and BPMF/template_search.py); the heavy part of the post-CC step, the
+RMS sliding threshold of BPMF/libc.c:516-673, has a device version in threshold.py.
+"""
+import numpy as np
+
+
+# ----------------------------------------------------------------- time conversion ---
+def sec_to_samp(t, sr, epsilon=0.2):
+    """Seconds -> samples, BPMF/utils.py:1258-1271: truncate |t*sr| + epsilon, restore the sign."""
+    t = np.asarray(t, dtype=np.float64)
+    return np.int64(np.sign(t) * np.int64(np.abs(t * sr) + epsilon))
+
+
+def moveouts_to_samples(travel_times_sec, sr, relative_to_first=True):
+    """(K,S,P) travel times -> integer moveout table (BP-3).
+
+    BPMF/template_search.py:145-168 (sec_to_samp) and :212-214 (minus the per-source minimum over
+    stations and phases).  Returns (moveouts int32, moveout_to_tt int64 per source) -- the second is
+    what find_detections adds back to the origin time (:635-639)."""
+    tau = sec_to_samp(travel_times_sec, sr)
+    first = np.zeros(tau.shape[0], dtype=np.int64)
+    if relative_to_first:
+        first = tau.reshape(tau.shape[0], -1).min(axis=1)
+        tau = tau - first[:, None, None]
+    return tau.astype(np.int32), first
+
+
+# ------------------------------------------------------------------- input conditioning ---
+def normalize_data(data_arr):
+    """MatchedFilter.set_data conditioning, BPMF/similarity_search.py:181-185: each channel is
+    divided by its standard deviation (channels with zero std are left untouched)."""
+    d = np.array(data_arr, dtype=np.float32, copy=True)
+    std = d.std(axis=-1, keepdims=True)
+    std[std == 0.0] = 1.0
+    return d / std
+
+
+def normalize_weights(weights):
+    """Sum of channel weights = 1 per template, BPMF/similarity_search.py:469-472."""
+    w = np.array(weights, dtype=np.float32, copy=True)
+    norm = w.sum(axis=(1, 2), keepdims=True)
+    norm[norm == 0.0] = 1.0
+    return w / norm
+
+
+def weights_sources_closest(moveouts, n_closest, online=None):
+    """Source weights of BP-4, BPMF/template_search.py:779-798: 1 for the `n_closest` stations
+    with the smallest first-phase moveout of each source (ties at the cut-off included), 0 for
+    offline stations."""
+    first = np.asarray(moveouts)[:, :, 0]
+    K, S = first.shape
+    n_closest = min(int(n_closest), S)
+    cut = np.partition(first, n_closest - 1, axis=1)[:, n_closest - 1]
+    w = (first <= cut[:, None]).astype(np.float32)
+    if online is not None:
+        w[:, ~np.asarray(online, dtype=bool)] = 0.0
+    return w
+
+
+# ------------------------------------------------------------------------ peak picking ---
+def detect_peaks(x, mpd=1):
+    """Indices of local maxima of `x` at least `mpd` samples apart (tallest first wins).
+
+    Restates the path of BPMF/utils.py:2203-2354 that BPMF uses (edge="rising", no height or
+    prominence threshold, kpsh=False): a peak is a sample strictly above its left neighbour and
+    not below its right one; the first and last sample never qualify; peaks are then visited in
+    decreasing height and every other peak within +-mpd of a kept one is dropped.
+    """
+    x = np.atleast_1d(np.asarray(x)).astype(np.float64)
+    if x.size < 3:
+        return np.array([], dtype=int)
+    dx = np.diff(x)
+    nan = np.flatnonzero(np.isnan(x))
+    if nan.size:
+        x = x.copy()
+        x[nan] = np.inf
+        dx[np.isnan(dx)] = np.inf
+    rising = np.flatnonzero((np.append(dx, 0.0) <= 0) & (np.insert(dx, 0, 0.0) > 0))
+    ind = np.unique(rising)
+    if ind.size and nan.size:
+        bad = np.unique(np.concatenate((nan, nan - 1, nan + 1)))
+        ind = ind[~np.isin(ind, bad)]
+    if ind.size and ind[0] == 0:
+        ind = ind[1:]
+    if ind.size and ind[-1] == x.size - 1:
+        ind = ind[:-1]
+    if ind.size and mpd > 1:
+        order = ind[np.argsort(x[ind])][::-1]     # tallest first (ties: same order as argsort)
+        dropped = np.zeros(order.size, dtype=bool)
+        for q in range(order.size):
+            if dropped[q]:
+                continue
+            near = (order >= order[q] - mpd) & (order <= order[q] + mpd)
+            dropped |= near
+            dropped[q] = False
+        ind = np.sort(order[~dropped])
+    return ind
+
+
+def find_beam_detections(maxbeam, maxbeam_sources, threshold, mpd):
+    """Peak logic of Beamformer.find_detections (BP-6), BPMF/template_search.py:604-627.
+
+    Peaks of `maxbeam` at least `mpd` samples apart and above `threshold`, each snapped to the
+    largest sample within +-mpd/2, duplicates merged.  Returns (peak sample indices, their source
+    indices) -- the "detection sample indices" that must match the reference exactly."""
+    maxbeam = np.asarray(maxbeam)
+    n = maxbeam.size
+    threshold = np.broadcast_to(np.asarray(threshold), (n,))
+    peaks = detect_peaks(maxbeam, mpd=mpd)
+    peaks = peaks[maxbeam[peaks] > threshold[peaks]]
+    for q in range(peaks.size):
+        lo = max(0, peaks[q] - mpd / 2)
+        hi = min(peaks[q] + mpd / 2, n)
+        win = np.arange(lo, hi).astype(np.int32)   # same float->int truncation as the reference
+        snapped = np.argmax(maxbeam[win]) + win[0]
+        peaks[peaks == peaks[q]] = snapped
+    peaks = np.unique(peaks)
+    return peaks, np.asarray(maxbeam_sources)[peaks]
+
+
+def select_cc_indexes(cc_t, threshold, search_win, *, step, sr, data_duration_sec,
+                      n_dev_threshold, min_freq_hz, data_buffer_sec, threshold_type="rms",
+                      remove_edges=True, anomalous_cdf_at_mean_plus_1sig=0.50,
+                      window_for_validation_Tmax=100.0):
+    """Peak list of one CC series (MF-4), BPMF/similarity_search.py:187-286.
+
+    Explicit keyword arguments replace the reference's module-level config (`cfg.N_DEV_MF_THRESHOLD`,
+    `cfg.MIN_FREQ_HZ`, `cfg.DATA_BUFFER_SEC`) and `self.data.sr / duration / step`.
+    Returns CC indices (multiply by `step` for data samples)."""
+    cc_t = np.asarray(cc_t)
+    threshold = np.broadcast_to(np.asarray(threshold), cc_t.shape)
+    idx = list(np.flatnonzero(cc_t > threshold))
+    one_sigma = threshold / n_dev_threshold
+    if threshold_type == "mad":
+        one_sigma = one_sigma * 1.48
+    # sequential pair-wise merge with the reference's own bookkeeping: after each removal the
+    # comparison pointer stays on the survivor (:240-251)
+    removed = 0
+    for q in range(1, len(idx)):
+        cur, prev = idx[q - removed], idx[q - removed - 1]
+        if cur - prev < search_win:
+            idx.remove(prev if cc_t[cur] > cc_t[prev] else cur)
+            removed += 1
+    idx = np.asarray(idx, dtype=np.int64)
+
+    if anomalous_cdf_at_mean_plus_1sig > 0.0 and idx.size:
+        win = int(1.0 / min_freq_hz * window_for_validation_Tmax)
+        keep = np.ones(idx.size, dtype=bool)
+        for q, i in enumerate(idx):
+            i0 = max(0, i - win // 2)
+            i1 = i0 + win
+            if i1 >= cc_t.size:
+                i1 = cc_t.size - 1
+                i0 = i1 - win
+            seg = cc_t[i0:i1]
+            left, right = seg[: win // 2], seg[win // 2:]
+            frac = min(np.sum(left < one_sigma[i]) / float(len(left)),
+                       np.sum(right < one_sigma[i]) / float(len(right)))
+            keep[q] = frac >= anomalous_cdf_at_mean_plus_1sig
+        idx = idx[keep]
+
+    if remove_edges:
+        samples = idx * step
+        idx = idx[samples >= sec_to_samp(data_buffer_sec, sr)]
+        samples = idx * step
+        idx = idx[samples < sec_to_samp(data_duration_sec + data_buffer_sec, sr)]
+    return idx
+
+
+def time_dependent_threshold_mad(time_series, sliding_window, n_dev, overlap=0.66,
+                                 white_noise=None):
+    """MAD variant of the MF detection threshold (MF-5), BPMF/similarity_search.py:1079-1113."""
+    x = np.array(time_series, copy=True)
+    n = x.size
+    half = sliding_window // 2
+    shift = int((1.0 - overlap) * sliding_window)
+    zeros = x == 0.0
+    n_zeros = int(zeros.sum())
+    if white_noise is None:
+        white_noise = np.random.normal(size=n_zeros).astype("float32")
+    centre0 = np.median(x[~zeros])
+    dev0 = np.median(np.abs(x[~zeros] - centre0))
+    x[zeros] = white_noise[:n_zeros] * dev0 + centre0
+    wins = np.lib.stride_tricks.sliding_window_view(x, sliding_window)[::shift, :]
+    centre = np.median(wins, axis=-1)
+    dev = np.median(np.abs(wins - centre[:, None]), axis=-1)
+    thr = centre + n_dev * dev
+    thr[1:] = np.maximum(thr[:-1], thr[1:])
+    thr[:-1] = np.maximum(thr[:-1], thr[1:])
+    where = np.arange(half, n - (sliding_window - half)) // shift
+    where[where >= thr.size] = thr.size - 1
+    thr = thr[where]
+    return np.hstack((thr[0] * np.ones(half, dtype=np.float32), thr,
+                      thr[-1] * np.ones(sliding_window - half, dtype=np.float32)))

@@ -1,0 +1,89 @@
+"""CPU: host-side callers of the hot paths against golden vectors from the reference's own Python
+(tests/golden/make_goldens.py).  Integer outputs must match exactly."""
+import os
+
+import numpy as np
+
+from seismic_bpmf_amd import postprocess as pp
+from seismic_bpmf_amd import synthetic as syn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def test_sec_to_samp():
+    g = load("host_helpers.npz")
+    for sr in (25, 50, 100):
+        got = pp.sec_to_samp(g["t"], float(sr))
+        assert got.dtype == np.int64 and np.array_equal(got, g[f"sr_{sr}"])
+        assert np.array_equal(syn.sec_to_samp(g["t"], float(sr)), g[f"sr_{sr}"])
+    assert pp.sec_to_samp(7.96, 25.0) == 199 and pp.sec_to_samp(-0.04, 25.0) == -1
+
+
+def test_detect_peaks():
+    g = load("host_helpers.npz")
+    assert list(pp.detect_peaks([0, 1, 0, 2, 0, 3, 0, 2, 0, 1, 0], mpd=2)) == [1, 5, 9]
+    for j in range(int(g["n_series"])):
+        for mpd in (1, 2, 25, 300):
+            got = pp.detect_peaks(g[f"x_{j}"], mpd=mpd)
+            assert np.array_equal(got, g[f"ind_{j}_{mpd}"]), (j, mpd)
+
+
+def test_find_beam_detections():
+    g = load("bp_find_detections.npz")
+    for j in range(int(g["n_cases"])):
+        peaks, src = pp.find_beam_detections(g[f"maxbeam_{j}"], g[f"sources_{j}"], g[f"thr_{j}"],
+                                             int(g[f"mpd_{j}"]))
+        assert np.array_equal(peaks, g[f"peaks_{j}"]), j
+        assert np.array_equal(src, g[f"peak_sources_{j}"]), j
+        assert peaks.size >= 3
+
+
+def test_select_cc_indexes_python_variant():
+    g = load("select_cc_indexes_py.npz")
+    for j in range(int(g["n_cases"])):
+        idx = pp.select_cc_indexes(
+            g[f"x_{j}"], g[f"thr_{j}"], int(g[f"win_{j}"]), step=int(g[f"step_{j}"]), sr=float(g["sr"]),
+            data_duration_sec=float(g["duration"]), n_dev_threshold=float(g["n_dev"]),
+            min_freq_hz=float(g["min_freq_hz"]), data_buffer_sec=float(g["data_buffer_sec"]),
+            remove_edges=bool(g[f"remove_edges_{j}"]),
+            anomalous_cdf_at_mean_plus_1sig=float(g[f"acdf_{j}"]))
+        assert np.array_equal(idx, g[f"idx_{j}"]), (j, idx, g[f"idx_{j}"])
+
+
+def test_time_dependent_threshold_mad():
+    g = load("tdt_mad.npz")
+    thr = pp.time_dependent_threshold_mad(g["x"], int(g["window"]), float(g["n_dev"]),
+                                          overlap=float(g["overlap"]), white_noise=g["white_noise"])
+    assert thr.shape == g["thr"].shape and np.array_equal(thr, g["thr"])
+
+
+def test_conditioning_helpers():
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((3, 2, 500)).astype(np.float32) * 7
+    d[1, 1] = 0
+    n = pp.normalize_data(d)
+    assert np.allclose(n[0, 0].std(), 1.0, atol=1e-5) and not n[1, 1].any()
+    w = pp.normalize_weights(rng.random((4, 3, 2)))
+    assert np.allclose(w.sum(axis=(1, 2)), 1.0, atol=1e-6)
+    tau = rng.integers(0, 200, (10, 6, 2))
+    ws = pp.weights_sources_closest(tau, 3)
+    assert (ws.sum(axis=1) >= 3).all() and set(np.unique(ws)) <= {0.0, 1.0}
+    mv, first = pp.moveouts_to_samples(rng.uniform(1, 30, (5, 4, 2)), 50.0)
+    assert mv.dtype == np.int32 and mv.min(axis=(1, 2)).max() == 0 and (first > 0).all()
+
+
+def test_synthetic_generators_are_seeded_and_conditioned():
+    a = syn.make_mf_inputs(3, 4, 3, 64, 20000, seed=5)
+    b = syn.make_mf_inputs(3, 4, 3, 64, 20000, seed=5)
+    assert all(np.array_equal(a[k], b[k]) for k in ("templates", "moveouts", "weights", "data"))
+    assert np.allclose(a["data"].std(axis=-1), 1.0, atol=1e-4)
+    assert np.allclose(a["templates"].std(axis=-1), 1.0, atol=1e-4)
+    assert np.allclose(a["weights"].sum(axis=(1, 2)), 1.0, atol=1e-6)
+    assert (a["moveouts"][:, :, 1] == a["moveouts"][:, :, 2]).all() and a["moveouts"].min() >= 0
+    geo = syn.make_bp_geometry((5, 4, 3), 6, 2, 25.0)
+    assert geo["moveouts"].shape == (60, 6, 2) and geo["moveouts"].min(axis=(1, 2)).max() == 0
+    assert np.allclose(geo["weights_sources"].sum(axis=1), 1.0, atol=1e-6)
