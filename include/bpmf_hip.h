@@ -134,6 +134,41 @@ int bpmf_bp_pack_max_dev(const float *d_beam, const int32_t *d_arg, size_t N, in
 int bpmf_bp_unpack_max_dev(const uint64_t *d_packed, size_t N, int as_signed,
                            bpmf_stream_t stream, float *d_beam, int32_t *d_arg);
 
+/* ------------------------------------------------ post-CC detection threshold --- */
+/*
+ * Device version of the step right after the matched filter:
+ * BPMF.clib.time_dependent_threshold (BPMF/clib.py:257-309 -> BPMF/libc.c:516-673, RMS variant)
+ * for ALL rows of a (n_rows, n) CC matrix resident in HBM, and the extraction of the samples above
+ * the threshold (BPMF/similarity_search.py:231-232, with the cap of :629), so that only candidate
+ * records leave the device.  Results equal the reference's single-threaded libc.c bit for bit.
+ *   half_window = window // 2, shift = int((1 - overlap) * window)   (as clib.py:292-293)
+ *   gaussian: 500 standard-normal floats used to fill exact zeros (libc.c:606-612)
+ *   thr_windows (n_rows, n_win): one threshold per sliding window, after "delay the jump"
+ *   threshold (n_rows, n) or NULL: the step-wise expansion the reference returns
+ */
+size_t bpmf_tdt_num_windows(size_t n, size_t half_window, size_t shift);
+size_t bpmf_tdt_workspace_bytes(size_t n_rows, size_t n, size_t half_window, size_t shift);
+int bpmf_tdt_rms_dev(const float *d_series, const float *d_gaussian, float num_dev, size_t n_rows,
+                     size_t n, size_t half_window, size_t shift, void *d_workspace,
+                     size_t workspace_bytes, bpmf_stream_t stream, float *d_thr_windows,
+                     float *d_threshold);
+
+typedef struct bpmf_candidate {
+    int32_t row;     /* template (row of the CC matrix) */
+    int32_t index;   /* CC index (x step = data sample) */
+    float cc;        /* CC value */
+    float threshold; /* threshold it exceeded */
+} bpmf_candidate;
+
+/* Append one record per sample with cc > min(threshold, row_cap[row]) (row_cap may be NULL).
+ * *d_count receives the number of candidates found (may exceed `capacity`; only the first
+ * `capacity` are stored, in arbitrary order). */
+int bpmf_extract_candidates_dev(const float *d_series, const float *d_thr_windows,
+                                const float *d_row_cap, size_t n_rows, size_t n,
+                                size_t half_window, size_t shift, uint32_t capacity,
+                                bpmf_stream_t stream, uint32_t *d_count,
+                                bpmf_candidate *d_records);
+
 #ifdef __cplusplus
 }
 #endif

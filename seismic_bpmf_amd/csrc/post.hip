@@ -1,0 +1,293 @@
+// Post-CC detection step on the device ("next" row 1): the RMS
+// time-dependent threshold of BPMF/libc.c:516-673 for a whole (templates x n_corr) CC matrix
+// that already lives in HBM, and the extraction of the samples above it, so that only a few
+// thousand candidate records -- not 17-173 GB of CCs -- leave the GPU or cross xGMI.
+//
+// Conventions = oracle/adjacent_oracle.c:tdt_rms_cpu, which is pinned bit for bit to the
+// reference's compiled libc.c (single-threaded).  Bit-exactness fixes the summation order:
+// every window statistic is a SEQUENTIAL float accumulation over the window (with the squares
+// formed in double, as the reference's pow(x - m, 2)), so the parallelism is one thread per
+// (series, window) -- 24-32 k threads for a day of 500 templates -- each streaming its window.
+// This is the one HBM-bound stage of the workflow (reads the CC matrix four times).
+#include "common.h"
+#include "../../include/bpmf_hip.h"
+
+namespace bpmf {
+
+constexpr int GAUSSIAN_LEN = 500;
+
+// (1) per (row, global window): sum and count of the non-zero samples.       libc.c:553-571
+__global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, size_t n,
+                                    size_t window, size_t n_glob, float* __restrict__ part,
+                                    unsigned long long* __restrict__ cnt)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_glob) return;
+    size_t row = idx / n_glob, q = idx % n_glob;
+    const float* p = x + row * n + q * window;
+    float acc = 0.0f;
+    unsigned long long c = 0;
+    for (size_t j = 0; j < window; ++j) {
+        float v = p[j];
+        if (v != 0.0f) { acc += v; ++c; }
+    }
+    part[idx] = acc;
+    cnt[idx] = c;
+}
+
+// (2) per row: centre = (sequential sum of the partials) / count.            libc.c:567-573
+__global__ void tdt_glob_centre_kernel(const float* __restrict__ part,
+                                       const unsigned long long* __restrict__ cnt, size_t n_rows,
+                                       size_t n_glob, float* __restrict__ centre,
+                                       unsigned long long* __restrict__ total)
+{
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    float acc = 0.0f;
+    unsigned long long c = 0;
+    for (size_t q = 0; q < n_glob; ++q) { acc += part[row * n_glob + q]; c += cnt[row * n_glob + q]; }
+    centre[row] = acc / (float)c;
+    total[row] = c;
+}
+
+// (3) per (row, global window): sum of squared deviations of the non-zero samples (float
+//     accumulator, squares in double).                                       libc.c:574-586
+__global__ void tdt_glob_dev_kernel(const float* __restrict__ x, const float* __restrict__ centre,
+                                    size_t n_rows, size_t n, size_t window, size_t n_glob,
+                                    float* __restrict__ part)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_glob) return;
+    size_t row = idx / n_glob, q = idx % n_glob;
+    const float* p = x + row * n + q * window;
+    const float c = centre[row];
+    float acc = 0.0f;
+    for (size_t j = 0; j < window; ++j) {
+        float v = p[j];
+        if (v != 0.0f) {
+            double d = (double)(v - c);
+            acc = (float)((double)acc + d * d);
+        }
+    }
+    part[idx] = acc;
+}
+
+// (4) per row: dev = sqrtf(sum / count).                                      libc.c:584-587
+__global__ void tdt_glob_std_kernel(const float* __restrict__ part,
+                                    const unsigned long long* __restrict__ total, size_t n_rows,
+                                    size_t n_glob, float* __restrict__ dev)
+{
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    float acc = 0.0f;
+    for (size_t q = 0; q < n_glob; ++q) acc += part[row * n_glob + q];
+    dev[row] = sqrtf(acc / (float)total[row]);
+}
+
+// (5) per (row, sliding window): mean + num_dev * std of the window, with exact zeros replaced
+//     on the fly by centre + g[i mod 500] * dev (fused multiply-add, as the reference binary).
+//                                                                            libc.c:606-627
+__global__ void tdt_window_kernel(const float* __restrict__ x, const float* __restrict__ gauss,
+                                  const float* __restrict__ centre, const float* __restrict__ dev,
+                                  float num_dev, size_t n_rows, size_t n, size_t window,
+                                  size_t shift, size_t n_win, float* __restrict__ thr_win)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n_win) return;
+    size_t row = idx / n_win, q = idx % n_win;
+    const size_t i0 = q * shift;
+    const float* p = x + row * n + i0;
+    const float c = centre[row], dv = dev[row];
+    float acc = 0.0f;
+    for (size_t j = 0; j < window; ++j) {
+        float v = p[j];
+        if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
+        acc += v;
+    }
+    const float mean = acc / (float)window;
+    float ss = 0.0f;
+    for (size_t j = 0; j < window; ++j) {
+        float v = p[j];
+        if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
+        double d = (double)(v - mean);
+        ss = (float)((double)ss + d * d);
+    }
+    thr_win[idx] = __fmaf_rn(num_dev, sqrtf(ss / (float)window), mean);
+}
+
+// (6) per row: "delay the jump" -- a drop is postponed by one window, a rise anticipated by
+//     one window; `diff` is scratch of n_win floats per row.                  libc.c:631-651
+__global__ void tdt_smooth_kernel(float* __restrict__ thr_win, float* __restrict__ diff,
+                                  size_t n_rows, size_t n_win)
+{
+    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows || n_win < 2) return;
+    float* w = thr_win + row * n_win;
+    float* d = diff + row * n_win;
+    for (size_t q = 0; q + 1 < n_win; ++q) d[q] = w[q + 1] - w[q];
+    for (size_t q = 1; q < n_win; ++q) {
+        if (d[q - 1] < 0.0f) w[q] -= d[q - 1];
+        d[q - 1] = w[q] - w[q - 1];
+    }
+    for (size_t q = 0; q + 1 < n_win; ++q)
+        if (d[q] > 0.0f) w[q] += d[q];
+}
+
+__device__ __forceinline__ size_t tdt_window_of(size_t i, size_t n, size_t shift, size_t n_win)
+{
+    if (i < shift) return 0;
+    if (i >= n - shift) return n_win - 1;
+    size_t q = i / shift;
+    return q > n_win - 1 ? n_win - 1 : q;  // clamp: documented deviation (reference reads past the end)
+}
+
+// (7, optional) step-wise expansion to one threshold per sample.             libc.c:654-669
+__global__ void tdt_expand_kernel(const float* __restrict__ thr_win, size_t n_rows, size_t n,
+                                  size_t shift, size_t n_win, float* __restrict__ thr)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t row = blockIdx.y;
+    if (i >= n) return;
+    thr[row * n + i] = thr_win[row * n_win + tdt_window_of(i, n, shift, n_win)];
+}
+
+// Candidate extraction: every sample with cc > min(threshold, cap[row]) becomes one record
+// (row, index, cc, threshold).  BPMF/similarity_search.py:629 (cap) and :231-232 (test).
+// Records are appended in arbitrary order; the host sorts the (few thousand) survivors.
+__global__ void cand_extract_kernel(const float* __restrict__ x, const float* __restrict__ thr_win,
+                                    const float* __restrict__ row_cap, size_t n_rows, size_t n,
+                                    size_t shift, size_t n_win, unsigned capacity,
+                                    unsigned* __restrict__ count, int4* __restrict__ records)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t row = blockIdx.y;
+    if (i >= n) return;
+    float t = thr_win[row * n_win + tdt_window_of(i, n, shift, n_win)];
+    if (row_cap) t = fminf(row_cap[row], t);
+    const float v = x[row * n + i];
+    if (v > t) {
+        unsigned slot = atomicAdd(count, 1u);
+        if (slot < capacity)
+            records[slot] = make_int4((int)row, (int)i, __float_as_int(v), __float_as_int(t));
+    }
+}
+
+struct TdtWorkspace {
+    float* part;               // [rows, n_glob]
+    unsigned long long* cnt;   // [rows, n_glob]
+    unsigned long long* total; // [rows]
+    float* centre;             // [rows]
+    float* dev;                // [rows]
+    float* diff;               // [rows, n_win]
+    size_t bytes;
+};
+
+static TdtWorkspace tdt_carve(void* base, size_t rows, size_t n_glob, size_t n_win)
+{
+    TdtWorkspace ws;
+    char* p = (char*)base;
+    size_t o = 0;
+    ws.part = (float*)(p + o);               o += align_up(rows * n_glob * sizeof(float), 256);
+    ws.cnt = (unsigned long long*)(p + o);   o += align_up(rows * n_glob * 8, 256);
+    ws.total = (unsigned long long*)(p + o); o += align_up(rows * 8, 256);
+    ws.centre = (float*)(p + o);             o += align_up(rows * sizeof(float), 256);
+    ws.dev = (float*)(p + o);                o += align_up(rows * sizeof(float), 256);
+    ws.diff = (float*)(p + o);               o += align_up(rows * n_win * sizeof(float), 256);
+    ws.bytes = o;
+    return ws;
+}
+
+static int tdt_sizes(size_t n, size_t half_window, size_t shift, size_t* window, size_t* n_glob,
+                     size_t* n_win)
+{
+    *window = 2 * half_window;
+    if (*window == 0 || shift == 0 || shift > *window || n < *window) return -1;
+    *n_win = (n - (*window - shift)) / shift;
+    *n_glob = n / *window;
+    return *n_win >= 1 ? 0 : -1;
+}
+
+}  // namespace bpmf
+
+using namespace bpmf;
+
+extern "C" size_t bpmf_tdt_num_windows(size_t n, size_t half_window, size_t shift)
+{
+    size_t w, g, nw;
+    return tdt_sizes(n, half_window, shift, &w, &g, &nw) ? 0 : nw;
+}
+
+extern "C" size_t bpmf_tdt_workspace_bytes(size_t n_rows, size_t n, size_t half_window, size_t shift)
+{
+    size_t w, g, nw;
+    if (tdt_sizes(n, half_window, shift, &w, &g, &nw)) return 0;
+    return tdt_carve(nullptr, n_rows, g, nw).bytes;
+}
+
+extern "C" int bpmf_tdt_rms_dev(const float* d_series, const float* d_gaussian, float num_dev,
+                                size_t n_rows, size_t n, size_t half_window, size_t shift,
+                                void* d_workspace, size_t workspace_bytes, bpmf_stream_t stream_,
+                                float* d_thr_windows, float* d_threshold)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t window, n_glob, n_win;
+    if (!d_series || !d_gaussian || !d_workspace || !d_thr_windows || n_rows == 0 ||
+        tdt_sizes(n, half_window, shift, &window, &n_glob, &n_win)) {
+        set_error("bpmf_tdt_rms_dev: bad argument (n=%zu half_window=%zu shift=%zu)", n,
+                  half_window, shift);
+        return -1;
+    }
+    TdtWorkspace ws = tdt_carve(d_workspace, n_rows, n_glob, n_win);
+    if (workspace_bytes < ws.bytes) {
+        set_error("bpmf_tdt_rms_dev: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+        return -1;
+    }
+    const unsigned B = 64;
+    auto blocks = [&](size_t work) { return dim3((unsigned)((work + B - 1) / B)); };
+    tdt_glob_sum_kernel<<<blocks(n_rows * n_glob), dim3(B), 0, stream>>>(d_series, n_rows, n, window,
+                                                                        n_glob, ws.part, ws.cnt);
+    BPMF_LAUNCH_CHECK();
+    tdt_glob_centre_kernel<<<blocks(n_rows), dim3(B), 0, stream>>>(ws.part, ws.cnt, n_rows, n_glob,
+                                                                   ws.centre, ws.total);
+    BPMF_LAUNCH_CHECK();
+    tdt_glob_dev_kernel<<<blocks(n_rows * n_glob), dim3(B), 0, stream>>>(d_series, ws.centre, n_rows, n,
+                                                                        window, n_glob, ws.part);
+    BPMF_LAUNCH_CHECK();
+    tdt_glob_std_kernel<<<blocks(n_rows), dim3(B), 0, stream>>>(ws.part, ws.total, n_rows, n_glob,
+                                                                ws.dev);
+    BPMF_LAUNCH_CHECK();
+    tdt_window_kernel<<<blocks(n_rows * n_win), dim3(B), 0, stream>>>(
+        d_series, d_gaussian, ws.centre, ws.dev, num_dev, n_rows, n, window, shift, n_win,
+        d_thr_windows);
+    BPMF_LAUNCH_CHECK();
+    tdt_smooth_kernel<<<blocks(n_rows), dim3(B), 0, stream>>>(d_thr_windows, ws.diff, n_rows, n_win);
+    BPMF_LAUNCH_CHECK();
+    if (d_threshold) {
+        if (n_rows > 65535) { set_error("bpmf_tdt_rms_dev: at most 65535 rows per call"); return -1; }
+        tdt_expand_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n_rows), dim3(256), 0, stream>>>(
+            d_thr_windows, n_rows, n, shift, n_win, d_threshold);
+        BPMF_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d_thr_windows,
+                                           const float* d_row_cap, size_t n_rows, size_t n,
+                                           size_t half_window, size_t shift, uint32_t capacity,
+                                           bpmf_stream_t stream_, uint32_t* d_count,
+                                           bpmf_candidate* d_records)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t window, n_glob, n_win;
+    if (!d_series || !d_thr_windows || !d_count || !d_records || n_rows == 0 || n_rows > 65535 ||
+        n > 0x7fffffffull || tdt_sizes(n, half_window, shift, &window, &n_glob, &n_win)) {
+        set_error("bpmf_extract_candidates_dev: bad argument");
+        return -1;
+    }
+    BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+    cand_extract_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n_rows), dim3(256), 0, stream>>>(
+        d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, capacity, d_count,
+        (int4*)d_records);
+    BPMF_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,93 @@
+"""Device-side post-CC step: RMS time-dependent threshold + candidate extraction.
+
+Mirrors ``BPMF.clib.time_dependent_threshold`` (BPMF/clib.py:257-309, RMS variant of
+BPMF/libc.c:516-673) for every row of a CC matrix that is already in HBM (the output of
+:class:`MatchedFilterGPU`), and the first test of ``MatchedFilter.select_cc_indexes``
+(``cc > threshold``, BPMF/similarity_search.py:231-232, capped as in :629).  Only the candidate
+records come back to the host, where :func:`seismic_bpmf_amd.postprocess.select_cc_indexes`-style
+merging runs on a few thousand entries instead of millions of samples.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+GAUSSIAN_SAMPLE_LEN = 500
+
+candidate_dtype = np.dtype([("row", np.int32), ("index", np.int32), ("cc", np.float32),
+                            ("threshold", np.float32)])
+
+
+def window_params(sliding_window_samp, overlap):
+    """(half_window, shift) exactly as BPMF/clib.py:292-293."""
+    return int(sliding_window_samp) // 2, int((1.0 - overlap) * int(sliding_window_samp))
+
+
+class ThresholdGPU:
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.BpmfHipError("ThresholdGPU needs a HIP device")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.lib = _lib.lib()
+        self._ws = None
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def time_dependent_threshold(self, cc, sliding_window_samp, num_dev, overlap=0.66,
+                                 white_noise=None, expand=False):
+        """cc: (rows, n) float32 device tensor.  Returns (thr_windows (rows, n_win), full or None)."""
+        t = self.torch
+        cc = cc.contiguous()
+        if cc.dim() == 1:
+            cc = cc[None]
+        rows, n = cc.shape
+        half, shift = window_params(sliding_window_samp, overlap)
+        n_win = self.lib.bpmf_tdt_num_windows(n, half, shift)
+        if n_win == 0:
+            raise ValueError("series shorter than the sliding window")
+        if white_noise is None:
+            white_noise = np.random.normal(size=GAUSSIAN_SAMPLE_LEN).astype("float32")
+        g = t.as_tensor(np.ascontiguousarray(white_noise[:GAUSSIAN_SAMPLE_LEN], dtype=np.float32),
+                        device=self.device)
+        nbytes = self.lib.bpmf_tdt_workspace_bytes(rows, n, half, shift)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        thr_win = t.empty((rows, n_win), dtype=t.float32, device=self.device)
+        full = t.empty((rows, n), dtype=t.float32, device=self.device) if expand else None
+        with t.cuda.device(self.device):
+            rc = self.lib.bpmf_tdt_rms_dev(cc.data_ptr(), g.data_ptr(), float(num_dev), rows, n, half,
+                                           shift, self._ws.data_ptr(), self._ws.numel(),
+                                           self._stream(), thr_win.data_ptr(),
+                                           full.data_ptr() if expand else None)
+        _lib.check(rc, "bpmf_tdt_rms_dev")
+        self._keep = (cc, g)
+        return thr_win, full
+
+    def extract_candidates(self, cc, thr_windows, sliding_window_samp, overlap=0.66, row_cap=None,
+                           capacity=1 << 20):
+        """Records (row, index, cc, threshold) of every sample above min(threshold, row_cap)."""
+        t = self.torch
+        cc = cc.contiguous()
+        if cc.dim() == 1:
+            cc = cc[None]
+        rows, n = cc.shape
+        half, shift = window_params(sliding_window_samp, overlap)
+        cap = None
+        if row_cap is not None:
+            cap = t.as_tensor(np.ascontiguousarray(row_cap, dtype=np.float32), device=self.device)
+        count = t.zeros(1, dtype=t.int32, device=self.device)
+        rec = t.empty((capacity, 4), dtype=t.int32, device=self.device)
+        with t.cuda.device(self.device):
+            rc = self.lib.bpmf_extract_candidates_dev(
+                cc.data_ptr(), thr_windows.contiguous().data_ptr(), cap.data_ptr() if cap is not None else None,
+                rows, n, half, shift, capacity, self._stream(), count.data_ptr(), rec.data_ptr())
+        _lib.check(rc, "bpmf_extract_candidates_dev")
+        n_found = int(count.item())
+        if n_found > capacity:
+            raise _lib.BpmfHipError(f"{n_found} candidates exceed the capacity {capacity}")
+        out = rec[:n_found].cpu().numpy().view(candidate_dtype).reshape(-1)
+        return out[np.lexsort((out["index"], out["row"]))]

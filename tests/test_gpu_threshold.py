@@ -1,0 +1,87 @@
+"""GPU: the device post-CC step against golden vectors of the reference's own libc.c
+(tests/golden/tdt_rms.npz) and against the pinned CPU oracle.  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_tdt_rms_matches_reference_goldens():
+    import torch
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    g = np.load(os.path.join(GOLD, "tdt_rms.npz"))
+    th = ThresholdGPU()
+    for j in range(int(g["n_cases"])):
+        x = torch.as_tensor(g[f"x_{j}"], device="cuda")
+        _, full = th.time_dependent_threshold(x, int(g[f"window_{j}"]), float(g[f"num_dev_{j}"]),
+                                              overlap=float(g[f"overlap_{j}"]),
+                                              white_noise=g[f"white_noise_{j}"], expand=True)
+        got = full.cpu().numpy()[0]
+        want = g[f"thr_{j}"]
+        assert np.array_equal(got, want), f"case {j}: max |diff| {np.abs(got - want).max()}"
+
+
+def test_tdt_rms_batched_rows_and_candidates(oracle_lib):
+    """Many rows at once (as for a (T, n_corr) CC matrix) + candidate extraction."""
+    import torch
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    rng = np.random.default_rng(3)
+    rows, n, window, overlap = 7, 60_000, 6000, 0.25
+    x = (0.02 * rng.standard_normal((rows, n))).astype(np.float32)
+    x[2, 1000:4000] = 0.0
+    for r in range(rows):
+        for p in rng.integers(200, n - 200, 9):
+            x[r, p] += rng.uniform(0.3, 0.9)
+    wn = rng.standard_normal(500).astype(np.float32)
+    th = ThresholdGPU()
+    xd = torch.as_tensor(x, device="cuda")
+    thr_win, full = th.time_dependent_threshold(xd, window, 8.0, overlap=overlap, white_noise=wn,
+                                                expand=True)
+    full = full.cpu().numpy()
+    for r in range(rows):
+        want = oracle_lib.time_dependent_threshold(x[r], window, 8.0, overlap, wn)
+        assert np.array_equal(full[r], want), r
+    cap = np.full(rows, 0.5, dtype=np.float32)
+    cand = th.extract_candidates(xd, thr_win, window, overlap=overlap, row_cap=cap)
+    thr_capped = np.minimum(full, cap[:, None])
+    rr, ii = np.nonzero(x > thr_capped)
+    assert np.array_equal(cand["row"], rr) and np.array_equal(cand["index"], ii)
+    assert np.array_equal(cand["cc"], x[rr, ii]) and np.array_equal(cand["threshold"], thr_capped[rr, ii])
+    assert 20 < cand.size < 500
+
+
+def test_end_to_end_planted_events_are_detected_at_exact_samples(oracle_lib):
+    """MF on device -> threshold on device -> candidates -> host merge: the planted events come
+    out at exactly the planted CC indices, identical to the CPU oracle pipeline."""
+    import torch
+    from seismic_bpmf_amd import MatchedFilterGPU, postprocess as pp, synthetic as syn
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    mf_in = syn.make_mf_inputs(T=3, S=5, C=3, L=64, N=120_000, seed=11, max_moveout=300, n_events=4)
+    mf = MatchedFilterGPU()
+    mf.set_data(mf_in["data"])
+    cc = mf.run(mf_in["templates"], mf_in["moveouts"], mf_in["weights"], 1)
+    cc_ref = oracle_lib.matched_filter(mf_in["templates"], mf_in["moveouts"], mf_in["weights"], mf_in["data"], 1)
+    assert np.array_equal(cc.cpu().numpy(), cc_ref)
+    window, overlap, wn = 20_000, 0.25, np.random.default_rng(1).standard_normal(500).astype(np.float32)
+    th = ThresholdGPU()
+    thr_win, _ = th.time_dependent_threshold(cc, window, 8.0, overlap=overlap, white_noise=wn)
+    cand = th.extract_candidates(cc, thr_win, window, overlap=overlap)
+    for t in range(3):
+        thr_ref = oracle_lib.time_dependent_threshold(cc_ref[t], window, 8.0, overlap, wn)
+        # host merge of the sparse candidates == reference-style selection on the full series
+        want = pp.select_cc_indexes(cc_ref[t], thr_ref, 500, step=1, sr=100.0, data_duration_sec=1e9,
+                                    n_dev_threshold=8.0, min_freq_hz=2.0, data_buffer_sec=0.0,
+                                    remove_edges=False, anomalous_cdf_at_mean_plus_1sig=0.0)
+        mine = cand[cand["row"] == t]
+        sparse = np.zeros_like(cc_ref[t])
+        sparse[mine["index"]] = mine["cc"]
+        got = pp.select_cc_indexes(sparse, np.where(sparse > 0, 0.0, np.inf).astype(np.float32), 500,
+                                   step=1, sr=100.0, data_duration_sec=1e9, n_dev_threshold=8.0,
+                                   min_freq_hz=2.0, data_buffer_sec=0.0, remove_edges=False,
+                                   anomalous_cdf_at_mean_plus_1sig=0.0)
+        assert np.array_equal(got, want)
+        planted = sorted(i0 for tt, i0 in mf_in["planted"] if tt == t)
+        assert list(got) == planted, (t, got, planted)
