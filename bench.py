@@ -81,7 +81,8 @@ def mf_inputs_device(cfg, device, seed):
             j = (slots[t, e] * 4 * L + mv[t].long())[..., None] + ar        # (S, C, L)
             data.scatter_add_(2, j, amps[t, e] * tmpl[t])
     data /= data.std(dim=-1, keepdim=True)
-    return tmpl, mv, w, data
+    planted = (slots * 4 * L).cpu().numpy()            # (T, n_ev) CC indices of the planted events
+    return tmpl, mv, w, data, planted
 
 
 def bp_inputs(cfg, device, seed, rank, world):
@@ -144,6 +145,58 @@ def cpu_baseline(cfg, target_seconds):
                       f"gcc -O3 -march={march}), {dt:.1f} s wall"}
 
 
+# ------------------------------------------------------- detection stage (untimed extra) ---
+def detection_stage(cc, planted, local_rank, dist, device):
+    """What follows the hot path in BPMF (similarity_search.py:620-666), on the CC matrix that is
+    still in HBM: RMS threshold on device, candidates above it, host merge, and -- for N > 1 -- the
+    all-gather of the per-rank peak records (the path's only inter-GPU traffic).  Reported beside
+    the headline numbers, never inside the timed region.  Also a full-size correctness check: every
+    planted event must be detected at exactly its planted CC index."""
+    from seismic_bpmf_amd import parallel, postprocess as pp
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    th = ThresholdGPU(device=local_rank)
+    window, overlap = 180_000, 0.25                       # 30 min @ 100 Hz
+    wn = np.random.default_rng(5).standard_normal(500).astype(np.float32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    thr_win, _ = th.time_dependent_threshold(cc, window, 8.0, overlap=overlap, white_noise=wn)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    cand = th.extract_candidates(cc, thr_win, window, overlap=overlap)
+    t2 = time.perf_counter()
+    found = exact = 0
+    n_det = 0
+    for t in range(planted.shape[0]):
+        mine = cand[cand["row"] == t]
+        idx = list(mine["index"])
+        val = list(mine["cc"])
+        q = 1                                   # pair-wise merge, similarity_search.py:240-251
+        while q < len(idx):
+            if idx[q] - idx[q - 1] < 512:
+                drop = q - 1 if val[q] > val[q - 1] else q
+                del idx[drop], val[drop]
+            else:
+                q += 1
+        n_det += len(idx)
+        exact += len(set(idx) & set(planted[t].tolist()))
+        found += planted.shape[1]
+    out = {"threshold_ms": round((t1 - t0) * 1e3, 1), "candidates_ms": round((t2 - t1) * 1e3, 1),
+           "candidates": int(cand.size), "detections": n_det, "planted": found,
+           "planted_found_at_exact_index": exact}
+    if dist is not None:
+        rec = torch.zeros((8192, 4), dtype=torch.int32, device=device)
+        k = min(int(cand.size), 8192)
+        if k:
+            rec[:k] = torch.as_tensor(cand[:k].view(np.int32).reshape(-1, 4), device=device)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        parts = parallel.allgather_records(rec, k)
+        torch.cuda.synchronize()
+        out["allgather_records_ms"] = round((time.perf_counter() - t3) * 1e3, 2)
+        out["records_all_ranks"] = int(sum(len(p) for p in parts))
+    return out
+
+
 # ------------------------------------------------------------------------------- main ---
 def main():
     args = parse()
@@ -193,7 +246,7 @@ def main():
         cfg["T"] = args.templates
     T, S, C, L, N = cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"]
     n_corr = N - L + 1
-    tmpl, mv, w, data = mf_inputs_device(cfg, device, 20260928 + 1000 * rank)
+    tmpl, mv, w, data, planted = mf_inputs_device(cfg, device, 20260928 + 1000 * rank)
     mf = sb.MatchedFilterGPU(device=local_rank)
     mf.set_data(data)
     cc = torch.empty((T, n_corr), dtype=torch.float32, device=device)
@@ -221,8 +274,8 @@ def main():
                 "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",
                 "hbm_frac_informational": round(
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    # sanity inside the bench: planted events must be the row maxima region (cheap check)
     peak = float(cc[0].max().item())
+    detect = detection_stage(cc, planted, local_rank, dist, device)
     del cc, mf
     torch.cuda.empty_cache()
 
@@ -279,7 +332,7 @@ def main():
                        "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
                        "parallelism": f"templates sharded x{world}" if world > 1 else "single GPU",
                        "row0_peak_cc": round(peak, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj,
+            "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj, "detection": detect,
         }
         def _clean(o):  # NaN is not JSON
             if isinstance(o, float) and not math.isfinite(o):

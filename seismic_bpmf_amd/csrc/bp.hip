@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
 // broadcast (the limiter of the time-split kernel: 13 x 1 KiB per source per wave) by four,
 // and one address add serves TPW gathers.  Every wave keeps its own running (max, arg-max)
 // for the tile; they are merged through LDS at the end with the same (value, lowest id) order.
-template <int TPW, int NTV, int OOB, int REDUCE>
+template <int TPW, int NTV, int OOB, int REDUCE, int PAIR>
 __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
@@ -421,7 +421,10 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const long long t0 = (long long)blockIdx.x * TILE;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    const char* lds_l = (const char*)lds + lane * 4;
+    // sample j of this lane inside the tile: lane + 64 j, or (PAIR) adjacent samples
+    // 2 lane + {0,1} + 128 (j/2) fetched as one 8-byte LDS read
+    auto tmap = [&](int j) { return PAIR ? 2 * lane + 128 * (j >> 1) + (j & 1) : lane + 64 * j; };
+    const char* lds_l = (const char*)lds + lane * (PAIR ? 8 : 4);
 
     float best[TPW];
     int arg[TPW];
@@ -477,8 +480,19 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
                     const float* lp0 = (const float*)(lds_l + tt.x);
                     const float* lp1 = (const float*)(lds_l + tt.z);
                     float x0[TPW], x1[TPW];
+                    if (PAIR) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
+                        for (int j = 0; j < TPW; j += 2) {
+                            const f32x2 v0 = *(const f32x2*)(lp0 + j * 64);  // +128 floats per pair
+                            const f32x2 v1 = *(const f32x2*)(lp1 + j * 64);
+                            x0[j] = v0[0]; x0[j + 1] = v0[1];
+                            x1[j] = v1[0]; x1[j + 1] = v1[1];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
+                    }
                     const float b0 = __int_as_float(tt.y), b1 = __int_as_float(tt.w);
 #pragma unroll
                     for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(b0, x0[j], acc[j]);
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
             const int sid = m.hd.x;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                const long long t = t0 + lane + j * 64;
+                const long long t = t0 + tmap(j);
                 bool computed = nterm > 0;
                 if (OOB == BPMF_BP_STRICT) computed = computed && (t + m.hd.y >= 0) && (t + m.hd.z < N);
                 if (REDUCE == BPMF_BP_REDUCE_MAX) {
@@ -517,8 +531,8 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
         int* ma = (int*)(lds + NW * TILE);     // [NW][TILE]
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-            mb[wv * TILE + lane + 64 * j] = best[j];
-            ma[wv * TILE + lane + 64 * j] = arg[j];
+            mb[wv * TILE + tmap(j)] = best[j];
+            ma[wv * TILE + tmap(j)] = arg[j];
         }
         __syncthreads();
         for (int x = tid; x < TILE; x += BP_THREADS) {
@@ -590,6 +604,7 @@ struct bpmf_bp_plan {
     float* d_beta = nullptr;
     int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
     int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
+    int pair = 0;                // wps kernel: adjacent-sample pairs per lane (8-byte LDS reads)
     BpTermV* d_termsv = nullptr; // [K, ntv]
 };
 
@@ -821,6 +836,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     const int ntv_opts[4] = {8, 16, 24, 32};
     const bool want_uv = env_int("BPMF_BP_UVGPR", 1) != 0;
     pl->wps = env_int("BPMF_BP_WPS", 1);
+    pl->pair = env_int("BPMF_BP_PAIR", 0);
     std::vector<BpTermV> tv;
     for (int o = 0; o < 4 && want_uv && !pl->ntv; ++o)
         if (ph.NT <= ntv_opts[o]) pl->ntv = ntv_opts[o];
@@ -937,11 +953,11 @@ int dispatch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, 
     return launch_beam_uv<TPT, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
-template <int TPW, int NTV, int OOB, int REDUCE>
+template <int TPW, int NTV, int OOB, int REDUCE, int PAIR>
 int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                     float* beam, int32_t* arg)
 {
-    auto kern = bp_beam_wps_kernel<TPW, NTV, OOB, REDUCE>;
+    auto kern = bp_beam_wps_kernel<TPW, NTV, OOB, REDUCE, PAIR>;
     // the end-of-kernel merge needs 2 * 4 * tile floats of LDS
     const size_t lds = std::max(pl->lds_bytes, (size_t)8 * 64 * TPW * sizeof(float));
     if (lds > 64 * 1024)
@@ -959,17 +975,25 @@ int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_
     return 0;
 }
 
+template <int TPW, int NTV, int PAIR>
+int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                       hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX, PAIR>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX, PAIR>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE, PAIR>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE, PAIR>(pl, U, N, stream, beam, arg);
+}
+
 template <int TPW, int NTV>
 int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                       hipStream_t stream, float* beam, int32_t* arg)
 {
-    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_STRICT)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
-    return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    if (pl->pair) return dispatch_beam_wps2<TPW, NTV, 1>(pl, U, N, oob, reduce, stream, beam, arg);
+    return dispatch_beam_wps2<TPW, NTV, 0>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
 template <int TPT>

@@ -86,6 +86,8 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
         raise NotImplementedError("only normalize='short' (no window-mean removal) is implemented; "
                                   "it is the only mode the BPMF workflow uses")
     step = int(step)
+    if step < 1:
+        raise ValueError("step must be a positive number of samples")
     tp, mv, w, d = _prepare_host(templates, moveouts, weights, data)
     T, S, Cc, L = tp.shape
     N = d.shape[-1]

@@ -1,0 +1,121 @@
+"""GPU: every kernel variant the dispatchers can pick, each bit-exact against the oracle.
+
+MF: staging-register variants (L <= 273 / 1041 / 2065), the generic kernel beyond, step > 1.
+BP: wave-per-source (<= 32 terms/source), uniform-VGPR time-split, readlane kernels with 1 / 2 / 4
+metadata blocks (up to 256 terms/source), tile fall-backs, P = 1 / 3 / 5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    assert a.shape == b.shape, what
+    if not np.array_equal(a, b):
+        raise AssertionError(f"{what}: {(a != b).sum()} of {a.size} differ, max |diff| "
+                             f"{np.abs(a.astype(np.float64) - b).max():.3e}")
+
+
+@pytest.mark.parametrize("L", [1, 7, 273, 274, 600, 1041, 1500, 2065, 2100])
+def test_mf_template_length_variants(oracle_lib, L):
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(L)
+    T, S, C, N = 2, 2, 3, max(3 * L + 500, 6000)
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-20, 200, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, d, 1, check_zeros=False, network_sum=ns)
+        _same(got, oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"MF L={L} network_sum={ns}")
+
+
+def test_mf_lag_block_boundaries(oracle_lib):
+    """n_corr around multiples of the 4096-lag workgroup / 1024-lag wave / 256-lag tile."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(0)
+    L = 48
+    for n_corr in (1, 255, 256, 257, 1023, 1025, 4095, 4096, 4097, 8193):
+        N = n_corr + L - 1
+        tp = rng.standard_normal((2, 2, 2, L)).astype(np.float32)
+        mv = np.zeros((2, 2, 2), np.int32)
+        w = np.full((2, 2, 2), 0.25, np.float32)
+        d = rng.standard_normal((2, 2, N)).astype(np.float32)
+        _same(matched_filter(tp, mv, w, d, 1, check_zeros=False), oracle_lib.matched_filter(tp, mv, w, d, 1),
+              f"n_corr={n_corr}")
+
+
+def test_mf_many_templates_and_channels(oracle_lib):
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(2)
+    T, S, C, L, N = 37, 7, 3, 40, 5000
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(0, 400, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[rng.random((T, S, C)) < 0.5] = 0.0   # "closest stations"-style sparse weights
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    _same(matched_filter(tp, mv, w, d, 1, check_zeros=False), oracle_lib.matched_filter(tp, mv, w, d, 1), "MF sparse")
+
+
+def _bp_inputs(rng, K, S, P, N, tau_max, density):
+    f = np.abs(rng.standard_normal((S, 3, N))).astype(np.float32)
+    tau = rng.integers(0, tau_max + 1, (K, S, P)).astype(np.int32)
+    wp = rng.random((S, 3, P)).astype(np.float32)
+    ws = rng.random((K, S)).astype(np.float32)
+    ws[rng.random((K, S)) > density] = 0.0
+    return f, tau, wp, ws
+
+
+def _bp_check(oracle_lib, f, tau, wp, ws, what):
+    from seismic_bpmf_amd import beamform
+    for oob in ("strict", "flexible"):
+        mb, ma = beamform(f, tau, wp, ws, reduce="max", out_of_bounds=oob)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        _same(mb, ob, f"{what} {oob} maxbeam")
+        assert np.array_equal(ma, oa), f"{what} {oob}: {(ma != oa).sum()} arg-max differ"
+    _same(beamform(f, tau, wp, ws, reduce="none"), oracle_lib.beamform(f, tau, wp, ws, "strict", "none"),
+          f"{what} full beam")
+
+
+@pytest.mark.parametrize("S,P,density,label", [(6, 2, 0.6, "wps <=8..16 terms"), (14, 2, 1.0, "wps 28 terms"),
+                                               (20, 2, 1.0, "readlane 40 terms"), (40, 2, 1.0, "readlane 80 terms"),
+                                               (45, 3, 1.0, "readlane 135 terms"), (9, 1, 0.8, "P=1"),
+                                               (6, 5, 1.0, "P=5 prestack_any")])
+def test_bp_term_count_variants(oracle_lib, S, P, density, label):
+    rng = np.random.default_rng(S * 10 + P)
+    f, tau, wp, ws = _bp_inputs(rng, 120, S, P, 2500, 150, density)
+    _bp_check(oracle_lib, f, tau, wp, ws, label)
+
+
+@pytest.mark.parametrize("env", [{"BPMF_BP_WPS": "0"}, {"BPMF_BP_UVGPR": "0"}, {"BPMF_BP_UVGPR": "0", "BPMF_BP_CHUNK": "8"},
+                                 {"BPMF_BP_TPT": "1", "BPMF_BP_WPS": "0"}, {"BPMF_BP_TPT": "4", "BPMF_BP_WPS": "0"},
+                                 {"BPMF_BP_REORDER": "0"}, {"BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "5"}])
+def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(99)
+    f, tau, wp, ws = _bp_inputs(rng, 200, 8, 2, 3000, 250, 0.7)
+    _bp_check(oracle_lib, f, tau, wp, ws, str(env))
+
+
+def test_bp_huge_moveout_spread_falls_back_to_smaller_tiles(oracle_lib):
+    """Moveouts spread over ~30 000 samples: windows only fit with the smallest tile."""
+    rng = np.random.default_rng(7)
+    f, tau, wp, ws = _bp_inputs(rng, 30, 6, 2, 40_000, 30_000, 1.0)
+    _bp_check(oracle_lib, f, tau, wp, ws, "huge spread")
+
+
+def test_bad_arguments_raise_with_a_message():
+    import seismic_bpmf_amd as sb
+    from seismic_bpmf_amd import _lib
+    tp = np.zeros((1, 1, 1, 100), np.float32)
+    with pytest.raises(ValueError):
+        sb.matched_filter(tp, np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 1, 50), np.float32), 1)
+    with pytest.raises(ValueError, match="step"):
+        sb.matched_filter(tp, np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 1, 500), np.float32), 0)
+    with pytest.raises(_lib.BpmfHipError, match="station-phase"):
+        sb.beamform(np.zeros((150, 1, 100), np.float32), np.zeros((2, 150, 2), np.int32),
+                    np.ones((150, 1, 2), np.float32), np.ones((2, 150), np.float32))
