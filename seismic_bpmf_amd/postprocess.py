@@ -198,3 +198,31 @@ def time_dependent_threshold_mad(time_series, sliding_window, n_dev, overlap=0.6
     thr = thr[where]
     return np.hstack((thr[0] * np.ones(half, dtype=np.float32), thr,
                       thr[-1] * np.ones(sliding_window - half, dtype=np.float32)))
+
+
+def bp_time_dependent_threshold(network_response, window, n_dev, overlap=0.75):
+    """Detection threshold on the maximum beam (BP side of row BP-6),
+    BPMF/template_search.py:1418-1487: median + n_dev * MAD over sliding windows (float32
+    per-window values), the first/last window repeated at the ends, linear interpolation
+    between window centres."""
+    x = np.asarray(network_response)
+    n = x.size
+    shift = int((1.0 - overlap) * window)
+    n_windows = int((n - window) // shift) + 1
+    med = np.zeros(n_windows + 2, dtype=np.float32)
+    mad = np.zeros(n_windows + 2, dtype=np.float32)
+    centre = np.zeros(n_windows + 2, dtype=np.float32)
+    for q in range(1, n_windows + 1):
+        i1 = q * shift
+        i2 = min(n, i1 + window)
+        seg = x[i1:i2]
+        m = np.median(seg)
+        med[q] = m
+        mad[q] = np.median(np.abs(seg - m))
+        centre[q] = (i1 + i2) / 2.0
+    med[0], mad[0], centre[0] = med[1], mad[1], 0.0
+    med[-1], mad[-1], centre[-1] = med[-2], mad[-2], n
+    thr = med + n_dev * mad
+    # scipy interp1d(kind="slinear", bounds_error=False, fill_value=(first, last))
+    return np.interp(np.arange(n, dtype=np.float64), centre.astype(np.float64), thr.astype(np.float64),
+                     left=thr[0], right=thr[-1])

@@ -206,6 +206,11 @@ def main():
                                                      white_noise=wn)
     np.savez_compressed(os.path.join(HERE, "tdt_mad.npz"), x=x, white_noise=wn, window=6000,
                         overlap=0.5, n_dev=8.0, thr=np.asarray(thr))
+    # ---- template_search.time_dependent_threshold (median/MAD on the max beam) ----------------
+    mb = (np.abs(rng.standard_normal(40_000)) + 6 * (rng.random(40_000) > 0.998)).astype(np.float32)
+    thr = template_search.time_dependent_threshold(mb, 3000, overlap=0.75, CNR_threshold=15.0)
+    np.savez_compressed(os.path.join(HERE, "bp_threshold.npz"), maxbeam=mb, window=3000, overlap=0.75,
+                        n_dev=15.0, thr=np.asarray(thr))
     print("goldens written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):

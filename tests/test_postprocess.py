@@ -87,3 +87,34 @@ def test_synthetic_generators_are_seeded_and_conditioned():
     geo = syn.make_bp_geometry((5, 4, 3), 6, 2, 25.0)
     assert geo["moveouts"].shape == (60, 6, 2) and geo["moveouts"].min(axis=(1, 2)).max() == 0
     assert np.allclose(geo["weights_sources"].sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_bp_time_dependent_threshold():
+    """Same windows / medians / MADs as the reference; the final linear interpolation differs from
+    scipy's interp1d only in operation order (<= 2e-15 relative), hence the tiny tolerance."""
+    g = load("bp_threshold.npz")
+    thr = pp.bp_time_dependent_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]),
+                                         float(g["overlap"]))
+    assert thr.shape == g["thr"].shape
+    assert np.abs(thr - g["thr"]).max() <= 1e-12 * np.abs(g["thr"]).max()
+    # and the detections it leads to are identical
+    a = pp.find_beam_detections(g["maxbeam"], np.arange(g["maxbeam"].size), thr, 200)[0]
+    b = pp.find_beam_detections(g["maxbeam"], np.arange(g["maxbeam"].size), g["thr"], 200)[0]
+    assert np.array_equal(a, b) and a.size > 0
+
+
+def test_candidate_merge_equals_reference_selection_on_the_full_series():
+    """workflow.merge_candidates on the sparse candidate list == the reference's select_cc_indexes
+    loop on the whole series (golden), for every golden case without edge removal/validation."""
+    from seismic_bpmf_amd.workflow import merge_candidates, search_window
+    g = load("select_cc_indexes_py.npz")
+    for j in (0, 3):
+        x, thr, win = g[f"x_{j}"], g[f"thr_{j}"], int(g[f"win_{j}"])
+        cand = np.flatnonzero(x > thr)
+        got = merge_candidates(cand, x[cand], win)
+        want = pp.select_cc_indexes(x, thr, win, step=1, sr=25.0, data_duration_sec=1e9,
+                                    n_dev_threshold=8.0, min_freq_hz=2.0, data_buffer_sec=0.0,
+                                    remove_edges=False, anomalous_cdf_at_mean_plus_1sig=0.0)
+        assert np.array_equal(got, want)
+    mv = np.array([[0, 40, 40], [10, 90, 90], [5, 25, 25]])
+    assert search_window(mv, 100, 1) == 100 and search_window(mv, 10, 2) == 20.5
