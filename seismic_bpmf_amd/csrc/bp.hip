@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
 // broadcast (the limiter of the time-split kernel: 13 x 1 KiB per source per wave) by four,
 // and one address add serves TPW gathers.  Every wave keeps its own running (max, arg-max)
 // for the tile; they are merged through LDS at the end with the same (value, lowest id) order.
-template <int TPW, int NTV, int OOB, int REDUCE, int PAIR>
+template <int TPW, int NTV, int OOB, int REDUCE>
 __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
@@ -421,10 +421,9 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const long long t0 = (long long)blockIdx.x * TILE;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    // sample j of this lane inside the tile: lane + 64 j, or (PAIR) adjacent samples
-    // 2 lane + {0,1} + 128 (j/2) fetched as one 8-byte LDS read
-    auto tmap = [&](int j) { return PAIR ? 2 * lane + 128 * (j >> 1) + (j & 1) : lane + 64 * j; };
-    const char* lds_l = (const char*)lds + lane * (PAIR ? 8 : 4);
+    // sample j of this lane inside the tile
+    auto tmap = [&](int j) { return lane + 64 * j; };
+    const char* lds_l = (const char*)lds + lane * 4;
 
     float best[TPW];
     int arg[TPW];
@@ -480,19 +479,8 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
                     const float* lp0 = (const float*)(lds_l + tt.x);
                     const float* lp1 = (const float*)(lds_l + tt.z);
                     float x0[TPW], x1[TPW];
-                    if (PAIR) {
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                        for (int j = 0; j < TPW; j += 2) {
-                            const f32x2 v0 = *(const f32x2*)(lp0 + j * 64);  // +128 floats per pair
-                            const f32x2 v1 = *(const f32x2*)(lp1 + j * 64);
-                            x0[j] = v0[0]; x0[j + 1] = v0[1];
-                            x1[j] = v1[0]; x1[j + 1] = v1[1];
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
-                    }
+                    for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
                     const float b0 = __int_as_float(tt.y), b1 = __int_as_float(tt.w);
 #pragma unroll
                     for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(b0, x0[j], acc[j]);
@@ -540,6 +528,165 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
             int a = ma[x];
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
+                const float bw = mb[w * TILE + x];
+                const int aw = ma[w * TILE + x];
+                if (bw > b || (bw == b && aw < a)) { b = bw; a = aw; }
+            }
+            const long long t = t0 + x;
+            if (t < N) { out_beam[t] = b; out_arg[t] = a; }
+        }
+    }
+}
+
+// ------------------------------------- beam, one wave per source, packed metadata (P = 2) ---
+// The production kernel for two-phase (P, S) grids.  Same flow as bp_beam_wps_kernel, but a
+// source's metadata is packed per STATION as {off_P | off_S << 16, weight} (LDS float offsets
+// fit 16 bits; both phases share the station weight): half the registers and half the
+// vector-memory traffic of the per-term table, two prefetched sets instead of three.
+// WPB = waves per workgroup (all waves share the group's LDS windows and take different
+// sources).  Measured on cfg3: WPB 4 (8 waves/CU) 0.351 s, WPB 6 (12 waves/CU) 0.491 s,
+// WPB 8 (16 waves/CU, spills at 128 VGPRs) 0.598 s -> 4 is the default.
+template <int NSV>
+struct BpMetaP {
+    int4 hd;            // id, tmin, tmax, stations (padded to 2; 0 = unused source)
+    int4 st[NSV / 2];   // two stations per int4: {offs, weight, offs, weight}
+    __device__ __forceinline__ void load(const int4* __restrict__ srcs4,
+                                         const int4* __restrict__ recs, int k, int vzero)
+    {
+        const size_t kk = (size_t)(k + vzero);  // vzero: see BpMetaV
+        hd = srcs4[kk];
+#pragma unroll
+        for (int i = 0; i < NSV / 2; ++i) st[i] = recs[kk * (NSV / 2) + i];
+    }
+};
+
+template <int WPB, int NSV, int OOB, int REDUCE>
+__global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kernel(
+    const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
+    const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
+    const int4* __restrict__ recs, int id_offset, float* __restrict__ out_beam,
+    int* __restrict__ out_arg)
+{
+    extern __shared__ float lds[];
+    constexpr int TPW = 8;
+    constexpr int TILE = 64 * TPW;
+    constexpr int NTHREADS = 64 * WPB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int sub = tid >> 8;        // staging sub-group of 256 threads
+    const int stid = tid & 255;
+    const long long t0 = (long long)blockIdx.x * TILE;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    const char* lds_l = (const char*)lds + lane * 4;
+
+    float best[TPW];
+    int arg[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
+    for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
+
+    for (int g = 0; g < n_groups; ++g) {
+        const BpGroup grp = groups[g];
+        const int k_last = grp.first_src + grp.n_src - 1;
+        const int k_first = grp.first_src + wv;
+        BpMetaP<NSV> m0, m1;
+        m0.load(srcs4, recs, min(k_first, k_last), vzero);
+        __syncthreads();  // previous group's gathers are done
+        for (int cb = 0; cb < grp.n_chunk; cb += 64) {
+            const int nb = min(64, grp.n_chunk - cb);
+            int4 d = make_int4(0, 0, 0, 0);
+            if (lane < nb) d = chunks[grp.first_chunk + cb + lane];
+            // 256-thread sub-groups take alternate blocks of 4 chunks; a trailing partial
+            // sub-group (WPB = 6) only computes
+            constexpr int NSUB = NTHREADS / 256;
+            for (int c = 4 * sub; c < nb && sub < NSUB; c += 4 * NSUB) {
+                int row[4], dd[4], n[4];
+                long long gi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = min(c + u, nb - 1);
+                    row[u] = lane_bcast(d.x, cc);
+                    gi[u] = t0 + lane_bcast(d.y, cc) + stid;
+                    dd[u] = lane_bcast(d.z, cc);
+                    n[u] = c + u < nb ? lane_bcast(d.w, cc) : 0;
+                }
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long gc = gi[u] < 0 ? 0 : (gi[u] >= N ? N - 1 : gi[u]);
+                    v[u] = U[(size_t)row[u] * (size_t)N + gc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (stid < n[u]) lds[dd[u] + stid] = (gi[u] >= 0 && gi[u] < N) ? v[u] : 0.0f;
+            }
+        }
+        __syncthreads();
+
+        auto process = [&](const BpMetaP<NSV>& m, bool live) {
+            const int nsta = live ? __builtin_amdgcn_readfirstlane(m.hd.w) : 0;
+            float acc[TPW];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NSV / 2; ++c) {
+                if (c * 2 < nsta) {  // wave-uniform
+                    const int4 tt = m.st[c];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned offs = (unsigned)(h ? tt.z : tt.x);
+                        const float beta = __int_as_float(h ? tt.w : tt.y);
+                        const float* lp0 = (const float*)(lds_l + ((offs & 0xffffu) << 2));
+                        const float* lp1 = (const float*)(lds_l + ((offs >> 16) << 2));
+                        float x0[TPW], x1[TPW];
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(beta, x0[j], acc[j]);
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(beta, x1[j], acc[j]);
+                    }
+                }
+            }
+            const int sid = m.hd.x;
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const long long t = t0 + lane + 64 * j;
+                bool computed = nsta > 0;
+                if (OOB == BPMF_BP_STRICT) computed = computed && (t + m.hd.y >= 0) && (t + m.hd.z < N);
+                if (REDUCE == BPMF_BP_REDUCE_MAX) {
+                    const bool better = acc[j] > best[j] || (acc[j] == best[j] && sid < arg[j]);
+                    if (computed && better) { best[j] = acc[j]; arg[j] = sid; }
+                } else {
+                    if (live && t < N)
+                        out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                }
+            }
+        };
+        for (int k = k_first; k <= k_last; k += 2 * WPB) {
+            m1.load(srcs4, recs, min(k + WPB, k_last), vzero);
+            process(m0, true);
+            m0.load(srcs4, recs, min(k + 2 * WPB, k_last), vzero);
+            process(m1, k + WPB <= k_last);
+        }
+    }
+    if (REDUCE == BPMF_BP_REDUCE_MAX) {
+        __syncthreads();
+        float* mb = lds;                        // [WPB][TILE]
+        int* ma = (int*)(lds + WPB * TILE);     // [WPB][TILE]
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            mb[wv * TILE + lane + 64 * j] = best[j];
+            ma[wv * TILE + lane + 64 * j] = arg[j];
+        }
+        __syncthreads();
+        for (int x = tid; x < TILE; x += NTHREADS) {
+            float b = mb[x];
+            int a = ma[x];
+#pragma unroll
+            for (int w = 1; w < WPB; ++w) {
                 const float bw = mb[w * TILE + x];
                 const int aw = ma[w * TILE + x];
                 if (bw > b || (bw == b && aw < a)) { b = bw; a = aw; }
@@ -604,7 +751,10 @@ struct bpmf_bp_plan {
     float* d_beta = nullptr;
     int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
     int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
-    int pair = 0;                // wps kernel: adjacent-sample pairs per lane (8-byte LDS reads)
+    int nsv = 0;                 // > 0: packed per-station records (P == 2), NSV stations padded
+    int wpb = 4;                 // waves per workgroup of the packed kernel (4, 6 or 8)
+    int4* d_recs = nullptr;      // [K, nsv/2]
+    int4* d_hdr2 = nullptr;      // [K] headers with the station count in .w
     BpTermV* d_termsv = nullptr; // [K, ntv]
 };
 
@@ -791,8 +941,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     const size_t soft_kb = (size_t)std::max(8, env_int("BPMF_BP_LDS_KB", 80));
     const int max_group = std::max(1, env_int("BPMF_BP_MAX_GROUP", 4096));
     const int tpt_first = env_int("BPMF_BP_TPT", 2);
-    int chunk = env_int("BPMF_BP_CHUNK", 4);
-    if (chunk != 4 && chunk != 8) chunk = 4;
+    const int chunk = 4;  // terms gathered side by side by the generic kernel (8 measured equal)
     const bool reorder = env_int("BPMF_BP_REORDER", 1) != 0;
     const size_t hard = BP_LDS_MAX / sizeof(float);
     const size_t soft = std::min(hard, soft_kb * 1024 / sizeof(float));
@@ -836,7 +985,6 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     const int ntv_opts[4] = {8, 16, 24, 32};
     const bool want_uv = env_int("BPMF_BP_UVGPR", 1) != 0;
     pl->wps = env_int("BPMF_BP_WPS", 1);
-    pl->pair = env_int("BPMF_BP_PAIR", 0);
     std::vector<BpTermV> tv;
     for (int o = 0; o < 4 && want_uv && !pl->ntv; ++o)
         if (ph.NT <= ntv_opts[o]) pl->ntv = ntv_opts[o];
@@ -846,6 +994,34 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             for (int j = 0; j < ph.NT; ++j)
                 tv[q * pl->ntv + j] = BpTermV{ph.off[q * ph.NT + j] * 4, ph.beta[q * ph.NT + j]};
         if ((rc = upload(tv, &pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
+    }
+    // packed per-station records for the two-phase fast kernel
+    if (P == 2 && pl->ntv && env_int("BPMF_BP_PACKED", 1)) {
+        const int nsta_max = ph.NT / 2;   // NT is a multiple of 4
+        const int opts[4] = {4, 8, 12, 16};
+        for (int o = 0; o < 4 && !pl->nsv; ++o)
+            if (nsta_max <= opts[o]) pl->nsv = opts[o];
+        pl->wpb = 4;  // measured on cfg3: 4 -> 0.351 s, 6 -> 0.491 s, 8 (spills) -> 0.598 s
+    }
+    if (pl->nsv) {
+        std::vector<int4> recs(K * (size_t)(pl->nsv / 2), make_int4(0, 0, 0, 0));
+        std::vector<int4> hdr(K);
+        for (size_t q = 0; q < K; ++q) {
+            int* r = (int*)&recs[q * (pl->nsv / 2)];
+            const int nterm = ph.srcs[q].nterm;  // padded to the chunk (4): pairs of terms = stations
+            int nsta = 0;
+            for (int j = 0; j + 1 < nterm; j += 2) {
+                const unsigned o0 = (unsigned)ph.off[q * ph.NT + j], o1 = (unsigned)ph.off[q * ph.NT + j + 1];
+                r[2 * nsta] = (int)(o0 | (o1 << 16));
+                r[2 * nsta + 1] = __builtin_bit_cast(int, ph.beta[q * ph.NT + j]);
+                ++nsta;
+            }
+            hdr[q] = make_int4(ph.srcs[q].id, ph.srcs[q].tmin, ph.srcs[q].tmax, (nsta + 1) / 2 * 2);
+        }
+        if ((rc = upload(recs, &pl->d_recs)) || (rc = upload(hdr, &pl->d_hdr2))) {
+            bpmf_bp_plan_destroy(pl);
+            return rc;
+        }
     }
     if ((rc = upload(ph.groups, &pl->d_groups)) || (rc = upload(ph.chunks, &pl->d_chunks)) ||
         (rc = upload(ph.srcs, &pl->d_srcs)) || (rc = upload(ph.off, &pl->d_off)) ||
@@ -866,6 +1042,8 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     (void)hipFree(pl->d_off);
     (void)hipFree(pl->d_beta);
     (void)hipFree(pl->d_termsv);
+    (void)hipFree(pl->d_recs);
+    (void)hipFree(pl->d_hdr2);
     delete pl;
 }
 
@@ -953,11 +1131,11 @@ int dispatch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, 
     return launch_beam_uv<TPT, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
-template <int TPW, int NTV, int OOB, int REDUCE, int PAIR>
+template <int TPW, int NTV, int OOB, int REDUCE>
 int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                     float* beam, int32_t* arg)
 {
-    auto kern = bp_beam_wps_kernel<TPW, NTV, OOB, REDUCE, PAIR>;
+    auto kern = bp_beam_wps_kernel<TPW, NTV, OOB, REDUCE>;
     // the end-of-kernel merge needs 2 * 4 * tile floats of LDS
     const size_t lds = std::max(pl->lds_bytes, (size_t)8 * 64 * TPW * sizeof(float));
     if (lds > 64 * 1024)
@@ -975,31 +1153,72 @@ int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_
     return 0;
 }
 
-template <int TPW, int NTV, int PAIR>
-int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
-                       hipStream_t stream, float* beam, int32_t* arg)
-{
-    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX, PAIR>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX, PAIR>(pl, U, N, stream, beam, arg);
-    if (oob == BPMF_BP_STRICT)
-        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE, PAIR>(pl, U, N, stream, beam, arg);
-    return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE, PAIR>(pl, U, N, stream, beam, arg);
-}
-
 template <int TPW, int NTV>
 int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                       hipStream_t stream, float* beam, int32_t* arg)
 {
-    if (pl->pair) return dispatch_beam_wps2<TPW, NTV, 1>(pl, U, N, oob, reduce, stream, beam, arg);
-    return dispatch_beam_wps2<TPW, NTV, 0>(pl, U, N, oob, reduce, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam_wps<TPW, NTV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+}
+
+template <int WPB, int NSV, int OOB, int REDUCE>
+int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
+                     float* beam, int32_t* arg)
+{
+    auto kern = bp_beam_wps2_kernel<WPB, NSV, OOB, REDUCE>;
+    const size_t lds = std::max(pl->lds_bytes, (size_t)2 * WPB * 512 * sizeof(float));
+    if (lds > 64 * 1024)
+        BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)BP_LDS_MAX));
+    dim3 grid((unsigned)((N + 511) / 512));
+    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
+                                                (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,
+                                                pl->id_offset, beam, arg);
+    BPMF_LAUNCH_CHECK();
+    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    return 0;
+}
+
+template <int WPB, int NSV>
+int dispatch_beam_wps2b(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                        hipStream_t stream, float* beam, int32_t* arg)
+{
+    if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+    if (oob == BPMF_BP_STRICT)
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+}
+
+template <int NSV>
+int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                       hipStream_t stream, float* beam, int32_t* arg)
+{
+    return dispatch_beam_wps2b<4, NSV>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
 template <int TPT>
 int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                   hipStream_t stream, float* beam, int32_t* arg)
 {
+    if (pl->wps && pl->nsv && TPT == 2) {  // packed two-phase kernel, 16 waves/CU
+        switch (pl->nsv) {
+            case 4: return dispatch_beam_wps2<4>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 8: return dispatch_beam_wps2<8>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 12: return dispatch_beam_wps2<12>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 16: return dispatch_beam_wps2<16>(pl, U, N, oob, reduce, stream, beam, arg);
+            default: break;
+        }
+    }
     if (pl->wps && pl->ntv && TPT == 2) {  // wave-per-source layout: tile 512 = 64 lanes x 8
         switch (pl->ntv) {
             case 8: return dispatch_beam_wps<8, 8>(pl, U, N, oob, reduce, stream, beam, arg);
@@ -1016,7 +1235,6 @@ int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int
         case 32: return dispatch_beam_uv<TPT, 32>(pl, U, N, oob, reduce, stream, beam, arg);
         default: break;
     }
-    if (pl->chunk == 8) return dispatch_beam2<TPT, 8>(pl, U, N, oob, reduce, stream, beam, arg);
     return dispatch_beam2<TPT, 4>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 

@@ -90,7 +90,7 @@ def test_bp_term_count_variants(oracle_lib, S, P, density, label):
     _bp_check(oracle_lib, f, tau, wp, ws, label)
 
 
-@pytest.mark.parametrize("env", [{"BPMF_BP_WPS": "0"}, {"BPMF_BP_UVGPR": "0"}, {"BPMF_BP_UVGPR": "0", "BPMF_BP_CHUNK": "8"},
+@pytest.mark.parametrize("env", [{"BPMF_BP_WPS": "0"}, {"BPMF_BP_UVGPR": "0"}, {"BPMF_BP_PACKED": "0"},
                                  {"BPMF_BP_TPT": "1", "BPMF_BP_WPS": "0"}, {"BPMF_BP_TPT": "4", "BPMF_BP_WPS": "0"},
                                  {"BPMF_BP_REORDER": "0"}, {"BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "5"}])
 def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
