@@ -76,9 +76,24 @@ __global__ void mf_csum_local_kernel(const float* __restrict__ data, size_t n_ch
     const float* d = data + ch * N;
     double* lo = local + ch * N;
     double acc = 0.0;
-    for (size_t n = n0; n < n1; ++n) {
+    // 16-byte loads / 32-byte stores (dword-aligned vector types: ch * N need not be a
+    // multiple of 4); the additions stay strictly sequential
+    typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+    typedef double f64x2a __attribute__((ext_vector_type(2), aligned(8)));
+    size_t n = n0;
+    for (; n + 4 <= n1; n += 4) {
+        const f32x4a v = *(const f32x4a*)(d + n);
+        f64x2a o0, o1;
+        double x = (double)v[0]; acc = acc + x * x; o0[0] = acc;  // squares are exact in double
+        x = (double)v[1]; acc = acc + x * x; o0[1] = acc;
+        x = (double)v[2]; acc = acc + x * x; o1[0] = acc;
+        x = (double)v[3]; acc = acc + x * x; o1[1] = acc;
+        *(f64x2a*)(lo + n) = o0;
+        *(f64x2a*)(lo + n + 2) = o1;
+    }
+    for (; n < n1; ++n) {
         double v = (double)d[n];
-        acc = acc + v * v;  // v*v is exact in double
+        acc = acc + v * v;
         lo[n] = acc;
     }
     tot[idx] = acc;
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int* __restrict__ mv, const float* __restrict__ wgt,
     const float* __restrict__ data, const float* __restrict__ e_t,
     const float* __restrict__ e_d, const int2* __restrict__ range, int L, long long N, int T,
-    int n_ch, long long n_corr, float* __restrict__ out, int ablate)
+    int n_ch, long long n_corr, float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -176,8 +191,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const int a = lane & 15;   // tile column (and band row for the A operand)
     const int kq = lane >> 4;  // k index of the operands / row group of the results
 
-    const int t = blockIdx.x % T;
-    const long long lag0 = (long long)(blockIdx.x / T) * MF_LAGS_PER_WG;
+    // Workgroup order: templates in batches of t_batch; inside a batch the template index is
+    // fastest, then the lag block: the workgroups in flight share a few lag blocks' data
+    // windows (L2) while touching at most t_batch rows of the output at a time.
+    const long long per_batch = (long long)t_batch * n_lag_blocks;
+    const int batch = (int)(blockIdx.x / per_batch);
+    const int rem = (int)(blockIdx.x - batch * per_batch);
+    const int tb = min(t_batch, T - batch * t_batch);
+    const int t = batch * t_batch + rem % tb;
+    const long long lag0 = (long long)(rem / tb) * MF_LAGS_PER_WG;
     const int2 rg = range[t];
     const long long nwin = N - L + 1;
 
@@ -516,10 +538,14 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         dim3 grid((unsigned)(T * n_lag_blocks));
         const char* abl = getenv("BPMF_MF_ABLATE");  // kernel-phase ablation, profiling only
         const int ablate = abl ? atoi(abl) : 0;
+        const char* tbe = getenv("BPMF_MF_TBATCH");
+        int t_batch = tbe ? atoi(tbe) : (int)T;
+        if (t_batch < 1 || t_batch > (int)T) t_batch = (int)T;
 #define BPMF_MF_LAUNCH(NS, R, TT)                                                            \
     mf_mfma_kernel<NS, R, TT><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
         d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (int)L,        \
-        (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out, ablate)
+        (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out, ablate, t_batch,        \
+        (int)n_lag_blocks)
         if (need_r <= 17 && need_t <= 2) {          // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
