@@ -169,6 +169,23 @@ int bpmf_extract_candidates_dev(const float *d_series, const float *d_thr_window
                                 bpmf_stream_t stream, uint32_t *d_count,
                                 bpmf_candidate *d_records);
 
+/* ------------------------------------------------------------ grid decimation --- */
+/*
+ * Device version of BPMF.clib.find_similar_sources (BPMF/clib.py:104-221), i.e. of
+ * BPMF/libc.c:find_similar_moveouts (:55-223, method 0 = "smallest") and
+ * find_similar_moveouts2 (:225-387, method 1 = "closest"): the one-time O(K^2 S) decimation
+ * of the source grid that precedes the backprojection.  Host arrays, same argument order as the
+ * reference's C functions (num_threads replaced by the method / device); the result equals the
+ * reference run single-threaded.
+ *   moveouts (K, S) f32 seconds; redundant_sources (K) i32 out (1 = redundant)
+ */
+int bpmf_find_similar_sources(const float *moveouts, const float *source_longitude,
+                              const float *source_latitude, const float *cell_longitude,
+                              const float *cell_latitude, float threshold, size_t n_sources,
+                              size_t n_stations, size_t n_cells_longitude,
+                              size_t n_cells_latitude, size_t n_stations_for_diff, int method,
+                              int device, int32_t *redundant_sources);
+
 #ifdef __cplusplus
 }
 #endif

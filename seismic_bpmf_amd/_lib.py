@@ -41,6 +41,8 @@ SIGNATURES = {
     "bpmf_tdt_num_windows": (_sz, [_sz, _sz, _sz]),
     "bpmf_tdt_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
     "bpmf_tdt_rms_dev": (C.c_int, [_vp, _vp, C.c_float, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "bpmf_find_similar_sources": (C.c_int, [_f, _f, _f, _f, _f, C.c_float, _sz, _sz, _sz, _sz, _sz,
+                                            C.c_int, C.c_int, _i]),
     "bpmf_extract_candidates_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp,
                                               _vp, _vp]),
 }

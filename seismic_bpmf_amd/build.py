@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libbpmf_hip.so")
-SOURCES = ["mf.hip", "bp.hip", "post.hip", "util.hip"]
+SOURCES = ["mf.hip", "bp.hip", "post.hip", "decimate.hip", "util.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fmaf; the compiler must not fuse more.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

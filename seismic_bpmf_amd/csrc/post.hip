@@ -16,6 +16,9 @@ namespace bpmf {
 
 constexpr int GAUSSIAN_LEN = 500;
 
+// dword-aligned 16-byte load: rows and windows start at arbitrary sample offsets
+typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+
 // (1) per (row, global window): sum and count of the non-zero samples.       libc.c:553-571
 __global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, size_t n,
                                     size_t window, size_t n_glob, float* __restrict__ part,
@@ -27,7 +30,14 @@ __global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, 
     const float* p = x + row * n + q * window;
     float acc = 0.0f;
     unsigned long long c = 0;
-    for (size_t j = 0; j < window; ++j) {
+    size_t j = 0;
+    for (; j + 4 <= window; j += 4) {  // 16-byte loads, strictly sequential adds
+        const f32x4a v4 = *(const f32x4a*)(p + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v4[e] != 0.0f) { acc += v4[e]; ++c; }
+    }
+    for (; j < window; ++j) {
         float v = p[j];
         if (v != 0.0f) { acc += v; ++c; }
     }
@@ -62,7 +72,17 @@ __global__ void tdt_glob_dev_kernel(const float* __restrict__ x, const float* __
     const float* p = x + row * n + q * window;
     const float c = centre[row];
     float acc = 0.0f;
-    for (size_t j = 0; j < window; ++j) {
+    size_t j = 0;
+    for (; j + 4 <= window; j += 4) {
+        const f32x4a v4 = *(const f32x4a*)(p + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v4[e] != 0.0f) {
+                double d = (double)(v4[e] - c);
+                acc = (float)((double)acc + d * d);
+            }
+    }
+    for (; j < window; ++j) {
         float v = p[j];
         if (v != 0.0f) {
             double d = (double)(v - c);
@@ -99,14 +119,34 @@ __global__ void tdt_window_kernel(const float* __restrict__ x, const float* __re
     const float* p = x + row * n + i0;
     const float c = centre[row], dv = dev[row];
     float acc = 0.0f;
-    for (size_t j = 0; j < window; ++j) {
+    size_t j = 0;
+    for (; j + 4 <= window; j += 4) {
+        const f32x4a v4 = *(const f32x4a*)(p + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = v4[e];
+            if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j + e) % GAUSSIAN_LEN], dv, c);
+            acc += v;
+        }
+    }
+    for (; j < window; ++j) {
         float v = p[j];
         if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
         acc += v;
     }
     const float mean = acc / (float)window;
     float ss = 0.0f;
-    for (size_t j = 0; j < window; ++j) {
+    for (j = 0; j + 4 <= window; j += 4) {
+        const f32x4a v4 = *(const f32x4a*)(p + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = v4[e];
+            if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j + e) % GAUSSIAN_LEN], dv, c);
+            double d = (double)(v - mean);
+            ss = (float)((double)ss + d * d);
+        }
+    }
+    for (; j < window; ++j) {
         float v = p[j];
         if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
         double d = (double)(v - mean);
