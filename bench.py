@@ -210,9 +210,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BPMF_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (exercises the N > 1 code path on
+    # a single-GPU box)
+    if world > 1 or os.environ.get("BPMF_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import seismic_bpmf_amd as sb
@@ -263,8 +266,8 @@ def main():
     achieved = flop_per_launch / (k_ms * 1e-3) / 1e12
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "mf_main_pmc.json")
-    if os.path.exists(pmc_file):
-        try:
+    if os.path.exists(pmc_file) and args.mf_config == "cfg2" and not args.templates:
+        try:  # PMC passes are separate rocprofv3 runs of this same launch (profiles/)
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -320,6 +323,7 @@ def main():
     if rank == 0 and world == 1 and not args.skip_cpu:
         cpu = cpu_baseline(cfg, args.cpu_seconds)
 
+    line = None
     if rank == 0:
         line = {
             "metric": "million network-CC-samples/s (matched filter)",
@@ -334,15 +338,24 @@ def main():
                        "row0_peak_cc": round(peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj, "detection": detect,
         }
+    if dist is not None:
+        dist.destroy_process_group()
+    if line is not None:
         def _clean(o):  # NaN is not JSON
             if isinstance(o, float) and not math.isfinite(o):
                 return None
             if isinstance(o, dict):
                 return {k: _clean(v) for k, v in o.items()}
             return o
-        print(json.dumps(_clean(line)))
-    if dist is not None:
-        dist.destroy_process_group()
+        # the JSON line is the LAST thing on stdout: flush C stdio first (RCCL prints a version
+        # banner through it)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(_clean(line)), flush=True)
 
 
 if __name__ == "__main__":
