@@ -34,21 +34,32 @@ __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t
 }
 
 // Valid lag range [first, last] of each template (first > last = empty).
-__global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restrict__ w, int T,
-                                int n_ch, long long step, long long L, long long N,
-                                long long n_corr, int2* __restrict__ range)
+// Also writes the template's compact list of used channels, one int4 {channel, moveout,
+// weight bits, r_t bits} per channel with w != 0, in channel order, closed by two {-1,..}
+// sentinels: the main kernel walks it with one (prefetched) scalar load per channel instead of
+// chasing weights / moveouts / norms through dependent loads.
+__global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restrict__ w,
+                                const float* __restrict__ r_t, int T, int n_ch, long long step,
+                                long long L, long long N, long long n_corr,
+                                int2* __restrict__ range, int4* __restrict__ chan_rec)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     long long mv_min = 0, mv_max = 0;
     bool any = false;
+    int4* rec = chan_rec + (size_t)t * (n_ch + 2);
+    int n_used = 0;
     for (int ch = 0; ch < n_ch; ++ch) {
-        if (w[(size_t)t * n_ch + ch] == 0.0f) continue;
+        const float wc = w[(size_t)t * n_ch + ch];
+        if (wc == 0.0f) continue;
         long long m = mv[(size_t)t * n_ch + ch];
+        rec[n_used++] = make_int4(ch, (int)m, __float_as_int(wc), __float_as_int(r_t[(size_t)t * n_ch + ch]));
         if (!any || m < mv_min) mv_min = m;
         if (!any || m > mv_max) mv_max = m;
         any = true;
     }
+    rec[n_used] = make_int4(-1, 0, 0, 0);
+    rec[n_used + 1] = make_int4(-1, 0, 0, 0);
     int2 r = make_int2(1, 0);
     if (any && N >= L) {
         long long first = mv_min < 0 ? (-mv_min + step - 1) / step : 0;
@@ -174,10 +185,10 @@ __host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L
 // (window <= 256 * MAXR floats, band <= 256 * MAXT floats).
 template <bool NETWORK_SUM, int MAXR, int MAXT>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
-    const float* __restrict__ tmpl, const int* __restrict__ mv, const float* __restrict__ wgt,
-    const float* __restrict__ data, const float* __restrict__ e_t,
-    const float* __restrict__ e_d, const int2* __restrict__ range, int L, long long N, int T,
-    int n_ch, long long n_corr, float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
+    const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
+    const float* __restrict__ data, const float* __restrict__ e_d,
+    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr,
+    float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -214,18 +225,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     if (wg_valid) {
         const int a_base = 15 - a + kq;
         const int b_base = 1088 * wv + 17 * a + kq;
-        const float* wrow = wgt + (size_t)t * n_ch;
-        const int* mrow = mv + (size_t)t * n_ch;
+        const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
 
         float rd[MAXR], rt[MAXT];
         // Staging loads go through buffer descriptors: an offset outside [0, bytes) -- a
         // window sample before the start / past the end of the trace, or a band row outside
         // the template -- returns 0 from the hardware bounds check, so the zero padding costs
         // no address clamping or select.
-        auto issue_stage = [&](int ch) {
+        auto issue_stage = [&](int ch, int mvc) {
             const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
-            const int o_d = (int)((lag0 + mrow[ch] + tid) * 4);  // wraps like the hardware's u32 offset
+            const int o_d = (int)((lag0 + mvc + tid) * 4);  // wraps like the hardware's u32 offset
 #pragma unroll
             for (int r = 0; r < MAXR; ++r)
                 rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -249,24 +259,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                 if (x < tp_len) tp[x] = rt[r];
             }
         };
-        auto next_active = [&](int ch) {
-            while (ch < n_ch && wrow[ch] == 0.0f) ++ch;
-            return ch;
-        };
-
-        int ch = next_active(0);
-        if (ch < n_ch) issue_stage(ch);
+        // records of the current / next channel are in SGPRs; the one after is fetched during
+        // the K loop, so no scalar-memory latency sits on the per-channel critical path
+        int4 rec = recs[0];
+        int4 rec1 = recs[1];
+        int ri = 0;
+        if (rec.x >= 0) issue_stage(rec.x, rec.y);
         int buf = 0;
-        while (ch < n_ch) {
+        while (rec.x >= 0) {
+            const int ch = rec.x;
             float* tp = smem + buf * buf_floats;  // tp[15 + l] = tmpl[l], zeros around
             float* dw = tp + tp_len;              // dw[pad(x)] = data[g0 + x]
             write_stage(tp, dw);
             // One barrier per channel: the other buffer is only rewritten after every wave
             // has passed this point, i.e. after it finished reading it.
             __syncthreads();
-            const float w = wrow[ch];
-            const int mvc = mrow[ch];
-            const float et = e_t[(size_t)t * n_ch + ch];
+            const float w = __int_as_float(rec.z);
+            const int mvc = rec.y;
+            const float et = __int_as_float(rec.w);
+            const int4 rec2 = recs[ri + 2];
             // window energies of this lane's 4 x 4 lags: in flight during the MFMA loop
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
             f32x4 ed[4];
@@ -286,8 +297,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                     }
                 }
             }
-            const int ch_next = next_active(ch + 1);
-            if (ch_next < n_ch && !(ablate & 2)) issue_stage(ch_next);
+            if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
 
             f32x4 acc[4];
 #pragma unroll
@@ -295,33 +305,54 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             // K loop: 16 band rows = 4 k-steps per trip; the operands of k-step j+2 are
             // requested before the MFMAs of k-step j issue (4 rotating register slots).
             const int nq = (ablate & 4) ? 0 : Kpad >> 4;
-            const float* ap = tp + a_base;
-            const float* bp = dw + b_base;
+            // K loop: 16 band rows = 4 k-steps per trip.  The 5 operands of k-step j+2 are
+            // requested from LDS before the 4 MFMAs of k-step j issue, in 4 rotating register
+            // slots.  The reads are inline asm with COUNTED waits: hipcc's own waitcnt insertion
+            // falls back to lgkmcnt(0) at the loop back-edge, which drains the operand pipeline
+            // once per trip (a ~100-cycle bubble every 512 cycles of matrix work).  In steady
+            // state 15 reads are in flight when k-step j needs its operands, the 10 newest belong
+            // to k-steps j+1 and j+2, and LDS returns in order: s_waitcnt lgkmcnt(10).
+            // sched_barrier keeps the compiler from moving MFMAs across the asm waits.
+            const unsigned a_addr = (unsigned)(size_t)(tp + a_base) ;      // LDS byte addresses
+            const unsigned b_addr = (unsigned)(size_t)(dw + b_base);
+            unsigned ap = a_addr, bp = b_addr;
             float sa[4], sb[4][4];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                sa[j] = ap[4 * j];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sb[j][u] = bp[4 * j + 272 * u];
-            }
+#define MF_LDS_READ(dst, addr, off) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MF_REQ(slot, aoff, boff)                                    \
+    MF_LDS_READ(sa[slot], ap, (aoff));                               \
+    MF_LDS_READ(sb[slot][0], bp, (boff));                            \
+    MF_LDS_READ(sb[slot][1], bp, (boff) + 1088);                     \
+    MF_LDS_READ(sb[slot][2], bp, (boff) + 2176);                     \
+    MF_LDS_READ(sb[slot][3], bp, (boff) + 3264)
+#define MF_STEP(slot)                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                  \
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0)
+            // (a scalar load may still be in flight here -- the next-but-one channel record; it
+            // only makes the counted waits stricter, never laxer: LDS returns in order)
+            __builtin_amdgcn_sched_barrier(0);
+            MF_REQ(0, 0, 0);
+            MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jn = j + 2;  // k-step to request now
-                    const float* apn = jn < 4 ? ap : ap + 16;
-                    const float* bpn = jn < 4 ? bp : bp + 17;  // past the last trip: slack, unused
-                    sa[jn & 3] = apn[4 * (jn & 3)];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) sb[jn & 3][u] = bpn[4 * (jn & 3) + 272 * u];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[j], sb[j][u], acc[u], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ap += 16;
-                bp += 17;
+                MF_REQ(2, 32, 32);
+                MF_STEP(0);
+                MF_REQ(3, 48, 48);
+                MF_STEP(1);
+                MF_REQ(0, 64, 68);   // k-step 0 of the next trip (past the last trip: slack, unused)
+                MF_STEP(2);
+                MF_REQ(1, 80, 84);
+                MF_STEP(3);
+                ap += 64;
+                bp += 68;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // drain the two k-steps read ahead
+            __builtin_amdgcn_sched_barrier(0);
+#undef MF_LDS_READ
+#undef MF_REQ
+#undef MF_STEP
 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -339,7 +370,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                     if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                 }
             }
-            ch = ch_next;
+            rec = rec1;
+            rec1 = rec2;
+            ++ri;
             buf ^= 1;
         }
     }
@@ -405,6 +438,7 @@ struct MfWorkspace {
     float* e_d;     // [n_ch, nwin]
     float* e_t;     // [T, n_ch]
     int2* range;    // [T]
+    int4* chan_rec; // [T, n_ch + 2] compact used-channel records
     size_t bytes;
 };
 
@@ -421,6 +455,7 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.e_d = (float*)(p + o);    o += align_up(n_ch * nwin * sizeof(float), 256);
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
+    ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
     ws.bytes = o;
     return ws;
 }
@@ -519,15 +554,16 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             d_templates, n, (int)L, ws.e_t);
         BPMF_LAUNCH_CHECK();
         mf_range_kernel<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, stream>>>(
-            d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
-            (long long)n_corr, ws.range);
+            d_moveouts, d_weights, ws.e_t, (int)T, (int)n_ch, (long long)step, (long long)L,
+            (long long)N, (long long)n_corr, ws.range, ws.chan_rec);
         BPMF_LAUNCH_CHECK();
     }
     if (!network_sum)
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
 
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
-    const size_t lds = mf_lds_bytes((int)L);
+    size_t lds = mf_lds_bytes((int)L);
+    if (const char* ex = getenv("BPMF_MF_LDS_EXTRA_KB")) lds += (size_t)atoi(ex) * 1024;  // occupancy experiments
     const size_t n_lag_blocks = (n_corr + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
     // staging registers needed per thread (window / band), rounded to a compiled variant
     const int need_r = (mf_window_len((int)L) + MF_THREADS - 1) / MF_THREADS;
@@ -543,9 +579,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         if (t_batch < 1 || t_batch > (int)T) t_batch = (int)T;
 #define BPMF_MF_LAUNCH(NS, R, TT)                                                            \
     mf_mfma_kernel<NS, R, TT><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
-        d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (int)L,        \
-        (long long)N, (int)T, (int)n_ch, (long long)n_corr, d_cc_out, ablate, t_batch,        \
-        (int)n_lag_blocks)
+        d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,      \
+        (int)n_ch, (long long)n_corr, d_cc_out, ablate, t_batch, (int)n_lag_blocks)
         if (need_r <= 17 && need_t <= 2) {          // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
