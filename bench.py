@@ -271,7 +271,7 @@ def main():
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "mf_mfma_kernel", "bound": "mfma", "achieved": round(achieved, 2),
+    roofline = {"kernel": "mf_mfma_wave_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
                 "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",

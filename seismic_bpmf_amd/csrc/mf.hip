@@ -392,6 +392,193 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     }
 }
 
+// ------------------------------------------------- MFMA kernel, independent waves ---
+// Same tile algebra and arithmetic as mf_mfma_kernel, different ownership of LDS: every wave
+// stages ITS OWN data window (1008 + Kpad floats) and its own copy of the band, so no wave ever
+// waits for another one -- there is no barrier in the channel loop -- and, because only the
+// owning wave reads a buffer, it can be refilled in place after the K loop (LDS ops of one wave
+// execute in order): single-buffered, 6.6 KB per wave instead of 9.9 KB.  The price is the
+// 256-float overlap between neighbouring waves' windows (25 % more staging traffic from L2).
+// Used for L <= 257 (window 1280 floats = 20 staging registers per lane).
+template <bool NETWORK_SUM, int MAXR, int MAXT>
+__global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
+    const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
+    const float* __restrict__ data, const float* __restrict__ e_d,
+    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr,
+    float* __restrict__ out, int ablate, int n_lag_blocks)
+{
+    extern __shared__ float smem[];
+    const int Kpad = mf_kpad(L);
+    const int tp_len = mf_band_len(L);
+    const int Ww = MF_LAGS_PER_WAVE - 16 + Kpad;          // this wave's window
+    const int wave_floats = tp_len + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int a = lane & 15;
+    const int kq = lane >> 4;
+
+    const int t = blockIdx.x % T;
+    const long long lag0 = (long long)(blockIdx.x / T) * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
+    const int2 rg = range[t];
+    const long long nwin = N - L + 1;
+    (void)n_lag_blocks;
+
+    f32x4 sum[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    const bool wave_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WAVE - 1 < rg.x);
+    const long long lag_w = lag0 + 16 * a + 4 * kq;
+
+    if (wave_valid) {
+        float* tp = smem + wv * wave_floats;  // tp[15 + l] = tmpl[l], zeros around
+        float* dw = tp + tp_len;              // dw[pad(x)] = data[g0 + x]
+        const int a_base = 15 - a + kq;
+        const int b_base = 18 * a + kq;  // window padded 2 floats per 16: conflict-free B reads
+        const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
+
+        float rd[MAXR], rt[MAXT];
+        auto issue_stage = [&](int ch, int mvc) {
+            const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
+            const int o_d = (int)((lag0 + mvc + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r)
+                rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_d, o_d + 64 * 4 * r, 0, 0));
+            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < MAXT; ++r)
+                rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_t, (lane + 64 * r - 15) * 4, 0, 0));
+        };
+        auto write_stage = [&]() {
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                const int x = lane + 64 * r;
+                if (x < Ww) dw[x + 2 * (x >> 4)] = rd[r];
+            }
+#pragma unroll
+            for (int r = 0; r < MAXT; ++r) {
+                const int x = lane + 64 * r;
+                if (x < tp_len) tp[x] = rt[r];
+            }
+        };
+
+        int4 rec = recs[0];
+        int4 rec1 = recs[1];
+        int ri = 0;
+        if (rec.x >= 0) issue_stage(rec.x, rec.y);
+        while (rec.x >= 0) {
+            const int ch = rec.x;
+            write_stage();  // in place: this wave finished reading the previous channel
+            const float w = __int_as_float(rec.z);
+            const int mvc = rec.y;
+            const float et = __int_as_float(rec.w);
+            const int4 rec2 = recs[ri + 2];
+            const float* edc = e_d + (size_t)ch * (size_t)nwin;
+            f32x4 ed[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long lag = lag_w + 256 * u;
+                if (ablate & 8) {
+                    ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+                } else if (lag >= rg.x && lag + 3 <= rg.y) {
+                    ed[u] = *(const f32x4u*)(edc + lag + mvc);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = lag + r >= rg.x && lag + r <= rg.y;
+                        ed[u][r] = ok ? edc[lag + r + mvc] : 0.0f;
+                    }
+                }
+            }
+            if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
+
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const int nq = (ablate & 4) ? 0 : Kpad >> 4;
+            unsigned ap = (unsigned)(size_t)(tp + a_base), bp = (unsigned)(size_t)(dw + b_base);
+            float sa[4], sb[4][4];
+            // counted waits as in mf_mfma_kernel; the ds_writes above are older than every read
+            // and complete first (one wave's LDS ops are ordered), so they can only make the
+            // count stricter
+#define MF_LDS_READ(dst, addr, off) \
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MF_REQ(slot, aoff, boff)                                    \
+    MF_LDS_READ(sa[slot], ap, (aoff));                               \
+    MF_LDS_READ(sb[slot][0], bp, (boff));                            \
+    MF_LDS_READ(sb[slot][1], bp, (boff) + 1152);                     \
+    MF_LDS_READ(sb[slot][2], bp, (boff) + 2304);                     \
+    MF_LDS_READ(sb[slot][3], bp, (boff) + 3456)
+#define MF_STEP(slot)                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                  \
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0);     \
+    __builtin_amdgcn_sched_barrier(0)
+            __builtin_amdgcn_sched_barrier(0);
+            MF_REQ(0, 0, 0);
+            MF_REQ(1, 16, 16);
+            for (int q = 0; q < nq; ++q) {
+                MF_REQ(2, 32, 32);
+                MF_STEP(0);
+                MF_REQ(3, 48, 48);
+                MF_STEP(1);
+                MF_REQ(0, 64, 72);
+                MF_STEP(2);
+                MF_REQ(1, 80, 88);
+                MF_STEP(3);
+                ap += 64;
+                bp += 72;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#undef MF_LDS_READ
+#undef MF_REQ
+#undef MF_STEP
+
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long lag = lag_w + 256 * u + r;
+                    const bool ok = lag >= rg.x && lag <= rg.y;
+                    float cc = 0.0f;
+                    if (ablate & 1) cc = acc[u][r] * ed[u][r];
+                    else if (ok) {
+                        const float nrm = et * ed[u][r];  // r_t * r_d
+                        if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
+                        if (!NETWORK_SUM) out[((size_t)t * n_corr + lag) * n_ch + ch] = cc;
+                    }
+                    if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
+                }
+            }
+            rec = rec1;
+            rec1 = rec2;
+            ++ri;
+        }
+    }
+    if (NETWORK_SUM) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long lag = lag_w + 256 * u;
+            float* dst = out + (size_t)t * n_corr + lag;
+            if (lag + 3 < n_corr) {
+                *(f32x4u*)dst = sum[u];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (lag + r < n_corr) dst[r] = sum[u][r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------ generic (any step) kernel ---
 // One thread per (template, lag); plain fmaf chain.  Used when step != 1 or when the
 // template is too long for the LDS tile, and as an independent on-device cross-check.
@@ -581,7 +768,20 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     mf_mfma_kernel<NS, R, TT><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,      \
         (int)n_ch, (long long)n_corr, d_cc_out, ablate, t_batch, (int)n_lag_blocks)
-        if (need_r <= 17 && need_t <= 2) {          // L <= 273
+        const char* wke = getenv("BPMF_MF_WAVE_KERNEL");
+        const bool wave_kernel = (wke ? atoi(wke) != 0 : true) && mf_kpad((int)L) <= 272;
+        if (wave_kernel) {                          // L <= 257: independent waves, no barrier
+            const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
+            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
+            if (network_sum)
+                mf_mfma_wave_kernel<true, 20, 5><<<grid, dim3(MF_THREADS), wl, stream>>>(
+                    d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,
+                    (int)n_ch, (long long)n_corr, d_cc_out, ablate, (int)n_lag_blocks);
+            else
+                mf_mfma_wave_kernel<false, 20, 5><<<grid, dim3(MF_THREADS), wl, stream>>>(
+                    d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,
+                    (int)n_ch, (long long)n_corr, d_cc_out, ablate, (int)n_lag_blocks);
+        } else if (need_r <= 17 && need_t <= 2) {   // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
             if (network_sum) BPMF_MF_LAUNCH(true, 20, 5); else BPMF_MF_LAUNCH(false, 20, 5);

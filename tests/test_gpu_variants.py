@@ -33,6 +33,23 @@ def test_mf_template_length_variants(oracle_lib, L):
         _same(got, oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"MF L={L} network_sum={ns}")
 
 
+@pytest.mark.parametrize("wave_kernel", ["0", "1"])
+def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, monkeypatch):
+    """L <= 257 defaults to the independent-wave kernel; the workgroup kernel must agree too."""
+    from seismic_bpmf_amd import matched_filter
+    monkeypatch.setenv("BPMF_MF_WAVE_KERNEL", wave_kernel)
+    rng = np.random.default_rng(77)
+    T, S, C, L, N = 3, 5, 3, 200, 30_000
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-50, 900, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[1, 2] = 0.0
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for ns in (True, False):
+        _same(matched_filter(tp, mv, w, d, 1, check_zeros=False, network_sum=ns),
+              oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"wave_kernel={wave_kernel} ns={ns}")
+
+
 def test_mf_lag_block_boundaries(oracle_lib):
     """n_corr around multiples of the 4096-lag workgroup / 1024-lag wave / 256-lag tile."""
     from seismic_bpmf_amd import matched_filter
