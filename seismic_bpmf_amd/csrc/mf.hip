@@ -183,11 +183,11 @@ __host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L
 
 // MAXR / MAXT: per-thread staging registers for the data window / the Toeplitz band
 // (window <= 256 * MAXR floats, band <= 256 * MAXT floats).
-template <bool NETWORK_SUM, int MAXR, int MAXT>
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
-    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr,
+    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
     float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
 {
     extern __shared__ float smem[];
@@ -211,7 +211,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const int tb = min(t_batch, T - batch * t_batch);
     const int t = batch * t_batch + rem % tb;
     const long long lag0 = (long long)(rem / tb) * MF_LAGS_PER_WG;
-    const int2 rg = range[t];
+    // `range` holds CC indices; the kernel works on data-sample offsets (lag = index * step) and
+    // simply skips the offsets that are not multiples of step
+    const int2 rgi = range[t];
+    const int2 rg = make_int2(rgi.x * step, rgi.y * step);
     const long long nwin = N - L + 1;
 
     f32x4 sum[4];
@@ -359,13 +362,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long lag = lag_w + 256 * u + r;
-                    const bool ok = lag >= rg.x && lag <= rg.y;
+                    // STEP1 builds carry no division at all; otherwise 32-bit (lags < 2^31)
+                    const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
                     if (ablate & 1) cc = acc[u][r] * ed[u][r];
                     else if (ok) {
                         const float nrm = et * ed[u][r];  // r_t * r_d
                         if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
-                        if (!NETWORK_SUM) out[((size_t)t * n_corr + lag) * n_ch + ch] = cc;
+                        if (!NETWORK_SUM)
+                            out[((size_t)t * n_corr + (STEP1 ? lag : (long long)((unsigned)lag / (unsigned)step))) * n_ch + ch] = cc;
                     }
                     if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                 }
@@ -381,12 +386,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
         for (int u = 0; u < 4; ++u) {
             const long long lag = lag_w + 256 * u;
             float* dst = out + (size_t)t * n_corr + lag;
-            if (lag + 3 < n_corr) {
+            if (STEP1 && lag + 3 < n_corr) {
                 *(f32x4u*)dst = sum[u];
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (lag + r < n_corr) dst[r] = sum[u][r];
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned smp = (unsigned)(lag + r);
+                    const long long i = STEP1 ? (long long)smp : (long long)(smp / (unsigned)step);
+                    if ((STEP1 || smp % (unsigned)step == 0) && i < n_corr) out[(size_t)t * n_corr + i] = sum[u][r];
+                }
             }
         }
     }
@@ -400,11 +408,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // execute in order): single-buffered, 6.6 KB per wave instead of 9.9 KB.  The price is the
 // 256-float overlap between neighbouring waves' windows (25 % more staging traffic from L2).
 // Used for L <= 257 (window 1280 floats = 20 staging registers per lane).
-template <bool NETWORK_SUM, int MAXR, int MAXT>
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
-    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr,
+    const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
     float* __restrict__ out, int ablate, int n_lag_blocks)
 {
     extern __shared__ float smem[];
@@ -421,7 +429,8 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 
     const int t = blockIdx.x % T;
     const long long lag0 = (long long)(blockIdx.x / T) * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
-    const int2 rg = range[t];
+    const int2 rgi = range[t];
+    const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
     (void)n_lag_blocks;
 
@@ -547,13 +556,15 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long lag = lag_w + 256 * u + r;
-                    const bool ok = lag >= rg.x && lag <= rg.y;
+                    // STEP1 builds carry no division at all; otherwise 32-bit (lags < 2^31)
+                    const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
                     if (ablate & 1) cc = acc[u][r] * ed[u][r];
                     else if (ok) {
                         const float nrm = et * ed[u][r];  // r_t * r_d
                         if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
-                        if (!NETWORK_SUM) out[((size_t)t * n_corr + lag) * n_ch + ch] = cc;
+                        if (!NETWORK_SUM)
+                            out[((size_t)t * n_corr + (STEP1 ? lag : (long long)((unsigned)lag / (unsigned)step))) * n_ch + ch] = cc;
                     }
                     if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                 }
@@ -568,12 +579,15 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         for (int u = 0; u < 4; ++u) {
             const long long lag = lag_w + 256 * u;
             float* dst = out + (size_t)t * n_corr + lag;
-            if (lag + 3 < n_corr) {
+            if (STEP1 && lag + 3 < n_corr) {
                 *(f32x4u*)dst = sum[u];
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (lag + r < n_corr) dst[r] = sum[u][r];
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned smp = (unsigned)(lag + r);
+                    const long long i = STEP1 ? (long long)smp : (long long)(smp / (unsigned)step);
+                    if ((STEP1 || smp % (unsigned)step == 0) && i < n_corr) out[(size_t)t * n_corr + i] = sum[u][r];
+                }
             }
         }
     }
@@ -751,11 +765,15 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     size_t lds = mf_lds_bytes((int)L);
     if (const char* ex = getenv("BPMF_MF_LDS_EXTRA_KB")) lds += (size_t)atoi(ex) * 1024;  // occupancy experiments
-    const size_t n_lag_blocks = (n_corr + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
+    // the MFMA kernels evaluate every data-sample offset and keep the multiples of `step`
+    const size_t n_offsets = (n_corr - 1) * step + 1;
+    const size_t n_lag_blocks = (n_offsets + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
     // staging registers needed per thread (window / band), rounded to a compiled variant
     const int need_r = (mf_window_len((int)L) + MF_THREADS - 1) / MF_THREADS;
     const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
-    const bool use_mfma = step == 1 && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
+    const char* mse = getenv("BPMF_MF_MAX_MFMA_STEP");
+    const size_t max_mfma_step = mse ? (size_t)atoi(mse) : 64;  // beyond this the direct kernel wins
+    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
                           need_t <= 9 && T * n_lag_blocks < 0x7fffffffull;
     if (use_mfma) {
         dim3 grid((unsigned)(T * n_lag_blocks));
@@ -764,23 +782,26 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         const char* tbe = getenv("BPMF_MF_TBATCH");
         int t_batch = tbe ? atoi(tbe) : (int)T;
         if (t_batch < 1 || t_batch > (int)T) t_batch = (int)T;
-#define BPMF_MF_LAUNCH(NS, R, TT)                                                            \
-    mf_mfma_kernel<NS, R, TT><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
+#define BPMF_MF_LAUNCH2(NS, R, TT, S1)                                                            \
+    mf_mfma_kernel<NS, R, TT, S1><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,      \
-        (int)n_ch, (long long)n_corr, d_cc_out, ablate, t_batch, (int)n_lag_blocks)
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, t_batch, (int)n_lag_blocks)
+#define BPMF_MF_LAUNCH(NS, R, TT) \
+    do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
         const char* wke = getenv("BPMF_MF_WAVE_KERNEL");
         const bool wave_kernel = (wke ? atoi(wke) != 0 : true) && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
-            if (network_sum)
-                mf_mfma_wave_kernel<true, 20, 5><<<grid, dim3(MF_THREADS), wl, stream>>>(
-                    d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,
-                    (int)n_ch, (long long)n_corr, d_cc_out, ablate, (int)n_lag_blocks);
-            else
-                mf_mfma_wave_kernel<false, 20, 5><<<grid, dim3(MF_THREADS), wl, stream>>>(
-                    d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,
-                    (int)n_ch, (long long)n_corr, d_cc_out, ablate, (int)n_lag_blocks);
+#define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                           \
+    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid, dim3(MF_THREADS), wl, stream>>>(                  \
+        d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks)
+            if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
+            else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
+            else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);
+            else BPMF_MF_WAVE_LAUNCH(false, false);
+#undef BPMF_MF_WAVE_LAUNCH
         } else if (need_r <= 17 && need_t <= 2) {   // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
@@ -789,6 +810,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             if (network_sum) BPMF_MF_LAUNCH(true, 24, 9); else BPMF_MF_LAUNCH(false, 24, 9);
         }
 #undef BPMF_MF_LAUNCH
+#undef BPMF_MF_LAUNCH2
     } else {
         dim3 grid((unsigned)((n_corr + 255) / 256), (unsigned)T);
         if (T > 65535) {

@@ -50,6 +50,23 @@ def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, monkeypatch):
               oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"wave_kernel={wave_kernel} ns={ns}")
 
 
+@pytest.mark.parametrize("step", [2, 3, 7, 16, 17, 50])
+@pytest.mark.parametrize("L", [64, 400])
+def test_mf_step_greater_than_one(oracle_lib, step, L):
+    """step <= 16 runs on the MFMA kernels (every offset evaluated, multiples of step kept);
+    larger steps on the generic kernel.  Negative moveouts exercise the ceil in the first valid lag."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(step * 100 + L)
+    T, S, C, N = 3, 3, 3, 9000 + step
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-37, 300, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns)
+        _same(got, oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"step={step} L={L} ns={ns}")
+
+
 def test_mf_lag_block_boundaries(oracle_lib):
     """n_corr around multiples of the 4096-lag workgroup / 1024-lag wave / 256-lag tile."""
     from seismic_bpmf_amd import matched_filter
