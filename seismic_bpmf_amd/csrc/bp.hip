@@ -802,7 +802,7 @@ void bisect_order(const int32_t* mv, size_t SP, std::vector<int>& idx, size_t lo
 // next source would push the LDS need (zero slab + sum over used rows of tile + moveout
 // spread) past the soft budget.  Returns false if one source alone exceeds `hard_floats`.
 bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P, int tile,
-                int chunk, size_t soft_floats, size_t hard_floats, int max_group, bool reorder,
+                int chunk, size_t soft_floats, const size_t hard_floats, int max_group, bool reorder,
                 int32_t id_offset, PlanHost& ph)
 {
     const size_t SP = S * P;
@@ -831,6 +831,13 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     }
     const int NT = (int)((max_terms + chunk - 1) / chunk * chunk);
     ph.NT = NT;
+    // A source's own windows (terms x tile + the zero slab) must leave room for the moveout
+    // spread of a useful group.  When they do not even fit the soft budget with 16 samples of
+    // spread per row (dense station weights), use the whole LDS (one workgroup per CU) instead of
+    // degenerating to one source per group.  (Measured on cfg3 geometry, 10 / 15 / 20 used
+    // stations: 0.35 / 0.64 / 0.91 s.)
+    const size_t base_need = (max_terms + 1) * (size_t)tile;
+    if (base_need + max_terms * 16 > soft_floats) soft_floats = hard_floats;
     ph.off.assign(K * (size_t)NT, 0);       // padded terms read the zero slab at offset 0
     ph.beta.assign(K * (size_t)NT, 0.0f);
 
@@ -996,10 +1003,10 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         if ((rc = upload(tv, &pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
     }
     // packed per-station records for the two-phase fast kernel
-    if (P == 2 && pl->ntv && env_int("BPMF_BP_PACKED", 1)) {
+    if (P == 2 && ph.NT <= 64 && env_int("BPMF_BP_PACKED", 1)) {
         const int nsta_max = ph.NT / 2;   // NT is a multiple of 4
-        const int opts[4] = {4, 8, 12, 16};
-        for (int o = 0; o < 4 && !pl->nsv; ++o)
+        const int opts[6] = {4, 8, 12, 16, 24, 32};
+        for (int o = 0; o < 6 && !pl->nsv; ++o)
             if (nsta_max <= opts[o]) pl->nsv = opts[o];
         pl->wpb = 4;  // measured on cfg3: 4 -> 0.351 s, 6 -> 0.491 s, 8 (spills) -> 0.598 s
     }
@@ -1216,6 +1223,8 @@ int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int
             case 8: return dispatch_beam_wps2<8>(pl, U, N, oob, reduce, stream, beam, arg);
             case 12: return dispatch_beam_wps2<12>(pl, U, N, oob, reduce, stream, beam, arg);
             case 16: return dispatch_beam_wps2<16>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 24: return dispatch_beam_wps2<24>(pl, U, N, oob, reduce, stream, beam, arg);
+            case 32: return dispatch_beam_wps2<32>(pl, U, N, oob, reduce, stream, beam, arg);
             default: break;
         }
     }
