@@ -777,15 +777,22 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                           need_t <= 9 && T * n_lag_blocks < 0x7fffffffull;
     if (use_mfma) {
         dim3 grid((unsigned)(T * n_lag_blocks));
+        const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
         const char* abl = getenv("BPMF_MF_ABLATE");  // kernel-phase ablation, profiling only
         const int ablate = abl ? atoi(abl) : 0;
         const char* tbe = getenv("BPMF_MF_TBATCH");
         int t_batch = tbe ? atoi(tbe) : (int)T;
         if (t_batch < 1 || t_batch > (int)T) t_batch = (int)T;
 #define BPMF_MF_LAUNCH2(NS, R, TT, S1)                                                            \
-    mf_mfma_kernel<NS, R, TT, S1><<<grid, dim3(MF_THREADS), lds, stream>>>(                      \
-        d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,      \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, t_batch, (int)n_lag_blocks)
+    do {                                                                                              \
+        auto kfn = mf_mfma_kernel<NS, R, TT, S1>;                                                     \
+        if (big_lds)                                                                                  \
+            BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kfn,                                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        kfn<<<grid, dim3(MF_THREADS), lds, stream>>>(                                                 \
+            d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,         \
+            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, t_batch, (int)n_lag_blocks);   \
+    } while (0)
 #define BPMF_MF_LAUNCH(NS, R, TT) \
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
         const char* wke = getenv("BPMF_MF_WAVE_KERNEL");
