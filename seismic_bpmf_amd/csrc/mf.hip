@@ -322,17 +322,37 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             float sa[4], sb[4][4];
 #define MF_LDS_READ(dst, addr, off) \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MF_MFMA(slot, u) \
+    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0)
 #define MF_REQ(slot, aoff, boff)                                    \
     MF_LDS_READ(sa[slot], ap, (aoff));                               \
     MF_LDS_READ(sb[slot][0], bp, (boff));                            \
     MF_LDS_READ(sb[slot][1], bp, (boff) + 1088);                     \
     MF_LDS_READ(sb[slot][2], bp, (boff) + 2176);                     \
     MF_LDS_READ(sb[slot][3], bp, (boff) + 3264)
-#define MF_STEP(slot)                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                  \
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0);     \
+// One k-step: the 4 MFMAs of slot `cur` with the 5 operand reads of slot `req` (two k-steps
+// ahead) issued between them (a wave waits ~32 cycles at every MFMA for the matrix pipe; a read
+// placed there issues for free).  On entry the reads of `cur` and of the following k-step are
+// outstanding (10) and LDS returns in order: lgkmcnt(5) = "cur has landed".
+#define MF_STEP(cur, req, aoff, boff)                                \
+    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 0);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sa[req], ap, (aoff));                                \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 1);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][0], bp, (boff));                             \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 2);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][1], bp, (boff) + 1088);                      \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 3);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][2], bp, (boff) + 2176);                      \
+    MF_LDS_READ(sb[req][3], bp, (boff) + 3264);                      \
     __builtin_amdgcn_sched_barrier(0)
             // (a scalar load may still be in flight here -- the next-but-one channel record; it
             // only makes the counted waits stricter, never laxer: LDS returns in order)
@@ -340,20 +360,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
-                MF_REQ(2, 32, 32);
-                MF_STEP(0);
-                MF_REQ(3, 48, 48);
-                MF_STEP(1);
-                MF_REQ(0, 64, 68);   // k-step 0 of the next trip (past the last trip: slack, unused)
-                MF_STEP(2);
-                MF_REQ(1, 80, 84);
-                MF_STEP(3);
+                MF_STEP(0, 2, 32, 32);
+                MF_STEP(1, 3, 48, 48);
+                MF_STEP(2, 0, 64, 68);   // requests k-step 0 of the next trip (past the end: slack)
+                MF_STEP(3, 1, 80, 84);
                 ap += 64;
                 bp += 68;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // drain the two k-steps read ahead
             __builtin_amdgcn_sched_barrier(0);
 #undef MF_LDS_READ
+#undef MF_MFMA
 #undef MF_REQ
 #undef MF_STEP
 
@@ -518,36 +535,54 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             // count stricter
 #define MF_LDS_READ(dst, addr, off) \
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MF_MFMA(slot, u) \
+    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0)
 #define MF_REQ(slot, aoff, boff)                                    \
     MF_LDS_READ(sa[slot], ap, (aoff));                               \
     MF_LDS_READ(sb[slot][0], bp, (boff));                            \
     MF_LDS_READ(sb[slot][1], bp, (boff) + 1152);                     \
     MF_LDS_READ(sb[slot][2], bp, (boff) + 2304);                     \
     MF_LDS_READ(sb[slot][3], bp, (boff) + 3456)
-#define MF_STEP(slot)                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                  \
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0);     \
+// One k-step: the 4 MFMAs of slot `cur` with the 5 operand reads of slot `req` (two k-steps
+// ahead) issued BETWEEN them.  A wave issues in order and waits ~32 cycles at every MFMA for the
+// matrix pipe; a read placed there issues for free, a block of reads after the MFMAs would add
+// its issue time to every k-step.  On entry the reads of `cur` and of the k-step after it are
+// outstanding (10), LDS returns in order, so lgkmcnt(5) = "cur has landed".
+#define MF_STEP(cur, req, aoff, boff)                                \
+    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 0);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sa[req], ap, (aoff));                                \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 1);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][0], bp, (boff));                             \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 2);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][1], bp, (boff) + 1152);                      \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_MFMA(cur, 3);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    MF_LDS_READ(sb[req][2], bp, (boff) + 2304);                      \
+    MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
     __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
-                MF_REQ(2, 32, 32);
-                MF_STEP(0);
-                MF_REQ(3, 48, 48);
-                MF_STEP(1);
-                MF_REQ(0, 64, 72);
-                MF_STEP(2);
-                MF_REQ(1, 80, 88);
-                MF_STEP(3);
+                MF_STEP(0, 2, 32, 32);
+                MF_STEP(1, 3, 48, 48);
+                MF_STEP(2, 0, 64, 72);   // requests k-step 0 of the next trip (past the end: slack)
+                MF_STEP(3, 1, 80, 88);
                 ap += 64;
                 bp += 72;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #undef MF_LDS_READ
+#undef MF_MFMA
 #undef MF_REQ
 #undef MF_STEP
 
