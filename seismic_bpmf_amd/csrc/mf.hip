@@ -288,16 +288,16 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             for (int u = 0; u < 4; ++u) {
                 const long long lag = lag_w + 256 * u;
                 // all four lags of the group inside the valid range -> one 16-byte load
+                // One 16-byte load per group of 4 lags.  A group that straddles an end of the
+                // valid range reads up to 3 floats outside this channel's row of norms -- the
+                // neighbouring row or the slack around the array -- and those lanes are masked in
+                // the epilogue (`ok`).
                 if (ablate & 8) {
                     ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (lag >= rg.x && lag + 3 <= rg.y) {
+                } else if (lag + 3 >= rg.x && lag <= rg.y) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = lag + r >= rg.x && lag + r <= rg.y;
-                        ed[u][r] = ok ? edc[lag + r + mvc] : 0.0f;
-                    }
+                    ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
             if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
@@ -510,16 +510,16 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long long lag = lag_w + 256 * u;
+                // One 16-byte load per group of 4 lags.  A group that straddles an end of the
+                // valid range reads up to 3 floats outside this channel's row of norms -- the
+                // neighbouring row or the slack around the array -- and those lanes are masked in
+                // the epilogue (`ok`).
                 if (ablate & 8) {
                     ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (lag >= rg.x && lag + 3 <= rg.y) {
+                } else if (lag + 3 >= rg.x && lag <= rg.y) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = lag + r >= rg.x && lag + r <= rg.y;
-                        ed[u][r] = ok ? edc[lag + r + mvc] : 0.0f;
-                    }
+                    ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
             if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
@@ -688,7 +688,8 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.local = (double*)(p + o); o += align_up(n_ch * N * sizeof(double), 256);
     ws.tot = (double*)(p + o);   o += align_up(n_ch * nq * sizeof(double), 256);
     ws.off = (double*)(p + o);   o += align_up(n_ch * nq * sizeof(double), 256);
-    ws.e_d = (float*)(p + o);    o += align_up(n_ch * nwin * sizeof(float), 256);
+    o += 256;  // slack: the main kernel's 16-byte norm loads may start 3 floats early ...
+    ws.e_d = (float*)(p + o);    o += align_up(n_ch * nwin * sizeof(float) + 64, 256);  // ... or end 3 late
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
     ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
