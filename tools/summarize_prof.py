@@ -30,4 +30,4 @@ if __name__ == "__main__":
         kernel_stats(ks[0], f"profiles/{tag}_kernel_stats.csv")
     pm = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
     if pm:
-        print(json.dumps(pmc(pm, ["mf_mfma_kernel", "bp_beam", "mf_csum_local", "bp_prestack"], f"profiles/{tag}_pmc.json"), indent=1))
+        print(json.dumps(pmc(pm, ["mf_mfma", "bp_beam", "mf_csum_local", "bp_prestack", "tdt_window"], f"profiles/{tag}_pmc.json"), indent=1))
