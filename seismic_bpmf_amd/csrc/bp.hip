@@ -16,6 +16,7 @@
 //      (max, arg-max) per time sample: no atomics, no cross-workgroup merge, and the
 //      sequential source order gives the "lowest index wins ties" rule for free.
 #include "common.h"
+#include <type_traits>
 #include "../../include/bpmf_hip.h"
 
 #include <algorithm>
@@ -544,8 +545,9 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
 // fit 16 bits; both phases share the station weight): half the registers and half the
 // vector-memory traffic of the per-term table, two prefetched sets instead of three.
 // WPB = waves per workgroup (all waves share the group's LDS windows and take different
-// sources).  Measured on cfg3: WPB 4 (8 waves/CU) 0.351 s, WPB 6 (12 waves/CU) 0.491 s,
-// WPB 8 (16 waves/CU, spills at 128 VGPRs) 0.598 s -> 4 is the default.
+// sources).  Measured on cfg3 with the metadata in VGPRs: WPB 4 (8 waves/CU) 0.342 s, more waves
+// spill; with the metadata in SGPRs (BpMetaS, <= 80 VGPRs): WPB 4 0.280 s, WPB 8 (16 waves/CU)
+// 0.241 s, WPB 12 (24 waves/CU) 0.236 s.
 template <int NSV>
 struct BpMetaP {
     int4 hd;            // id, tmin, tmax, stations (padded to 2; 0 = unused source)
@@ -558,9 +560,47 @@ struct BpMetaP {
 #pragma unroll
         for (int i = 0; i < NSV / 2; ++i) st[i] = recs[kk * (NSV / 2) + i];
     }
+    __device__ __forceinline__ unsigned offs(int s) const { return (unsigned)((s & 1) ? st[s >> 1].z : st[s >> 1].x); }
+    __device__ __forceinline__ float beta(int s) const { return __int_as_float((s & 1) ? st[s >> 1].w : st[s >> 1].y); }
+    __device__ __forceinline__ int id() const { return hd.x; }
+    __device__ __forceinline__ int tmin() const { return hd.y; }
+    __device__ __forceinline__ int tmax() const { return hd.z; }
+    __device__ __forceinline__ int nsta() const { return hd.w; }
 };
 
-template <int WPB, int NSV, int OOB, int REDUCE>
+// Scalar-register variant of the metadata (NSV <= 16): ONE set of 4 + 2 NSV SGPRs, filled by
+// inline-asm s_load_dwordx4/x8 for the NEXT source right after the last gather of the current
+// one, so the scalar-cache latency hides behind the max/arg-max epilogue.  SMEM shares lgkmcnt
+// with the LDS gathers and returns out of order, hence the placement: nothing else is in flight
+// between the issue and the lgkmcnt(0) that closes the source.  Frees 2 x (4 + 2 NSV) VGPRs,
+// which is what lets 16 waves/CU (128 VGPRs) run without spills.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int NSV>
+struct BpMetaS {
+    i32x4 hd;
+    i32x8 r[NSV / 4];   // station s: dword 2 s = offs, 2 s + 1 = weight
+    __device__ __forceinline__ void issue(const int4* __restrict__ srcs4,
+                                          const int4* __restrict__ recs, int k)
+    {
+        const int4* ph = srcs4 + k;
+        const int4* pr = recs + (size_t)k * (NSV / 2);
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(hd) : "s"(ph));
+#pragma unroll
+        for (int i = 0; i < NSV / 4; ++i) {
+            const int4* pi = pr + 2 * i;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r[i]) : "s"(pi));
+        }
+    }
+    __device__ __forceinline__ unsigned offs(int s) const { return (unsigned)r[(2 * s) >> 3][(2 * s) & 7]; }
+    __device__ __forceinline__ float beta(int s) const { return __int_as_float(r[(2 * s + 1) >> 3][(2 * s + 1) & 7]); }
+    __device__ __forceinline__ int id() const { return hd[0]; }
+    __device__ __forceinline__ int tmin() const { return hd[1]; }
+    __device__ __forceinline__ int tmax() const { return hd[2]; }
+    __device__ __forceinline__ int nsta() const { return hd[3]; }
+};
+
+template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA = false>
 __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
@@ -573,7 +613,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
     constexpr int NTHREADS = 64 * WPB;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = tid >> 8;        // staging sub-group of 256 threads
     const int stid = tid & 255;
     const long long t0 = (long long)blockIdx.x * TILE;
@@ -591,8 +631,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
         const BpGroup grp = groups[g];
         const int k_last = grp.first_src + grp.n_src - 1;
         const int k_first = grp.first_src + wv;
-        BpMetaP<NSV> m0, m1;
-        m0.load(srcs4, recs, min(k_first, k_last), vzero);
+        using Meta = typename std::conditional<SMETA, BpMetaS<NSV>, BpMetaP<NSV>>::type;
+        Meta m0, m1;
+        if constexpr (SMETA) {
+            if (k_first <= k_last) m0.issue(srcs4, recs, k_first);  // waited for below
+        } else {
+            m0.load(srcs4, recs, min(k_first, k_last), vzero);
+        }
         __syncthreads();  // previous group's gathers are done
         for (int cb = 0; cb < grp.n_chunk; cb += 64) {
             const int nb = min(64, grp.n_chunk - cb);
@@ -625,52 +670,119 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
         }
         __syncthreads();
 
-        auto process = [&](const BpMetaP<NSV>& m, bool live) {
-            const int nsta = live ? __builtin_amdgcn_readfirstlane(m.hd.w) : 0;
+        // Gathers of one station (2 phases x 8 samples = 8 ds_read2st64_b32) are inline asm with
+        // counted waits, software-pipelined one station ahead: while station s is accumulated the
+        // 8 reads of station s+1 are already queued, so the LDS never drains between stations
+        // (hipcc's own schedule is [16 reads][wait][16 fma] per pair of stations, which leaves the
+        // LDS idle during the fma / issue phases of all 8 waves: 62 % busy).  LDS returns in
+        // order: with 16 reads outstanding, lgkmcnt(8) = "station s has landed".
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const unsigned lds_lu = (unsigned)(size_t)lds_l;
+#define BP_RD2(dst, addr, o0, o1) \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
+#define BP_PKFMA(acc2, b2, x2) \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2) : "v"(b2), "v"(x2))
+#define BP_ISSUE(X, OFFS)                                                   \
+    {                                                                       \
+        const unsigned a0 = lds_lu + (((OFFS) & 0xffffu) << 2);             \
+        const unsigned a1 = lds_lu + (((OFFS) >> 16) << 2);                 \
+        BP_RD2(X[0], a0, 0, 1); BP_RD2(X[1], a0, 2, 3);                     \
+        BP_RD2(X[2], a0, 4, 5); BP_RD2(X[3], a0, 6, 7);                     \
+        BP_RD2(X[4], a1, 0, 1); BP_RD2(X[5], a1, 2, 3);                     \
+        BP_RD2(X[6], a1, 4, 5); BP_RD2(X[7], a1, 6, 7);                     \
+    }
+        // One straight-line body per station count (no control flow between the asm reads and
+        // their uses: with phis in between, the compiler copies the destination registers of
+        // reads that are still in flight).
+        // The fma chain is asm volatile as well: plain fmaf()s are pure and get sunk below the
+        // later reads at IR level (every station then needs its own 16 destination VGPRs).
+        auto gather = [&](auto nst_c, const Meta& m, float (&acc)[TPW]) {
+            constexpr int NST = decltype(nst_c)::value;
+            f32x2 xe[8], xo[8];  // gathers of the even / odd station in flight
+            f32x2 ac[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { ac[jj][0] = 0.0f; ac[jj][1] = 0.0f; }
+            BP_ISSUE(xe, m.offs(0))
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                const float beta = m.beta(st);
+                f32x2 bb; bb[0] = beta; bb[1] = beta;
+                if (st + 1 < NST) {
+                    const unsigned offs_n = m.offs(st + 1);
+                    if (st & 1) BP_ISSUE(xe, offs_n) else BP_ISSUE(xo, offs_n)
+                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p)      // phase P then phase S, as the oracle
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (st & 1) BP_PKFMA(ac[jj], bb, xo[4 * p + jj]);
+                        else BP_PKFMA(ac[jj], bb, xe[4 * p + jj]);
+                    }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { acc[2 * jj] = ac[jj][0]; acc[2 * jj + 1] = ac[jj][1]; }
+        };
+        // k_next >= 0 (SMETA): refill m with that source once its own gathers are done
+        auto process = [&](Meta& m, bool live, int k_next) {
+            const int nsta = live ? __builtin_amdgcn_readfirstlane(m.nsta()) : 0;
+            const int sid = m.id(), tmin = m.tmin(), tmax = m.tmax();
             float acc[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[j] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < NSV / 2; ++c) {
-                if (c * 2 < nsta) {  // wave-uniform
-                    const int4 tt = m.st[c];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const unsigned offs = (unsigned)(h ? tt.z : tt.x);
-                        const float beta = __int_as_float(h ? tt.w : tt.y);
-                        const float* lp0 = (const float*)(lds_l + ((offs & 0xffffu) << 2));
-                        const float* lp1 = (const float*)(lds_l + ((offs >> 16) << 2));
-                        float x0[TPW], x1[TPW];
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) { x0[j] = lp0[j * 64]; x1[j] = lp1[j * 64]; }
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(beta, x0[j], acc[j]);
-#pragma unroll
-                        for (int j = 0; j < TPW; ++j) acc[j] = __fmaf_rn(beta, x1[j], acc[j]);
-                    }
-                }
+#define BP_CASE(n) \
+    case n: if constexpr (2 * n <= NSV) gather(std::integral_constant<int, 2 * n>{}, m, acc); break;
+            switch (nsta >> 1) {  // wave-uniform; station records come in pairs
+                BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) BP_CASE(8)
+                BP_CASE(9) BP_CASE(10) BP_CASE(11) BP_CASE(12) BP_CASE(13) BP_CASE(14) BP_CASE(15)
+                BP_CASE(16)
+                default: break;
             }
-            const int sid = m.hd.x;
+#undef BP_CASE
+            if constexpr (SMETA) m.issue(srcs4, recs, k_next);
+            // strict bounds as a wave-uniform window [lo, hi) of the tile: 0 <= t + tmin and
+            // t + tmax < N with t = t0 + x
+            int lo = 0, hi = TILE;
+            if (OOB == BPMF_BP_STRICT) {
+                const long long lo64 = -(t0 + tmin), hi64 = N - t0 - tmax;
+                lo = (int)(lo64 < 0 ? 0 : (lo64 > TILE ? TILE : lo64));
+                hi = (int)(hi64 < 0 ? 0 : (hi64 > TILE ? TILE : hi64));
+            }
+            if (nsta <= 0) hi = 0;
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                const long long t = t0 + lane + 64 * j;
-                bool computed = nsta > 0;
-                if (OOB == BPMF_BP_STRICT) computed = computed && (t + m.hd.y >= 0) && (t + m.hd.z < N);
+                const int x = lane + 64 * j;
+                // bitwise, not short-circuit: keeps the epilogue free of branches
+                const bool computed = (x >= lo) & (x < hi);
                 if (REDUCE == BPMF_BP_REDUCE_MAX) {
-                    const bool better = acc[j] > best[j] || (acc[j] == best[j] && sid < arg[j]);
-                    if (computed && better) { best[j] = acc[j]; arg[j] = sid; }
+                    const bool take =
+                        computed & ((acc[j] > best[j]) | ((acc[j] == best[j]) & (sid < arg[j])));
+                    best[j] = take ? acc[j] : best[j];
+                    arg[j] = take ? sid : arg[j];
                 } else {
+                    const long long t = t0 + x;
                     if (live && t < N)
                         out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
                 }
             }
+            if constexpr (SMETA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-        for (int k = k_first; k <= k_last; k += 2 * WPB) {
-            m1.load(srcs4, recs, min(k + WPB, k_last), vzero);
-            process(m0, true);
-            m0.load(srcs4, recs, min(k + 2 * WPB, k_last), vzero);
-            process(m1, k + WPB <= k_last);
+        if constexpr (SMETA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int k = k_first; k <= k_last; k += WPB) process(m0, true, min(k + WPB, k_last));
+        } else {
+            for (int k = k_first; k <= k_last; k += 2 * WPB) {
+                m1.load(srcs4, recs, min(k + WPB, k_last), vzero);
+                process(m0, true, -1);
+                m0.load(srcs4, recs, min(k + 2 * WPB, k_last), vzero);
+                process(m1, k + WPB <= k_last, -1);
+            }
         }
+#undef BP_RD2
+#undef BP_ISSUE
+#undef BP_PKFMA
     }
     if (REDUCE == BPMF_BP_REDUCE_MAX) {
         __syncthreads();
@@ -1173,11 +1285,11 @@ int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob,
     return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
-template <int WPB, int NSV, int OOB, int REDUCE>
+template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA>
 int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                      float* beam, int32_t* arg)
 {
-    auto kern = bp_beam_wps2_kernel<WPB, NSV, OOB, REDUCE>;
+    auto kern = bp_beam_wps2_kernel<WPB, NSV, OOB, REDUCE, SMETA>;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * WPB * 512 * sizeof(float));
     if (lds > 64 * 1024)
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
@@ -1193,24 +1305,34 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
     return 0;
 }
 
-template <int WPB, int NSV>
+template <int WPB, int NSV, bool SMETA>
 int dispatch_beam_wps2b(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                         hipStream_t stream, float* beam, int32_t* arg)
 {
     if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX, SMETA>(pl, U, N, stream, beam, arg);
     if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX, SMETA>(pl, U, N, stream, beam, arg);
     if (oob == BPMF_BP_STRICT)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
-    return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE, SMETA>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE, SMETA>(pl, U, N, stream, beam, arg);
 }
 
 template <int NSV>
 int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                        hipStream_t stream, float* beam, int32_t* arg)
 {
-    return dispatch_beam_wps2b<4, NSV>(pl, U, N, oob, reduce, stream, beam, arg);
+    // NSV <= 16: metadata in SGPRs, 12 waves per workgroup, 2 workgroups (24 waves) per CU --
+    // ds_read_b32-class gathers need >= 4 waves/SIMD to reach the LDS rate.  Above 16 stations
+    // the SGPR set no longer fits and the VGPR-metadata variant (8 waves/CU) runs.
+    static const int wpb = env_int("BPMF_BP_WPB", 12);
+    static const int smeta = env_int("BPMF_BP_SMETA", 1);
+    if constexpr (NSV <= 16) {
+        if (smeta && wpb == 12) return dispatch_beam_wps2b<12, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+        if (smeta && wpb == 8) return dispatch_beam_wps2b<8, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+        if (smeta) return dispatch_beam_wps2b<4, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+    }
+    return dispatch_beam_wps2b<4, NSV, false>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
 template <int TPT>
