@@ -576,6 +576,7 @@ struct BpMetaP {
 // which is what lets 16 waves/CU (128 VGPRs) run without spills.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <int NSV>
 struct BpMetaS {
     i32x4 hd;
@@ -592,16 +593,45 @@ struct BpMetaS {
             asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r[i]) : "s"(pi));
         }
     }
+    // s_waitcnt lgkmcnt(0) with every register of the set as an INPUT: no part of the set is
+    // dead (= free for the register allocator to hand out as a temporary) while the loads are
+    // in flight.  Inputs only -- a "+s" tie makes the compiler copy the in-flight registers in
+    // front of the wait.  The sched_barrier keeps later uses behind the wait.
+    __device__ __forceinline__ void wait() const
+    {
+        static_assert(NSV / 4 >= 1 && NSV / 4 <= 4, "BpMetaS: NSV in {4, 8, 12, 16}");
+        if constexpr (NSV / 4 == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]) : "memory");
+        else if constexpr (NSV / 4 == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]), "s"(r[1]) : "memory");
+        else if constexpr (NSV / 4 == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]), "s"(r[1]), "s"(r[2]) : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : : "s"(hd), "s"(r[0]), "s"(r[1]), "s"(r[2]), "s"(r[3]) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __device__ __forceinline__ unsigned offs(int s) const { return (unsigned)r[(2 * s) >> 3][(2 * s) & 7]; }
     __device__ __forceinline__ float beta(int s) const { return __int_as_float(r[(2 * s + 1) >> 3][(2 * s + 1) & 7]); }
+    // {offs, weight} as one aligned SGPR pair: v_pk_fma_f32 takes the weight from its high half
+    __device__ __forceinline__ i32x2 pair(int s) const
+    {
+        i32x2 p;
+        p[0] = r[(2 * s) >> 3][(2 * s) & 7];
+        p[1] = r[(2 * s + 1) >> 3][(2 * s + 1) & 7];
+        return p;
+    }
     __device__ __forceinline__ int id() const { return hd[0]; }
     __device__ __forceinline__ int tmin() const { return hd[1]; }
     __device__ __forceinline__ int tmax() const { return hd[2]; }
     __device__ __forceinline__ int nsta() const { return hd[3]; }
 };
 
-template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA = false>
-__global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kernel(
+// B64 (plans with dual windows, see build_plan): every LDS offset is even, a lane owns the
+// sample PAIRS 128 j + 2 lane + {0, 1} and gathers them with ds_read_b64 -- 256 B/clk/CU instead of
+// the 128 B/clk/CU of the 4-byte gathers.
+template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA = false, bool B64 = false>
+__global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) void bp_beam_wps2_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ recs, int id_offset, float* __restrict__ out_beam,
@@ -611,6 +641,12 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
     constexpr int TPW = 8;
     constexpr int TILE = 64 * TPW;
     constexpr int NTHREADS = 64 * WPB;
+#ifndef BP_DBG
+#define BP_DBG 0
+#endif
+    constexpr bool GLOCAL = B64 && REDUCE == BPMF_BP_REDUCE_MAX && !(BP_DBG & 1);
+    constexpr bool SPAIR = SMETA && !(BP_DBG & 2);
+    constexpr bool FASTP = !(BP_DBG & 4);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -619,7 +655,9 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
     const long long t0 = (long long)blockIdx.x * TILE;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    const char* lds_l = (const char*)lds + lane * 4;
+    const char* lds_l = (const char*)lds + lane * (B64 ? 8 : 4);
+    // tile sample held in accumulator slot j of this lane
+    auto slot_x = [&](int j) { return B64 ? 128 * (j >> 1) + 2 * lane + (j & 1) : lane + 64 * j; };
 
     float best[TPW];
     int arg[TPW];
@@ -633,8 +671,17 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
         const int k_first = grp.first_src + wv;
         using Meta = typename std::conditional<SMETA, BpMetaS<NSV>, BpMetaP<NSV>>::type;
         Meta m0, m1;
+        // GLOCAL: the plan lists a group's sources by ascending id, so inside a group a plain
+        // strict > keeps the lowest id on ties; the full tie rule runs once per group.
+        float bestg[GLOCAL ? TPW : 1];
+        int argg[GLOCAL ? TPW : 1];
+        if constexpr (GLOCAL) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
+        }
         if constexpr (SMETA) {
-            if (k_first <= k_last) m0.issue(srcs4, recs, k_first);  // waited for below
+            // not kept in flight across the staging below: once per group, nothing to hide
+            if (k_first <= k_last) { m0.issue(srcs4, recs, k_first); m0.wait(); }
         } else {
             m0.load(srcs4, recs, min(k_first, k_last), vzero);
         }
@@ -682,14 +729,26 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
     asm volatile("ds_read2st64_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(addr))
 #define BP_PKFMA(acc2, b2, x2) \
     asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc2) : "v"(b2), "v"(x2))
+#define BP_PKFMA_S(acc2, sp2, x2)                                                      \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"        \
+                 : "+v"(acc2) : "s"(sp2), "v"(x2))
+#define BP_RD64(dst, addr, o) \
+    asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
 #define BP_ISSUE(X, OFFS)                                                   \
     {                                                                       \
         const unsigned a0 = lds_lu + (((OFFS) & 0xffffu) << 2);             \
         const unsigned a1 = lds_lu + (((OFFS) >> 16) << 2);                 \
-        BP_RD2(X[0], a0, 0, 1); BP_RD2(X[1], a0, 2, 3);                     \
-        BP_RD2(X[2], a0, 4, 5); BP_RD2(X[3], a0, 6, 7);                     \
-        BP_RD2(X[4], a1, 0, 1); BP_RD2(X[5], a1, 2, 3);                     \
-        BP_RD2(X[6], a1, 4, 5); BP_RD2(X[7], a1, 6, 7);                     \
+        if constexpr (B64) {                                                \
+            BP_RD64(X[0], a0, 0); BP_RD64(X[1], a0, 512);                   \
+            BP_RD64(X[2], a0, 1024); BP_RD64(X[3], a0, 1536);               \
+            BP_RD64(X[4], a1, 0); BP_RD64(X[5], a1, 512);                   \
+            BP_RD64(X[6], a1, 1024); BP_RD64(X[7], a1, 1536);               \
+        } else {                                                            \
+            BP_RD2(X[0], a0, 0, 1); BP_RD2(X[1], a0, 2, 3);                 \
+            BP_RD2(X[2], a0, 4, 5); BP_RD2(X[3], a0, 6, 7);                 \
+            BP_RD2(X[4], a1, 0, 1); BP_RD2(X[5], a1, 2, 3);                 \
+            BP_RD2(X[6], a1, 4, 5); BP_RD2(X[7], a1, 6, 7);                 \
+        }                                                                   \
     }
         // One straight-line body per station count (no control flow between the asm reads and
         // their uses: with phis in between, the compiler copies the destination registers of
@@ -705,8 +764,10 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
             BP_ISSUE(xe, m.offs(0))
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                const float beta = m.beta(st);
-                f32x2 bb; bb[0] = beta; bb[1] = beta;
+                f32x2 bb;
+                i32x2 sp;
+                if constexpr (SPAIR) { sp = m.pair(st); }
+                else { const float beta = m.beta(st); bb[0] = beta; bb[1] = beta; }
                 if (st + 1 < NST) {
                     const unsigned offs_n = m.offs(st + 1);
                     if (st & 1) BP_ISSUE(xe, offs_n) else BP_ISSUE(xo, offs_n)
@@ -718,8 +779,13 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
                 for (int p = 0; p < 2; ++p)      // phase P then phase S, as the oracle
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        if (st & 1) BP_PKFMA(ac[jj], bb, xo[4 * p + jj]);
-                        else BP_PKFMA(ac[jj], bb, xe[4 * p + jj]);
+                        if constexpr (SPAIR) {
+                            if (st & 1) BP_PKFMA_S(ac[jj], sp, xo[4 * p + jj]);
+                            else BP_PKFMA_S(ac[jj], sp, xe[4 * p + jj]);
+                        } else {
+                            if (st & 1) BP_PKFMA(ac[jj], bb, xo[4 * p + jj]);
+                            else BP_PKFMA(ac[jj], bb, xe[4 * p + jj]);
+                        }
                     }
             }
 #pragma unroll
@@ -751,26 +817,38 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
                 hi = (int)(hi64 < 0 ? 0 : (hi64 > TILE ? TILE : hi64));
             }
             if (nsta <= 0) hi = 0;
+            if (GLOCAL && FASTP && lo == 0 && hi == TILE) {  // whole tile inside the bounds (wave-uniform)
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const int x = lane + 64 * j;
-                // bitwise, not short-circuit: keeps the epilogue free of branches
-                const bool computed = (x >= lo) & (x < hi);
-                if (REDUCE == BPMF_BP_REDUCE_MAX) {
-                    const bool take =
-                        computed & ((acc[j] > best[j]) | ((acc[j] == best[j]) & (sid < arg[j])));
-                    best[j] = take ? acc[j] : best[j];
-                    arg[j] = take ? sid : arg[j];
-                } else {
-                    const long long t = t0 + x;
-                    if (live && t < N)
-                        out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                for (int j = 0; j < TPW; ++j) {
+                    const bool take = acc[j] > bestg[j];
+                    bestg[j] = take ? acc[j] : bestg[j];
+                    argg[j] = take ? sid : argg[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) {
+                    const int x = slot_x(j);
+                    // bitwise, not short-circuit: keeps the epilogue free of branches
+                    const bool computed = (x >= lo) & (x < hi);
+                    if (GLOCAL) {
+                        const bool take = computed & (acc[j] > bestg[j]);
+                        bestg[j] = take ? acc[j] : bestg[j];
+                        argg[j] = take ? sid : argg[j];
+                    } else if (REDUCE == BPMF_BP_REDUCE_MAX) {
+                        const bool take =
+                            computed & ((acc[j] > best[j]) | ((acc[j] == best[j]) & (sid < arg[j])));
+                        best[j] = take ? acc[j] : best[j];
+                        arg[j] = take ? sid : arg[j];
+                    } else {
+                        const long long t = t0 + x;
+                        if (live && t < N)
+                            out_beam[(size_t)(sid - id_offset) * (size_t)N + t] = computed ? acc[j] : 0.0f;
+                    }
                 }
             }
-            if constexpr (SMETA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (SMETA) m.wait();
         };
         if constexpr (SMETA) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             for (int k = k_first; k <= k_last; k += WPB) process(m0, true, min(k + WPB, k_last));
         } else {
             for (int k = k_first; k <= k_last; k += 2 * WPB) {
@@ -780,7 +858,17 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
                 process(m1, k + WPB <= k_last, -1);
             }
         }
+        if constexpr (GLOCAL) {
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                const bool take = (bestg[j] > best[j]) | ((bestg[j] == best[j]) & (argg[j] < arg[j]));
+                best[j] = take ? bestg[j] : best[j];
+                arg[j] = take ? argg[j] : arg[j];
+            }
+        }
 #undef BP_RD2
+#undef BP_PKFMA_S
+#undef BP_RD64
 #undef BP_ISSUE
 #undef BP_PKFMA
     }
@@ -790,8 +878,8 @@ __global__ __launch_bounds__(64 * WPB, (WPB * 2 + 3) / 4) void bp_beam_wps2_kern
         int* ma = (int*)(lds + WPB * TILE);     // [WPB][TILE]
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-            mb[wv * TILE + lane + 64 * j] = best[j];
-            ma[wv * TILE + lane + 64 * j] = arg[j];
+            mb[wv * TILE + slot_x(j)] = best[j];
+            ma[wv * TILE + slot_x(j)] = arg[j];
         }
         __syncthreads();
         for (int x = tid; x < TILE; x += NTHREADS) {
@@ -854,6 +942,7 @@ struct bpmf_bp_plan {
     int NT = 4;            // padded number of (station, phase) terms per source
     int n_groups = 0;
     size_t lds_bytes = 0;  // largest group
+    bool dual = false;     // dual (shifted) windows: every term offset is even
     int id_offset = 0;
     double mean_group = 0; // diagnostics
     BpGroup* d_groups = nullptr;
@@ -864,7 +953,6 @@ struct bpmf_bp_plan {
     int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
     int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
     int nsv = 0;                 // > 0: packed per-station records (P == 2), NSV stations padded
-    int wpb = 4;                 // waves per workgroup of the packed kernel (4, 6 or 8)
     int4* d_recs = nullptr;      // [K, nsv/2]
     int4* d_hdr2 = nullptr;      // [K] headers with the station count in .w
     BpTermV* d_termsv = nullptr; // [K, ntv]
@@ -913,10 +1001,17 @@ void bisect_order(const int32_t* mv, size_t SP, std::vector<int>& idx, size_t lo
 // Greedy grouping of consecutive sources (in processing order): a group is closed when the
 // next source would push the LDS need (zero slab + sum over used rows of tile + moveout
 // spread) past the soft budget.  Returns false if one source alone exceeds `hard_floats`.
+// dual: every window is staged twice, the second copy shifted by one sample, both at even
+// offsets; a term whose offset into the window is odd reads the shifted copy, so that ALL emitted
+// offsets are even (8-byte aligned pairs for the ds_read_b64 kernel).
 bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P, int tile,
                 int chunk, size_t soft_floats, const size_t hard_floats, int max_group, bool reorder,
-                int32_t id_offset, PlanHost& ph)
+                int32_t id_offset, bool dual, PlanHost& ph)
 {
+    auto row_cost = [&](int spread) -> size_t {
+        const size_t len = (size_t)tile + (size_t)spread;
+        return dual ? 2 * ((len + 1) & ~(size_t)1) : len;
+    };
     const size_t SP = S * P;
     std::vector<int> order(K);
     for (size_t k = 0; k < K; ++k) order[k] = (int)k;
@@ -924,8 +1019,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
 
     size_t max_terms = 1;
     ph.srcs.resize(K);
-    for (size_t q = 0; q < K; ++q) {
-        const size_t k = (size_t)order[q];
+    auto src_of = [&](size_t k) {
         int n = 0;
         long long lo = 0, hi = 0;
         for (size_t s = 0; s < S; ++s) {
@@ -937,10 +1031,11 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                 ++n;
             }
         }
-        ph.srcs[q] = BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi,
-                              (n + chunk - 1) / chunk * chunk};
         max_terms = std::max(max_terms, (size_t)n);
-    }
+        return BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi,
+                        (n + chunk - 1) / chunk * chunk};
+    };
+    for (size_t q = 0; q < K; ++q) ph.srcs[q] = src_of((size_t)order[q]);
     const int NT = (int)((max_terms + chunk - 1) / chunk * chunk);
     ph.NT = NT;
     // A source's own windows (terms x tile + the zero slab) must leave room for the moveout
@@ -948,8 +1043,8 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     // spread per row (dense station weights), use the whole LDS (one workgroup per CU) instead of
     // degenerating to one source per group.  (Measured on cfg3 geometry, 10 / 15 / 20 used
     // stations: 0.35 / 0.64 / 0.91 s.)
-    const size_t base_need = (max_terms + 1) * (size_t)tile;
-    if (base_need + max_terms * 16 > soft_floats) soft_floats = hard_floats;
+    const size_t base_need = (size_t)tile + max_terms * row_cost(0);
+    if (base_need + max_terms * (row_cost(16) - row_cost(0)) > soft_floats) soft_floats = hard_floats;
     ph.off.assign(K * (size_t)NT, 0);       // padded terms read the zero slab at offset 0
     ph.beta.assign(K * (size_t)NT, 0.0f);
 
@@ -975,9 +1070,9 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                     if (used[r]) {
                         lo = std::min(lo, gmin[r]);
                         hi = std::max(hi, gmax[r]);
-                        need2 += (size_t)((hi - lo) - (gmax[r] - gmin[r]));
+                        need2 += row_cost(hi - lo) - row_cost(gmax[r] - gmin[r]);
                     } else {
-                        need2 += (size_t)tile;
+                        need2 += row_cost(0);
                     }
                     upd.push_back(RowUpdate{r, lo, hi});
                 }
@@ -1005,10 +1100,20 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
             for (int x0 = 0; x0 < len; x0 += BP_THREADS)
                 ph.chunks.push_back(BpChunk{(int)r, gmin[r] + x0, (int)o + x0,
                                             std::min(BP_THREADS, len - x0)});
-            o += (size_t)len;
+            if (dual) {  // the copy shifted by one sample, right behind (both bases even)
+                const int half = (int)(row_cost(gmax[r] - gmin[r]) / 2);
+                for (int x0 = 0; x0 < len - 1; x0 += BP_THREADS)
+                    ph.chunks.push_back(BpChunk{(int)r, gmin[r] + 1 + x0, (int)o + half + x0,
+                                                std::min(BP_THREADS, len - 1 - x0)});
+            }
+            o += row_cost(gmax[r] - gmin[r]);
         }
         g.n_chunk = (int)ph.chunks.size() - g.first_chunk;
         ph.lds_floats = std::max(ph.lds_floats, o);
+        if (dual) {  // ascending ids inside the group (see GLOCAL in bp_beam_wps2_kernel)
+            std::sort(order.begin() + first, order.begin() + q);
+            for (size_t qq = first; qq < q; ++qq) ph.srcs[qq] = src_of((size_t)order[qq]);
+        }
         for (size_t qq = first; qq < q; ++qq) {
             const size_t k = (size_t)order[qq];
             size_t j = 0;
@@ -1016,7 +1121,11 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                 if (ws[k * S + s] == 0.0f) continue;
                 for (size_t p = 0; p < P; ++p, ++j) {
                     const size_t r = s * P + p;
-                    ph.off[qq * NT + j] = base[r] + (mv[(k * S + s) * P + p] - gmin[r]);
+                    const int rel = mv[(k * S + s) * P + p] - gmin[r];
+                    if (dual && (rel & 1))
+                        ph.off[qq * NT + j] = base[r] + (int)(row_cost(gmax[r] - gmin[r]) / 2) + rel - 1;
+                    else
+                        ph.off[qq * NT + j] = base[r] + rel;
                     ph.beta[qq * NT + j] = ws[k * S + s];
                 }
             }
@@ -1067,13 +1176,32 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
 
     PlanHost ph;
     int tpt = 0;
+    // Two-phase grids with at most 16 weighted stations per source run the ds_read_b64 kernel:
+    // dual windows, one 16-wave workgroup per CU with the whole LDS.  When one source's dual
+    // windows do not fit, fall through to the single-window plans.
+    bool dual = false;
+    if (P == 2 && env_int("BPMF_BP_DUAL", 1) && env_int("BPMF_BP_PACKED", 1) &&
+        env_int("BPMF_BP_WPS", 1) && tpt_first == 2) {
+        size_t max_sta = 0;
+        for (size_t k = 0; k < K; ++k) {
+            size_t n = 0;
+            for (size_t s = 0; s < S; ++s) n += w_sources[k * S + s] != 0.0f;
+            max_sta = std::max(max_sta, n);
+        }
+        if (max_sta <= 16 &&
+            build_plan(moveouts, w_sources, K, S, P, BP_THREADS * 2, chunk, hard, hard, max_group,
+                       reorder, source_id_offset, true, ph)) {
+            tpt = 2;
+            dual = true;
+        }
+    }
     const int candidates[3] = {tpt_first, 2, 1};
     for (int c = 0; c < 3 && !tpt; ++c) {
         const int cand = candidates[c];
         if (cand != 1 && cand != 2 && cand != 4) continue;
         ph = PlanHost();
         if (build_plan(moveouts, w_sources, K, S, P, BP_THREADS * cand, chunk, soft, hard,
-                       max_group, reorder, source_id_offset, ph))
+                       max_group, reorder, source_id_offset, false, ph))
             tpt = cand;
     }
     if (!tpt) {
@@ -1096,9 +1224,10 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     pl->lds_bytes = ph.lds_floats * sizeof(float);
     pl->id_offset = source_id_offset;
     pl->mean_group = (double)K / (double)ph.groups.size();
+    pl->dual = dual;
     if (env_int("BPMF_BP_VERBOSE", 0))
-        fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B\n",
-                K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes);
+        fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B dual=%d\n",
+                K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes, (int)dual);
     int rc = 0;
     // fast-path copy of the term table: {byte offset, weight} pairs padded to ntv per source
     const int ntv_opts[4] = {8, 16, 24, 32};
@@ -1120,7 +1249,6 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         const int opts[6] = {4, 8, 12, 16, 24, 32};
         for (int o = 0; o < 6 && !pl->nsv; ++o)
             if (nsta_max <= opts[o]) pl->nsv = opts[o];
-        pl->wpb = 4;  // measured on cfg3: 4 -> 0.351 s, 6 -> 0.491 s, 8 (spills) -> 0.598 s
     }
     if (pl->nsv) {
         std::vector<int4> recs(K * (size_t)(pl->nsv / 2), make_int4(0, 0, 0, 0));
@@ -1285,11 +1413,11 @@ int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob,
     return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
-template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA>
+template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA, bool B64>
 int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                      float* beam, int32_t* arg)
 {
-    auto kern = bp_beam_wps2_kernel<WPB, NSV, OOB, REDUCE, SMETA>;
+    auto kern = bp_beam_wps2_kernel<WPB, NSV, OOB, REDUCE, SMETA, B64>;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * WPB * 512 * sizeof(float));
     if (lds > 64 * 1024)
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
@@ -1305,17 +1433,17 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
     return 0;
 }
 
-template <int WPB, int NSV, bool SMETA>
+template <int WPB, int NSV, bool SMETA, bool B64 = false>
 int dispatch_beam_wps2b(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
                         hipStream_t stream, float* beam, int32_t* arg)
 {
     if (oob == BPMF_BP_STRICT && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX, SMETA>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_MAX, SMETA, B64>(pl, U, N, stream, beam, arg);
     if (oob == BPMF_BP_FLEXIBLE && reduce == BPMF_BP_REDUCE_MAX)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX, SMETA>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_MAX, SMETA, B64>(pl, U, N, stream, beam, arg);
     if (oob == BPMF_BP_STRICT)
-        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE, SMETA>(pl, U, N, stream, beam, arg);
-    return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE, SMETA>(pl, U, N, stream, beam, arg);
+        return launch_beam_wps2<WPB, NSV, BPMF_BP_STRICT, BPMF_BP_REDUCE_NONE, SMETA, B64>(pl, U, N, stream, beam, arg);
+    return launch_beam_wps2<WPB, NSV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE, SMETA, B64>(pl, U, N, stream, beam, arg);
 }
 
 template <int NSV>
@@ -1326,11 +1454,10 @@ int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob
     // ds_read_b32-class gathers need >= 4 waves/SIMD to reach the LDS rate.  Above 16 stations
     // the SGPR set no longer fits and the VGPR-metadata variant (8 waves/CU) runs.
     static const int wpb = env_int("BPMF_BP_WPB", 12);
-    static const int smeta = env_int("BPMF_BP_SMETA", 1);
     if constexpr (NSV <= 16) {
-        if (smeta && wpb == 12) return dispatch_beam_wps2b<12, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
-        if (smeta && wpb == 8) return dispatch_beam_wps2b<8, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
-        if (smeta) return dispatch_beam_wps2b<4, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+        if (pl->dual) return dispatch_beam_wps2b<16, NSV, true, true>(pl, U, N, oob, reduce, stream, beam, arg);
+        if (wpb == 8) return dispatch_beam_wps2b<8, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+        return dispatch_beam_wps2b<12, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
     }
     return dispatch_beam_wps2b<4, NSV, false>(pl, U, N, oob, reduce, stream, beam, arg);
 }

@@ -1,0 +1,65 @@
+"""Static check of the generated gfx950 ISA: the beam kernel issues its LDS gathers and its
+metadata loads from inline asm with hand-counted s_waitcnt, which the compiler cannot see.  No
+instruction may touch a register that such a load still has in flight (tools/check_inflight.py).
+Runs on CPU: hipcc cross-compiles bp.hip to an assembly listing."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_inflight  # noqa: E402
+
+
+def test_checker_flags_copy_of_register_in_flight():
+    listing = """
+k1:
+	ds_read_b64 v[4:5], v2 offset:0
+	ds_read_b64 v[6:7], v2 offset:512
+	s_waitcnt lgkmcnt(1)
+	v_add_f32_e32 v8, v4, v5
+	v_mov_b32_e32 v9, v6
+	s_waitcnt lgkmcnt(0)
+	v_mov_b32_e32 v9, v7
+	s_load_dwordx4 s[8:11], s[0:1], 0x0
+	s_mov_b32 s9, 0
+	s_waitcnt lgkmcnt(0)
+	s_mov_b32 s12, s9
+	s_endpgm
+"""
+    kernels = check_inflight.split_kernels(listing)
+    bad = check_inflight.check_kernel(kernels["k1"])
+    assert [b[1].split()[0] for b in bad] == ["v_mov_b32_e32", "s_mov_b32"]
+    assert bad[0][2] == [6] and bad[1][3] == [9]
+
+
+def test_checker_follows_branches():
+    listing = """
+k2:
+	ds_read_b32 v1, v0
+	s_cbranch_scc1 .LBB0_2
+	s_waitcnt lgkmcnt(0)
+.LBB0_2:
+	v_mov_b32_e32 v2, v1
+	s_endpgm
+"""
+    bad = check_inflight.check_kernel(check_inflight.split_kernels(listing)["k2"])
+    assert len(bad) == 1 and bad[0][2] == [1]
+
+
+@pytest.mark.timeout(900)
+def test_beam_kernels_touch_no_register_in_flight(tmp_path):
+    from seismic_bpmf_amd.build import ARCH, CSRC, find_hipcc
+    out = tmp_path / "bp.s"
+    cmd = [find_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+           "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "bp.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels = check_inflight.split_kernels(out.read_text())
+    names = [n for n in kernels if "bp_beam_wps2_kernel" in n]
+    assert len(names) >= 16
+    for n in names:
+        bad = check_inflight.check_kernel(kernels[n])
+        assert not bad, f"{n}: {bad[:4]}"

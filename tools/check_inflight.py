@@ -1,0 +1,173 @@
+"""Static hazard check of a gfx950 ISA listing (hipcc -S output) for the kernels that issue LDS / SMEM
+loads from inline asm.
+
+The compiler does not know that the destination registers of an inline-asm `ds_read*` / `s_load*`
+are still in flight: it may copy them, or hand a dead part of them out as a temporary, before the
+hand-placed `s_waitcnt`.  This script replays every basic block of a kernel, tracks which registers
+are in flight (exactly inside a block -- LDS returns in order, so `lgkmcnt(n)` retires all but the
+youngest n; conservatively across blocks -- only `lgkmcnt(0)` retires what a predecessor left in
+flight) and reports every instruction that reads or writes such a register.
+
+    python tools/check_inflight.py file.s [kernel-name-regex]
+"""
+import re
+import sys
+
+_V = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+_S = re.compile(r'\bs\[(\d+):(\d+)\]|\bs(\d+)\b')
+_BR = re.compile(r'^(s_cbranch_\w+|s_branch)\s+(\S+)')
+
+
+def _regs(rx, tok):
+    out = set()
+    for m in rx.finditer(tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def split_kernels(text):
+    """{name: [instruction lines]} for every function of the listing."""
+    kernels, name, body = {}, None, []
+    for line in text.splitlines():
+        m = re.match(r'^(_Z\w+|\w+):\s*(;.*)?$', line)
+        if m and not line.startswith('.'):
+            if name is not None:
+                kernels[name] = body
+            name, body = m.group(1), []
+            continue
+        if name is None:
+            continue
+        t = line.split(';')[0].strip()
+        if not t:
+            continue
+        if t.startswith('.') and not t.endswith(':'):
+            if t.startswith('.Lfunc_end'):
+                kernels[name] = body
+                name, body = None, []
+            continue
+        body.append(t)
+        if t.startswith('s_endpgm'):
+            kernels[name] = body
+            name, body = None, []
+    return kernels
+
+
+def _blocks(lines):
+    blocks, cur, label = [], [], '<entry>'
+    for t in lines:
+        if t.endswith(':'):
+            blocks.append((label, cur))
+            label, cur = t[:-1], []
+            continue
+        cur.append(t)
+        if _BR.match(t) or t.startswith('s_endpgm') or t.startswith('s_setpc'):
+            blocks.append((label, cur))
+            label, cur = None, []
+    blocks.append((label, cur))
+    blocks = [(l, b) for l, b in blocks if b or l]
+    index = {l: i for i, (l, _) in enumerate(blocks) if l}
+    succ = []
+    for i, (l, b) in enumerate(blocks):
+        s = set()
+        last = b[-1] if b else ''
+        m = _BR.match(last)
+        if m and m.group(2) in index:
+            s.add(index[m.group(2)])
+        if not (last.startswith('s_branch') or last.startswith('s_endpgm') or last.startswith('s_setpc')):
+            if i + 1 < len(blocks):
+                s.add(i + 1)
+        succ.append(s)
+    return blocks, succ
+
+
+def _run_block(lines, state, report=None):
+    """Replay one block from `state` = (queue, v_un, s_un): `queue` is the in-order list of ops in
+    flight that every predecessor agrees on, v_un / s_un are registers some predecessor may have
+    left in flight in an unknown order (only lgkmcnt(0) retires those).  Returns the end state."""
+    q = [(k, set(d)) for k, d in state[0]]
+    v_un, s_un = set(state[1]), set(state[2])
+    for t in lines:
+        op = t.split()[0]
+        args = t[len(op):]
+        if op == 's_waitcnt':
+            m = re.search(r'lgkmcnt\((\d+)\)', t)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    q, v_un, s_un = [], set(), set()
+                elif not any(k == 'smem' for k, _ in q) and not s_un and not v_un:
+                    while len(q) > n:      # LDS only: in-order return
+                        q.pop(0)
+            continue
+        v_fl = set(v_un).union(*[d for k, d in q if k == 'lds'])
+        s_fl = set(s_un).union(*[d for k, d in q if k == 'smem'])
+        v_t, s_t = _regs(_V, args), _regs(_S, args)
+        hit = (v_t & v_fl, s_t & s_fl)
+        if (hit[0] or hit[1]) and report is not None:
+            report(t, sorted(hit[0]), sorted(hit[1]))
+        if op.startswith('ds_read') or op.startswith('ds_load'):
+            q.append(('lds', _regs(_V, args.split(',')[0])))
+        elif op.startswith('ds_'):
+            q.append(('lds', set()))
+        elif op.startswith('s_load') or op.startswith('s_buffer_load'):
+            q.append(('smem', _regs(_S, args.split(',')[0])))
+    return (tuple((k, frozenset(d)) for k, d in q), frozenset(v_un), frozenset(s_un))
+
+
+def _merge(a, b):
+    if a is None:
+        return b
+    if a[0] == b[0]:
+        return (a[0], a[1] | b[1], a[2] | b[2])
+    v = set(a[1] | b[1]).union(*[d for k, d in a[0] + b[0] if k == 'lds'])
+    s = set(a[2] | b[2]).union(*[d for k, d in a[0] + b[0] if k == 'smem'])
+    return ((), frozenset(v), frozenset(s))
+
+
+def check_kernel(lines):
+    """List of (block, instruction, vgprs, sgprs) violations of one kernel."""
+    blocks, succ = _blocks(lines)
+    n = len(blocks)
+    entry = [None] * n
+    entry[0] = ((), frozenset(), frozenset())
+    work = [0]
+    while work:
+        i = work.pop(0)
+        out = _run_block(blocks[i][1], entry[i])
+        for j in succ[i]:
+            merged = _merge(entry[j], out)
+            if merged != entry[j]:
+                entry[j] = merged
+                if j not in work:
+                    work.append(j)
+    found = []
+    for i in range(n):
+        if entry[i] is None:
+            continue
+        _run_block(blocks[i][1], entry[i],
+                   report=lambda t, v, s, lab=blocks[i][0]: found.append((lab, t, v, s)))
+    return found
+
+
+def main(argv):
+    text = open(argv[1]).read()
+    pat = re.compile(argv[2]) if len(argv) > 2 else None
+    total = 0
+    for name, lines in split_kernels(text).items():
+        if pat and not pat.search(name):
+            continue
+        if not any('ds_read' in t or 's_load' in t for t in lines):
+            continue
+        bad = check_kernel(lines)
+        total += len(bad)
+        for lab, t, v, s in bad[:8]:
+            print(f"{name[:60]} [{lab}]: {t}   <-- in flight: v{v} s{s}")
+    print("violations:", total)
+    return 1 if total else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv))
