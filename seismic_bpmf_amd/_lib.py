@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, "lib", "libbpmf_hip.so")
+# BPMF_HIP_LIB: path of an alternative build of the same library (experiments, ablations)
+LIBPATH = os.environ.get("BPMF_HIP_LIB") or os.path.join(_HERE, "lib", "libbpmf_hip.so")
 
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)

@@ -647,6 +647,8 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     constexpr bool GLOCAL = B64 && REDUCE == BPMF_BP_REDUCE_MAX && !(BP_DBG & 1);
     constexpr bool SPAIR = SMETA && !(BP_DBG & 2);
     constexpr bool FASTP = !(BP_DBG & 4);
+    // timing ablations (results are WRONG with these): 8 no epilogue, 16 no metadata reload, 32 no fma
+    constexpr bool AB_NOEPI = BP_DBG & 8, AB_NOLOAD = BP_DBG & 16, AB_NOFMA = BP_DBG & 32;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -734,60 +736,55 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                  : "+v"(acc2) : "s"(sp2), "v"(x2))
 #define BP_RD64(dst, addr, o) \
     asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
-#define BP_ISSUE(X, OFFS)                                                   \
-    {                                                                       \
-        const unsigned a0 = lds_lu + (((OFFS) & 0xffffu) << 2);             \
-        const unsigned a1 = lds_lu + (((OFFS) >> 16) << 2);                 \
-        if constexpr (B64) {                                                \
-            BP_RD64(X[0], a0, 0); BP_RD64(X[1], a0, 512);                   \
-            BP_RD64(X[2], a0, 1024); BP_RD64(X[3], a0, 1536);               \
-            BP_RD64(X[4], a1, 0); BP_RD64(X[5], a1, 512);                   \
-            BP_RD64(X[6], a1, 1024); BP_RD64(X[7], a1, 1536);               \
-        } else {                                                            \
-            BP_RD2(X[0], a0, 0, 1); BP_RD2(X[1], a0, 2, 3);                 \
-            BP_RD2(X[2], a0, 4, 5); BP_RD2(X[3], a0, 6, 7);                 \
-            BP_RD2(X[4], a1, 0, 1); BP_RD2(X[5], a1, 2, 3);                 \
-            BP_RD2(X[6], a1, 4, 5); BP_RD2(X[7], a1, 6, 7);                 \
-        }                                                                   \
-    }
         // One straight-line body per station count (no control flow between the asm reads and
         // their uses: with phis in between, the compiler copies the destination registers of
         // reads that are still in flight).
         // The fma chain is asm volatile as well: plain fmaf()s are pure and get sunk below the
         // later reads at IR level (every station then needs its own 16 destination VGPRs).
+        // A unit = one phase of one station = 4 reads (8 samples per lane).  Three units are kept in
+        // flight ahead of the one being accumulated (lgkmcnt counts to 15: 12 younger reads may
+        // stay outstanding while the wait retires the oldest 4).
         auto gather = [&](auto nst_c, const Meta& m, float (&acc)[TPW]) {
             constexpr int NST = decltype(nst_c)::value;
-            f32x2 xe[8], xo[8];  // gathers of the even / odd station in flight
+            constexpr int NU = 2 * NST, AH = 3;
+            f32x2 X[4][4];  // ring of 4 units
             f32x2 ac[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { ac[jj][0] = 0.0f; ac[jj][1] = 0.0f; }
-            BP_ISSUE(xe, m.offs(0))
+#define BP_ISSUE_U(u)                                                                          \
+    {                                                                                          \
+        const unsigned o_ = m.offs((u) >> 1);                                                  \
+        const unsigned a_ = lds_lu + ((((u) & 1) ? (o_ >> 16) : (o_ & 0xffffu)) << 2);         \
+        if constexpr (B64) {                                                                   \
+            BP_RD64(X[(u) & 3][0], a_, 0); BP_RD64(X[(u) & 3][1], a_, 512);                    \
+            BP_RD64(X[(u) & 3][2], a_, 1024); BP_RD64(X[(u) & 3][3], a_, 1536);                \
+        } else {                                                                               \
+            BP_RD2(X[(u) & 3][0], a_, 0, 1); BP_RD2(X[(u) & 3][1], a_, 2, 3);                  \
+            BP_RD2(X[(u) & 3][2], a_, 4, 5); BP_RD2(X[(u) & 3][3], a_, 6, 7);                  \
+        }                                                                                      \
+    }
 #pragma unroll
-            for (int st = 0; st < NST; ++st) {
+            for (int u = 0; u < AH; ++u) BP_ISSUE_U(u)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
                 f32x2 bb;
                 i32x2 sp;
-                if constexpr (SPAIR) { sp = m.pair(st); }
-                else { const float beta = m.beta(st); bb[0] = beta; bb[1] = beta; }
-                if (st + 1 < NST) {
-                    const unsigned offs_n = m.offs(st + 1);
-                    if (st & 1) BP_ISSUE(xe, offs_n) else BP_ISSUE(xo, offs_n)
-                    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (SPAIR) { sp = m.pair(u >> 1); }
+                else { const float beta = m.beta(u >> 1); bb[0] = beta; bb[1] = beta; }
+                if (u + AH < NU) BP_ISSUE_U(u + AH)
+                const int left = NU - 1 - u < AH ? NU - 1 - u : AH;  // units that may stay in flight
+                if (left == 3) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                else if (left == 2) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (left == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {  // phase P then phase S of a station, as the oracle
+                    if constexpr (AB_NOFMA) { if (jj == 0 && (u & 7) == 0) BP_PKFMA(ac[0], X[u & 3][1], X[u & 3][2]); asm volatile("" :: "v"(X[u & 3][jj])); }
+                    else if constexpr (SPAIR) BP_PKFMA_S(ac[jj], sp, X[u & 3][jj]);
+                    else BP_PKFMA(ac[jj], bb, X[u & 3][jj]);
                 }
-#pragma unroll
-                for (int p = 0; p < 2; ++p)      // phase P then phase S, as the oracle
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        if constexpr (SPAIR) {
-                            if (st & 1) BP_PKFMA_S(ac[jj], sp, xo[4 * p + jj]);
-                            else BP_PKFMA_S(ac[jj], sp, xe[4 * p + jj]);
-                        } else {
-                            if (st & 1) BP_PKFMA(ac[jj], bb, xo[4 * p + jj]);
-                            else BP_PKFMA(ac[jj], bb, xe[4 * p + jj]);
-                        }
-                    }
             }
+#undef BP_ISSUE_U
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) { acc[2 * jj] = ac[jj][0]; acc[2 * jj + 1] = ac[jj][1]; }
         };
@@ -807,7 +804,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                 default: break;
             }
 #undef BP_CASE
-            if constexpr (SMETA) m.issue(srcs4, recs, k_next);
+            if constexpr (SMETA && !AB_NOLOAD) m.issue(srcs4, recs, k_next);
             // strict bounds as a wave-uniform window [lo, hi) of the tile: 0 <= t + tmin and
             // t + tmax < N with t = t0 + x
             int lo = 0, hi = TILE;
@@ -817,7 +814,9 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                 hi = (int)(hi64 < 0 ? 0 : (hi64 > TILE ? TILE : hi64));
             }
             if (nsta <= 0) hi = 0;
-            if (GLOCAL && FASTP && lo == 0 && hi == TILE) {  // whole tile inside the bounds (wave-uniform)
+            if (AB_NOEPI) {
+                if (acc[0] == 123.456f) best[0] = acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
+            } else if (GLOCAL && FASTP && lo == 0 && hi == TILE) {  // whole tile inside the bounds (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) {
                     const bool take = acc[j] > bestg[j];
@@ -869,7 +868,6 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
 #undef BP_RD2
 #undef BP_PKFMA_S
 #undef BP_RD64
-#undef BP_ISSUE
 #undef BP_PKFMA
     }
     if (REDUCE == BPMF_BP_REDUCE_MAX) {
