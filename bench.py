@@ -307,14 +307,20 @@ def main():
         s_act = float((geo["weights_sources"] != 0).sum(axis=1).mean())
         bk = float(np.mean(bp_ms)) if bp_ms else float("nan")
         gather_tbs = 4.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12
+        pinfo = bf.plan_info()
+        # LDS rate of the gather instruction the plan dispatches to (MI355X_MICROARCH.md, LDS table):
+        # ds_read_b64 256 B/clk/CU on dual windows, 4-byte gathers 128 B/clk/CU
+        lds_peak = LDS_B32_PEAK_TBS * (2.0 if pinfo["gather_bytes"] == 8 else 1.0)
         bp_obj = {"metric": "grid-points x samples / s", "value": world * K_all * Nb * args.steps / bp_dt,
                   "ms_per_step": round(bp_dt / args.steps * 1e3, 3),
                   "config": {"workload": f"BASELINE configs[2]: {K_all} sources x {bcfg['S']} stations x "
                                          f"{bcfg['C']} comp x {bcfg['P']} phases, N={Nb} (1 day @ {bcfg['sr']:g} Hz), "
                                          f"{s_act:.1f} active stations/source, reduce=max, strict"},
-                  "roofline": {"kernel": "bp_beam_kernel", "bound": "lds-gather", "achieved": round(gather_tbs, 2),
-                               "peak": round(LDS_B32_PEAK_TBS, 1), "unit": "TB/s",
-                               "frac": round(gather_tbs / LDS_B32_PEAK_TBS, 4), "avg_launch_ms": round(bk, 3),
+                  "roofline": {"kernel": "bp_beam_wps2_kernel", "bound": "lds-gather", "achieved": round(gather_tbs, 2),
+                               "peak": round(lds_peak, 1), "unit": "TB/s",
+                               "frac": round(gather_tbs / lds_peak, 4),
+                               "frac_of_4byte_gather_rate": round(gather_tbs / LDS_B32_PEAK_TBS, 4),
+                               "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
         bf.close()

@@ -112,6 +112,17 @@ int bpmf_bp_plan_create(const int32_t *moveouts, const float *w_sources, size_t 
                         size_t P, int device, int32_t source_id_offset, bpmf_bp_plan **plan);
 void bpmf_bp_plan_destroy(bpmf_bp_plan *plan);
 
+/* Shape of a plan (diagnostics; bench.py prices the LDS roofline of the gather width in use). */
+typedef struct {
+    int32_t n_groups;      /* groups of sources that share one set of LDS windows */
+    int32_t tile;          /* time samples per workgroup */
+    int32_t lds_bytes;     /* LDS of the largest group */
+    int32_t gather_bytes;  /* 8: dual (shifted) windows + ds_read_b64 gathers; 4: 4-byte gathers */
+    int32_t stations_max;  /* padded station slots per source of the packed kernel (0: generic kernel) */
+    int32_t waves_per_cu;  /* resident waves per CU of the beam kernel this plan dispatches to */
+} bpmf_bp_plan_stats;
+int bpmf_bp_plan_info(const bpmf_bp_plan *plan, bpmf_bp_plan_stats *out);
+
 size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan *plan, size_t N, size_t C);
 
 int bpmf_bp_run_dev(const bpmf_bp_plan *plan, const float *d_features,

@@ -18,6 +18,12 @@ _sz = C.c_size_t
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); must list every symbol of include/bpmf_hip.h
+class BpPlanStats(C.Structure):
+    """bpmf_bp_plan_stats of include/bpmf_hip.h."""
+    _fields_ = [(n, C.c_int32) for n in ("n_groups", "tile", "lds_bytes", "gather_bytes",
+                                         "stations_max", "waves_per_cu")]
+
+
 SIGNATURES = {
     "bpmf_last_error": (C.c_char_p, []),
     "bpmf_device_count": (C.c_int, []),
@@ -33,6 +39,7 @@ SIGNATURES = {
                               C.c_int, _f]),
     "bpmf_bp_plan_create": (C.c_int, [_i, _f, _sz, _sz, _sz, C.c_int, C.c_int32, C.POINTER(_vp)]),
     "bpmf_bp_plan_destroy": (None, [_vp]),
+    "bpmf_bp_plan_info": (C.c_int, [_vp, C.POINTER(BpPlanStats)]),
     "bpmf_bp_workspace_bytes": (_sz, [_vp, _sz, _sz]),
     "bpmf_bp_run_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, C.c_int, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "bpmf_bp_run": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int, C.c_int,

@@ -99,6 +99,12 @@ class BeamformerGPU:
         _lib.check(rc, "bpmf_bp_plan_create")
         self._ws = None
 
+    def plan_info(self):
+        """Shape of the device plan: dict of bpmf_bp_plan_stats (include/bpmf_hip.h)."""
+        st = _lib.BpPlanStats()
+        _lib.check(self.lib.bpmf_bp_plan_info(self._plan, C.byref(st)), "bpmf_bp_plan_info")
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan.value:
             self.lib.bpmf_bp_plan_destroy(self._plan)

@@ -1292,6 +1292,22 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     delete pl;
 }
 
+extern "C" int bpmf_bp_plan_info(const bpmf_bp_plan* pl, bpmf_bp_plan_stats* out)
+{
+    if (!pl || !out) {
+        set_error("bpmf_bp_plan_info: bad argument");
+        return -1;
+    }
+    out->n_groups = pl->n_groups;
+    out->tile = BP_THREADS * pl->tpt;
+    out->lds_bytes = (int32_t)pl->lds_bytes;
+    out->gather_bytes = pl->dual ? 8 : 4;
+    out->stations_max = pl->wps ? pl->nsv : 0;
+    const bool packed = pl->wps && pl->nsv && pl->tpt == 2;
+    out->waves_per_cu = !packed ? 8 : (pl->nsv > 16 ? 8 : (pl->dual ? 16 : 24));
+    return 0;
+}
+
 extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size_t C)
 {
     (void)C;

@@ -126,13 +126,44 @@ def test_bp_term_count_variants(oracle_lib, S, P, density, label):
 
 @pytest.mark.parametrize("env", [{"BPMF_BP_WPS": "0"}, {"BPMF_BP_UVGPR": "0"}, {"BPMF_BP_PACKED": "0"},
                                  {"BPMF_BP_TPT": "1", "BPMF_BP_WPS": "0"}, {"BPMF_BP_TPT": "4", "BPMF_BP_WPS": "0"},
-                                 {"BPMF_BP_REORDER": "0"}, {"BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "5"}])
+                                 {"BPMF_BP_REORDER": "0"}, {"BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "5"},
+                                 {"BPMF_BP_DUAL": "0"}, {"BPMF_BP_DUAL": "0", "BPMF_BP_WPB": "8"},
+                                 {"BPMF_BP_DUAL": "0", "BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "3"}])
 def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(99)
     f, tau, wp, ws = _bp_inputs(rng, 200, 8, 2, 3000, 250, 0.7)
     _bp_check(oracle_lib, f, tau, wp, ws, str(env))
+
+
+@pytest.mark.parametrize("dual,S_used,gather", [("1", 10, 8), ("0", 10, 4), ("1", 16, 8), ("1", 17, 4)])
+def test_bp_plan_info_and_gather_width(oracle_lib, dual, S_used, gather, monkeypatch):
+    """Dual (8-byte gather) plans for <= 16 weighted stations per source, 4-byte gathers otherwise;
+    both must give the oracle's result, ties included (many equal beams: integer-valued features)."""
+    import torch
+    from seismic_bpmf_amd import BeamformerGPU
+    monkeypatch.setenv("BPMF_BP_DUAL", dual)
+    rng = np.random.default_rng(5 + S_used)
+    K, S, P, N = 400, 20, 2, 4000
+    f = rng.integers(0, 3, (S, 3, N)).astype(np.float32)      # exact ties between sources
+    tau = rng.integers(0, 120, (K, S, P)).astype(np.int32)
+    tau[K // 3] = tau[K // 3 + 7]                               # two identical sources
+    wp = np.ones((S, 3, P), np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        ws[k, rng.choice(S, S_used, replace=False)] = 1.0
+    ws[K // 3] = ws[K // 3 + 7]
+    bf = BeamformerGPU(tau, ws)
+    info = bf.plan_info()
+    assert info["gather_bytes"] == gather and info["tile"] == 512 and info["n_groups"] >= 1
+    assert info["waves_per_cu"] == (16 if gather == 8 else (24 if S_used <= 16 else 8))
+    for oob in ("strict", "flexible"):
+        mb, ma = bf.run(torch.as_tensor(f), wp, "max", oob)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        _same(mb.cpu().numpy(), ob, f"dual={dual} S_used={S_used} {oob} maxbeam")
+        assert np.array_equal(ma.cpu().numpy(), oa)
+    bf.close()
 
 
 def test_bp_huge_moveout_spread_falls_back_to_smaller_tiles(oracle_lib):
