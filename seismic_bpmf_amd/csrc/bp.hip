@@ -579,8 +579,9 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 template <int NSV>
 struct BpMetaS {
+    static constexpr int NS = NSV < 16 ? NSV : 16;  // stations held at a time; records have NSV slots
     i32x4 hd;
-    i32x8 r[NSV / 4];   // station s: dword 2 s = offs, 2 s + 1 = weight
+    i32x8 r[NS / 4];    // station s of the part: dword 2 s = offs, 2 s + 1 = weight
     __device__ __forceinline__ void issue(const int4* __restrict__ srcs4,
                                           const int4* __restrict__ recs, int k)
     {
@@ -588,7 +589,17 @@ struct BpMetaS {
         const int4* pr = recs + (size_t)k * (NSV / 2);
         asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(hd) : "s"(ph));
 #pragma unroll
-        for (int i = 0; i < NSV / 4; ++i) {
+        for (int i = 0; i < NS / 4; ++i) {
+            const int4* pi = pr + 2 * i;
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r[i]) : "s"(pi));
+        }
+    }
+    // stations 16 part .. 16 part + 15 of source k (NSV > 16: a source is gathered in parts)
+    __device__ __forceinline__ void issue_part(const int4* __restrict__ recs, int k, int part)
+    {
+        const int4* pr = recs + (size_t)k * (NSV / 2) + 8 * part;
+#pragma unroll
+        for (int i = 0; i < NS / 4; ++i) {
             const int4* pi = pr + 2 * i;
             asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r[i]) : "s"(pi));
         }
@@ -599,12 +610,12 @@ struct BpMetaS {
     // front of the wait.  The sched_barrier keeps later uses behind the wait.
     __device__ __forceinline__ void wait() const
     {
-        static_assert(NSV / 4 >= 1 && NSV / 4 <= 4, "BpMetaS: NSV in {4, 8, 12, 16}");
-        if constexpr (NSV / 4 == 1)
+        static_assert(NSV % 4 == 0 && (NSV <= 16 || NSV % 16 == 0), "BpMetaS: NSV in {4, 8, 12, 16, 32, ...}");
+        if constexpr (NS / 4 == 1)
             asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]) : "memory");
-        else if constexpr (NSV / 4 == 2)
+        else if constexpr (NS / 4 == 2)
             asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]), "s"(r[1]) : "memory");
-        else if constexpr (NSV / 4 == 3)
+        else if constexpr (NS / 4 == 3)
             asm volatile("s_waitcnt lgkmcnt(0)" : : "s"(hd), "s"(r[0]), "s"(r[1]), "s"(r[2]) : "memory");
         else
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -744,13 +755,17 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
         // A unit = one phase of one station = 4 reads (8 samples per lane).  Three units are kept in
         // flight ahead of the one being accumulated (lgkmcnt counts to 15: 12 younger reads may
         // stay outstanding while the wait retires the oldest 4).
-        auto gather = [&](auto nst_c, const Meta& m, float (&acc)[TPW]) {
+        auto gather = [&](auto nst_c, auto first_c, const Meta& m, float (&acc)[TPW]) {
             constexpr int NST = decltype(nst_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value;  // false: continue the sums of acc
             constexpr int NU = 2 * NST, AH = 3;
             f32x2 X[4][4];  // ring of 4 units
             f32x2 ac[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { ac[jj][0] = 0.0f; ac[jj][1] = 0.0f; }
+            for (int jj = 0; jj < 4; ++jj) {
+                ac[jj][0] = FIRST ? 0.0f : acc[2 * jj];
+                ac[jj][1] = FIRST ? 0.0f : acc[2 * jj + 1];
+            }
 #define BP_ISSUE_U(u)                                                                          \
     {                                                                                          \
         const unsigned o_ = m.offs((u) >> 1);                                                  \
@@ -789,20 +804,35 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
             for (int jj = 0; jj < 4; ++jj) { acc[2 * jj] = ac[jj][0]; acc[2 * jj + 1] = ac[jj][1]; }
         };
         // k_next >= 0 (SMETA): refill m with that source once its own gathers are done
-        auto process = [&](Meta& m, bool live, int k_next) {
+        constexpr int NS = SMETA ? (NSV < 16 ? NSV : 16) : NSV;  // stations per gather() call
+        auto process = [&](Meta& m, bool live, int k_cur, int k_next) {
             const int nsta = live ? __builtin_amdgcn_readfirstlane(m.nsta()) : 0;
             const int sid = m.id(), tmin = m.tmin(), tmax = m.tmax();
             float acc[TPW];
 #pragma unroll
             for (int j = 0; j < TPW; ++j) acc[j] = 0.0f;
 #define BP_CASE(n) \
-    case n: if constexpr (2 * n <= NSV) gather(std::integral_constant<int, 2 * n>{}, m, acc); break;
-            switch (nsta >> 1) {  // wave-uniform; station records come in pairs
-                BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) BP_CASE(8)
-                BP_CASE(9) BP_CASE(10) BP_CASE(11) BP_CASE(12) BP_CASE(13) BP_CASE(14) BP_CASE(15)
-                BP_CASE(16)
-                default: break;
+    case n: if constexpr (2 * n <= NS) gather(std::integral_constant<int, 2 * n>{}, first_c, m, acc); break;
+#define BP_SWITCH(npairs)                                                                              \
+    switch (npairs) { /* wave-uniform; station records come in pairs */                               \
+        BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) BP_CASE(8)        \
+        BP_CASE(9) BP_CASE(10) BP_CASE(11) BP_CASE(12) BP_CASE(13) BP_CASE(14) BP_CASE(15) BP_CASE(16) \
+        default: break;                                                                                \
+    }
+            {
+                constexpr std::true_type first_c{};
+                BP_SWITCH((nsta < NS ? nsta : NS) >> 1)
             }
+            if constexpr (SMETA && NSV > NS) {  // more than 16 stations: refill the set, keep summing
+                constexpr std::false_type first_c{};
+                for (int part = 1; part * NS < nsta; ++part) {
+                    m.issue_part(recs, k_cur, part);
+                    m.wait();
+                    const int rest = nsta - part * NS;
+                    BP_SWITCH((rest < NS ? rest : NS) >> 1)
+                }
+            }
+#undef BP_SWITCH
 #undef BP_CASE
             if constexpr (SMETA && !AB_NOLOAD) m.issue(srcs4, recs, k_next);
             // strict bounds as a wave-uniform window [lo, hi) of the tile: 0 <= t + tmin and
@@ -848,13 +878,13 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
             if constexpr (SMETA) m.wait();
         };
         if constexpr (SMETA) {
-            for (int k = k_first; k <= k_last; k += WPB) process(m0, true, min(k + WPB, k_last));
+            for (int k = k_first; k <= k_last; k += WPB) process(m0, true, k, min(k + WPB, k_last));
         } else {
             for (int k = k_first; k <= k_last; k += 2 * WPB) {
                 m1.load(srcs4, recs, min(k + WPB, k_last), vzero);
-                process(m0, true, -1);
+                process(m0, true, k, -1);
                 m0.load(srcs4, recs, min(k + 2 * WPB, k_last), vzero);
-                process(m1, k + WPB <= k_last, -1);
+                process(m1, k + WPB <= k_last, k + WPB, -1);
             }
         }
         if constexpr (GLOCAL) {
@@ -1042,7 +1072,9 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     // degenerating to one source per group.  (Measured on cfg3 geometry, 10 / 15 / 20 used
     // stations: 0.35 / 0.64 / 0.91 s.)
     const size_t base_need = (size_t)tile + max_terms * row_cost(0);
-    if (base_need + max_terms * (row_cost(16) - row_cost(0)) > soft_floats) soft_floats = hard_floats;
+    // More than 16 stations (P = 2: 32 terms): the packed kernel runs one 16-wave workgroup per CU.
+    if (base_need + max_terms * (row_cost(16) - row_cost(0)) > soft_floats || (P == 2 && max_terms > 32))
+        soft_floats = hard_floats;
     ph.off.assign(K * (size_t)NT, 0);       // padded terms read the zero slab at offset 0
     ph.beta.assign(K * (size_t)NT, 0.0f);
 
@@ -1244,8 +1276,8 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     // packed per-station records for the two-phase fast kernel
     if (P == 2 && ph.NT <= 64 && env_int("BPMF_BP_PACKED", 1)) {
         const int nsta_max = ph.NT / 2;   // NT is a multiple of 4
-        const int opts[6] = {4, 8, 12, 16, 24, 32};
-        for (int o = 0; o < 6 && !pl->nsv; ++o)
+        const int opts[5] = {4, 8, 12, 16, 32};
+        for (int o = 0; o < 5 && !pl->nsv; ++o)
             if (nsta_max <= opts[o]) pl->nsv = opts[o];
     }
     if (pl->nsv) {
@@ -1304,7 +1336,7 @@ extern "C" int bpmf_bp_plan_info(const bpmf_bp_plan* pl, bpmf_bp_plan_stats* out
     out->gather_bytes = pl->dual ? 8 : 4;
     out->stations_max = pl->wps ? pl->nsv : 0;
     const bool packed = pl->wps && pl->nsv && pl->tpt == 2;
-    out->waves_per_cu = !packed ? 8 : (pl->nsv > 16 ? 8 : (pl->dual ? 16 : 24));
+    out->waves_per_cu = !packed ? 8 : (pl->nsv > 16 ? 16 : (pl->dual ? 16 : 24));
     return 0;
 }
 
@@ -1473,6 +1505,10 @@ int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob
         if (wpb == 8) return dispatch_beam_wps2b<8, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
         return dispatch_beam_wps2b<12, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
     }
+    static const int smeta = env_int("BPMF_BP_SMETA", 1);
+    if constexpr (NSV % 16 == 0) {
+        if (smeta) return dispatch_beam_wps2b<16, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
+    }
     return dispatch_beam_wps2b<4, NSV, false>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
@@ -1486,7 +1522,6 @@ int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int
             case 8: return dispatch_beam_wps2<8>(pl, U, N, oob, reduce, stream, beam, arg);
             case 12: return dispatch_beam_wps2<12>(pl, U, N, oob, reduce, stream, beam, arg);
             case 16: return dispatch_beam_wps2<16>(pl, U, N, oob, reduce, stream, beam, arg);
-            case 24: return dispatch_beam_wps2<24>(pl, U, N, oob, reduce, stream, beam, arg);
             case 32: return dispatch_beam_wps2<32>(pl, U, N, oob, reduce, stream, beam, arg);
             default: break;
         }

@@ -137,15 +137,18 @@ def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
     _bp_check(oracle_lib, f, tau, wp, ws, str(env))
 
 
-@pytest.mark.parametrize("dual,S_used,gather", [("1", 10, 8), ("0", 10, 4), ("1", 16, 8), ("1", 17, 4)])
-def test_bp_plan_info_and_gather_width(oracle_lib, dual, S_used, gather, monkeypatch):
+@pytest.mark.parametrize("dual,S,S_used,gather,waves", [("1", 20, 10, 8, 16), ("0", 20, 10, 4, 24), ("1", 20, 16, 8, 16),
+                                                        ("1", 20, 17, 4, 16), ("1", 20, 20, 4, 16),
+                                                        ("1", 34, 31, 4, 16), ("1", 34, 32, 4, 16),
+                                                        ("1", 34, 33, 4, 8)])
+def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, waves, monkeypatch):
     """Dual (8-byte gather) plans for <= 16 weighted stations per source, 4-byte gathers otherwise;
     both must give the oracle's result, ties included (many equal beams: integer-valued features)."""
     import torch
     from seismic_bpmf_amd import BeamformerGPU
     monkeypatch.setenv("BPMF_BP_DUAL", dual)
     rng = np.random.default_rng(5 + S_used)
-    K, S, P, N = 400, 20, 2, 4000
+    K, P, N = 400, 2, 4000
     f = rng.integers(0, 3, (S, 3, N)).astype(np.float32)      # exact ties between sources
     tau = rng.integers(0, 120, (K, S, P)).astype(np.int32)
     tau[K // 3] = tau[K // 3 + 7]                               # two identical sources
@@ -157,7 +160,7 @@ def test_bp_plan_info_and_gather_width(oracle_lib, dual, S_used, gather, monkeyp
     bf = BeamformerGPU(tau, ws)
     info = bf.plan_info()
     assert info["gather_bytes"] == gather and info["tile"] == 512 and info["n_groups"] >= 1
-    assert info["waves_per_cu"] == (16 if gather == 8 else (24 if S_used <= 16 else 8))
+    assert info["waves_per_cu"] == waves
     for oob in ("strict", "flexible"):
         mb, ma = bf.run(torch.as_tensor(f), wp, "max", oob)
         ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
