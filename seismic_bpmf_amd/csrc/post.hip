@@ -19,6 +19,36 @@ constexpr int GAUSSIAN_LEN = 500;
 // dword-aligned 16-byte load: rows and windows start at arbitrary sample offsets
 typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
 
+// Stream one window through f(value, index) in strictly ascending order.  The adds of a window
+// form one dependent chain, so the only parallelism inside a thread is in the LOADS: a batch is
+// 8 x 16 B = one 128-byte line per lane, and the next batch is in flight while the current one is
+// accumulated (without this the chain waits for a memory round trip every 4 samples).
+template <typename F>
+__device__ __forceinline__ void tdt_stream(const float* __restrict__ p, size_t window, F f)
+{
+    constexpr int NB = 8;
+    const size_t nbatch = window / (4 * NB);
+    f32x4a cur[NB], nxt[NB];
+    if (nbatch) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cur[i] = *(const f32x4a*)(p + 4 * i);
+    }
+    for (size_t b = 0; b < nbatch; ++b) {
+        const float* pn = p + (b + 1) * (4 * NB);
+        if (b + 1 < nbatch) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) nxt[i] = *(const f32x4a*)(pn + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f(cur[i][e], b * (4 * NB) + 4 * i + e);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cur[i] = nxt[i];
+    }
+    for (size_t j = nbatch * (4 * NB); j < window; ++j) f(p[j], j);
+}
+
 // (1) per (row, global window): sum and count of the non-zero samples.       libc.c:553-571
 __global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, size_t n,
                                     size_t window, size_t n_glob, float* __restrict__ part,
@@ -30,17 +60,9 @@ __global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, 
     const float* p = x + row * n + q * window;
     float acc = 0.0f;
     unsigned long long c = 0;
-    size_t j = 0;
-    for (; j + 4 <= window; j += 4) {  // 16-byte loads, strictly sequential adds
-        const f32x4a v4 = *(const f32x4a*)(p + j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (v4[e] != 0.0f) { acc += v4[e]; ++c; }
-    }
-    for (; j < window; ++j) {
-        float v = p[j];
+    tdt_stream(p, window, [&](float v, size_t) {  // strictly sequential adds
         if (v != 0.0f) { acc += v; ++c; }
-    }
+    });
     part[idx] = acc;
     cnt[idx] = c;
 }
@@ -72,23 +94,12 @@ __global__ void tdt_glob_dev_kernel(const float* __restrict__ x, const float* __
     const float* p = x + row * n + q * window;
     const float c = centre[row];
     float acc = 0.0f;
-    size_t j = 0;
-    for (; j + 4 <= window; j += 4) {
-        const f32x4a v4 = *(const f32x4a*)(p + j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (v4[e] != 0.0f) {
-                double d = (double)(v4[e] - c);
-                acc = (float)((double)acc + d * d);
-            }
-    }
-    for (; j < window; ++j) {
-        float v = p[j];
+    tdt_stream(p, window, [&](float v, size_t) {
         if (v != 0.0f) {
             double d = (double)(v - c);
             acc = (float)((double)acc + d * d);
         }
-    }
+    });
     part[idx] = acc;
 }
 
@@ -119,39 +130,18 @@ __global__ void tdt_window_kernel(const float* __restrict__ x, const float* __re
     const float* p = x + row * n + i0;
     const float c = centre[row], dv = dev[row];
     float acc = 0.0f;
-    size_t j = 0;
-    for (; j + 4 <= window; j += 4) {
-        const f32x4a v4 = *(const f32x4a*)(p + j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = v4[e];
-            if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j + e) % GAUSSIAN_LEN], dv, c);
-            acc += v;
-        }
-    }
-    for (; j < window; ++j) {
-        float v = p[j];
-        if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
+    unsigned g0 = (unsigned)(i0 % GAUSSIAN_LEN);  // gauss index of sample j: (g0 + j) mod 500
+    tdt_stream(p, window, [&](float v, size_t j) {
+        if (v == 0.0f) v = __fmaf_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv, c);
         acc += v;
-    }
+    });
     const float mean = acc / (float)window;
     float ss = 0.0f;
-    for (j = 0; j + 4 <= window; j += 4) {
-        const f32x4a v4 = *(const f32x4a*)(p + j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = v4[e];
-            if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j + e) % GAUSSIAN_LEN], dv, c);
-            double d = (double)(v - mean);
-            ss = (float)((double)ss + d * d);
-        }
-    }
-    for (; j < window; ++j) {
-        float v = p[j];
-        if (v == 0.0f) v = __fmaf_rn(gauss[(i0 + j) % GAUSSIAN_LEN], dv, c);
+    tdt_stream(p, window, [&](float v, size_t j) {
+        if (v == 0.0f) v = __fmaf_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv, c);
         double d = (double)(v - mean);
         ss = (float)((double)ss + d * d);
-    }
+    });
     thr_win[idx] = __fmaf_rn(num_dev, sqrtf(ss / (float)window), mean);
 }
 
