@@ -83,29 +83,60 @@ def backprojection_detections(features, moveouts, weights_phases, weights_source
     return peaks, peak_sources, maxbeam, sources
 
 
+def numpy_order_sum(x):
+    """Sum over the last axis of a torch tensor in the order of numpy's float32 pairwise
+    `np.sum` (n < 8: running sum; n <= 128: eight strided partial sums combined as a tree, then
+    the tail; larger: split in halves of multiples of 8) -- element-wise adds only, so the
+    result is bit-identical to `np.sum(a, axis=(-1, -2))` of the reference
+    (dataset.py:4828-4830) whatever the device."""
+    n = x.shape[-1]
+    if n < 8:
+        res = x.new_zeros(x.shape[:-1])
+        for i in range(n):
+            res = res + x[..., i]
+        return res
+    if n <= 128:
+        r = [x[..., j] for j in range(8)]
+        m = n - (n % 8)
+        for i in range(8, m, 8):
+            r = [r[j] + x[..., i + j] for j in range(8)]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(m, n):
+            res = res + x[..., i]
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return numpy_order_sum(x[..., :n2]) + numpy_order_sum(x[..., n2:])
+
+
 def intertemplate_cc(waveforms_arr, weights, max_lag=10, device=None):
     """Pair-wise template similarity: intertp[t, u] = sum_{s,c} w[t][u,s,c] * max_lag CC.
 
-    waveforms_arr (T,S,C,L); weights (T, T, S, C) -- row t holds the channel weights the
-    reference builds for template t against every other template (dataset.py:4789-4816).
-    For each t the template's own waveform is the "data" and every template trimmed by max_lag
-    on both sides is correlated against it at 2*max_lag+1 lags (network_sum=False)."""
+    waveforms_arr (T,S,C,L); weights (T, T, S, C), or a callable t -> (T, S, C) -- row t holds the
+    channel weights the reference builds for template t against every other template
+    (dataset.py:4789-4816).  For each t the template's own waveform is the "data" and every
+    template trimmed by max_lag on both sides is correlated against it at 2*max_lag+1 lags
+    (network_sum=False, dataset.py:4818-4827).  Everything stays on the device -- the CCs, their
+    max over the lags and the weighted channel sum (in numpy's summation order) -- and only the
+    (T, T) matrix comes back."""
     import torch
     wf = np.ascontiguousarray(waveforms_arr, dtype=np.float32)
-    T = wf.shape[0]
-    trimmed = np.ascontiguousarray(wf[..., max_lag:-max_lag])
-    mv0 = np.zeros(wf.shape[:-1], dtype=np.int32)
+    T, S, Cc = wf.shape[:3]
     mf = MatchedFilterGPU(device=device)
-    tp_dev = mf._dev(trimmed, torch.float32)
-    out = np.zeros((T, T), dtype=np.float32)
+    wf_dev = mf._dev(wf, torch.float32)
+    tp_dev = wf_dev[..., max_lag:wf.shape[-1] - max_lag].contiguous()
+    mv0 = torch.zeros((T, S, Cc), dtype=torch.int32, device=wf_dev.device)
+    out_dev = torch.zeros((T, T), dtype=torch.float32, device=wf_dev.device)
     for t in range(T):
-        w = np.asarray(weights[t], dtype=np.float32)
+        w = np.asarray(weights(t) if callable(weights) else weights[t], dtype=np.float32)
         keep = np.flatnonzero((w != 0).reshape(T, -1).sum(axis=1) > 0)
         if keep.size == 0:
             continue
-        mf.set_data(wf[t])
-        cc = mf.run(tp_dev[torch.as_tensor(keep, device=tp_dev.device)], mv0[keep], w[keep], 1,
-                    network_sum=False)                       # (n_keep, 2*max_lag+1, S, C)
-        best = cc.max(dim=1).values.cpu().numpy()
-        out[t, keep] = np.sum(w[keep] * best, axis=(-1, -2))
+        keep_dev = torch.as_tensor(keep, device=wf_dev.device)
+        w_dev = mf._dev(w[keep], torch.float32)
+        mf.set_data(wf_dev[t])
+        cc = mf.run(tp_dev[keep_dev], mv0[keep_dev], w_dev, 1, network_sum=False)  # (n_keep, 2*max_lag+1, S, C)
+        best = cc.max(dim=1).values
+        out_dev[t, keep_dev] = numpy_order_sum((w_dev * best).reshape(keep.size, S * Cc))
+    out = out_dev.cpu().numpy()
     return (out + out.T) / 2.0

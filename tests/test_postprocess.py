@@ -118,3 +118,16 @@ def test_candidate_merge_equals_reference_selection_on_the_full_series():
         assert np.array_equal(got, want)
     mv = np.array([[0, 40, 40], [10, 90, 90], [5, 25, 25]])
     assert search_window(mv, 100, 1) == 100 and search_window(mv, 10, 2) == 20.5
+
+
+def test_numpy_order_sum_matches_numpy_bit_for_bit():
+    """workflow.numpy_order_sum (element-wise torch adds) == np.sum over the last two axes of a
+    contiguous float32 array, the reduction of dataset.py:4828-4830."""
+    import torch
+    from seismic_bpmf_amd.workflow import numpy_order_sum
+    rng = np.random.default_rng(11)
+    for S, C in [(1, 1), (2, 3), (3, 2), (4, 3), (8, 1), (20, 3), (40, 3), (43, 3), (50, 3), (100, 3), (200, 3)]:
+        x = (rng.standard_normal((37, S, C)) * rng.random((37, S, C)) * 10.0 ** rng.integers(-3, 4, (37, S, C))).astype(np.float32)
+        want = np.sum(x, axis=(-1, -2))
+        got = numpy_order_sum(torch.as_tensor(x).reshape(37, S * C)).numpy()
+        assert np.array_equal(got, want), (S, C)
