@@ -138,11 +138,54 @@ def cpu_baseline(cfg, target_seconds):
     oracle.matched_filter(smp["templates"], smp["moveouts"], smp["weights"], smp["data"], 1, lib=lib)
     dt = time.perf_counter() - t0
     value = T * (n - L + 1) / dt / 1e6
+    # one thread beside all threads, on the small probe: the kernel is linear in N
+    t0 = time.perf_counter()
+    oracle.matched_filter(probe["templates"][:2], probe["moveouts"][:2], probe["weights"][:2],
+                          probe["data"], 1, num_threads=1, lib=lib)
+    dt1 = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except Exception:
+        pass
     return {"value": round(value, 4), "unit": "million network-CC-samples/s", "cores": cores,
             "kind": "port",
+            "value_1_thread": round(2 * (60_000 - L + 1) / dt1 / 1e6, 5), "cpu_model": model,
             "sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n} samples of the "
                       f"{cfg['N']}-sample day, step 1; oracle/bpmf_oracle.c mf_cpu (C99+OpenMP, "
-                      f"gcc -O3 -march={march}), {dt:.1f} s wall"}
+                      f"gcc -O3 -march={march}), {dt:.1f} s wall; 1-thread figure on 2 templates x "
+                      f"60000 samples, {dt1:.1f} s"}
+
+
+def cpu_baseline_bp(bcfg, geo, target_seconds):
+    """The CPU oracle's beamformer on a bounded sample of the BP workload (all host threads)."""
+    from oracle import oracle
+    from seismic_bpmf_amd import synthetic as syn
+    try:
+        lib = oracle.load(oracle.build(march="native", out_dir="/tmp/bpmf_oracle_native"))
+    except Exception:
+        lib = oracle.load()
+    cores = os.cpu_count() or 1   # explicit: the 1-thread MF figure left OpenMP at one thread
+    S, C, P = bcfg["S"], bcfg["C"], bcfg["P"]
+    K = min(geo["moveouts"].shape[0], 2000)
+    mv, ws = geo["moveouts"][:K], geo["weights_sources"][:K]
+    wp = syn.phase_weights(S, C, P)
+    rng = np.random.default_rng(3)
+    n = 100_000
+    feat = np.abs(rng.standard_normal((S, C, n))).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.beamform(feat, mv, wp, ws, "strict", "max", num_threads=cores, lib=lib)
+    dt = time.perf_counter() - t0
+    n = int(min(bcfg["N"], max(n, n / dt * target_seconds)))
+    n -= n % 1000
+    feat = np.abs(rng.standard_normal((S, C, n))).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.beamform(feat, mv, wp, ws, "strict", "max", num_threads=cores, lib=lib)
+    dt = time.perf_counter() - t0
+    return {"value": K * n / dt, "unit": "grid-points x samples / s", "cores": cores, "kind": "port",
+            "sample": f"first {K} sources of the grid x N={n} samples, 10 closest stations, strict, "
+                      f"reduce=max; oracle/bpmf_oracle.c bp_cpu, {dt:.1f} s wall"}
 
 
 # ------------------------------------------------------- detection stage (untimed extra) ---
@@ -324,6 +367,8 @@ def main():
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
         bf.close()
+        if rank == 0 and world == 1 and not args.skip_cpu:
+            bp_obj["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
 
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
