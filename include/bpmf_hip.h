@@ -180,6 +180,19 @@ int bpmf_extract_candidates_dev(const float *d_series, const float *d_thr_window
                                 bpmf_stream_t stream, uint32_t *d_count,
                                 bpmf_candidate *d_records);
 
+/* ------------------------------------------------------ peak suppression (host) --- */
+/*
+ * The height-ordered suppression loop of BPMF/utils.py:2334-2345 (`_detect_peaks`, mpd > 1), which
+ * the reference runs as an O(peaks^2) NumPy loop: peaks are visited from the tallest down and a
+ * kept peak removes every other peak within +-mpd samples.  Same visiting order (the caller passes
+ * the reference's own argsort), same result, O(peaks) time.  Host arrays.
+ *   positions (n) i64 ascending sample indices of the candidate peaks
+ *   order     (n) i64: order[q] = index into `positions` of the q-th peak to visit
+ *   keep      (n) u8 out, indexed like `positions` (1 = survives)
+ */
+int bpmf_suppress_peaks(const int64_t *positions, const int64_t *order, size_t n, double mpd,
+                        uint8_t *keep);
+
 /* ------------------------------------------------------------ grid decimation --- */
 /*
  * Device version of BPMF.clib.find_similar_sources (BPMF/clib.py:104-221), i.e. of

@@ -109,3 +109,29 @@ extern "C" int bpmf_device_info(int device, char* name, size_t name_len, size_t*
     if (compute_units) *compute_units = prop.multiProcessorCount;
     return 0;
 }
+
+// ------------------------------------------------------------- peak suppression (host) ---
+// BPMF/utils.py:2334-2345: for every peak, tallest first, unless already removed:
+//   idel = idel | (ind >= ind[i] - mpd) & (ind <= ind[i] + mpd); idel[i] = 0
+// `positions` is ascending, so the peaks within +-mpd of one are its neighbours in the array.
+extern "C" int bpmf_suppress_peaks(const int64_t* positions, const int64_t* order, size_t n,
+                                   double mpd, uint8_t* keep)
+{
+    if ((!positions || !order || !keep) && n) {
+        bpmf::set_error("bpmf_suppress_peaks: bad argument");
+        return -1;
+    }
+    for (size_t i = 0; i < n; ++i) keep[i] = 1;
+    for (size_t q = 0; q < n; ++q) {
+        const int64_t i = order[q];
+        if (i < 0 || (size_t)i >= n) {
+            bpmf::set_error("bpmf_suppress_peaks: order[%zu] = %lld out of range", q, (long long)i);
+            return -1;
+        }
+        if (!keep[i]) continue;
+        const double lo = (double)positions[i] - mpd, hi = (double)positions[i] + mpd;
+        for (int64_t j = i - 1; j >= 0 && (double)positions[j] >= lo; --j) keep[j] = 0;
+        for (size_t j = (size_t)i + 1; j < n && (double)positions[j] <= hi; ++j) keep[j] = 0;
+    }
+    return 0;
+}

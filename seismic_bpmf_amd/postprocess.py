@@ -91,16 +91,47 @@ def detect_peaks(x, mpd=1):
     if ind.size and ind[-1] == x.size - 1:
         ind = ind[:-1]
     if ind.size and mpd > 1:
-        order = ind[np.argsort(x[ind])][::-1]     # tallest first (ties: same order as argsort)
-        dropped = np.zeros(order.size, dtype=bool)
-        for q in range(order.size):
-            if dropped[q]:
-                continue
-            near = (order >= order[q] - mpd) & (order <= order[q] + mpd)
-            dropped |= near
-            dropped[q] = False
-        ind = np.sort(order[~dropped])
+        rank = np.argsort(x[ind])[::-1]           # tallest first (ties: same order as argsort)
+        ind = ind[_suppress(ind, rank, mpd)]
     return ind
+
+
+def _suppress(ind, rank, mpd):
+    """Mask of the peaks `ind` (ascending) that survive the tallest-first +-mpd suppression of
+    BPMF/utils.py:2334-2345, visited in the order `rank` (indices into `ind`).  The reference's
+    loop is O(peaks^2) in NumPy -- hours for a day of beam; the library's host routine walks the
+    neighbours of each kept peak instead (same order, same result)."""
+    ind = np.ascontiguousarray(ind, dtype=np.int64)
+    rank = np.ascontiguousarray(rank, dtype=np.int64)
+    try:
+        from . import _lib
+        lib = _lib.lib()
+    except Exception:
+        lib = None
+    if lib is None:                               # library not built: the reference's own loop
+        return _suppress_reference_loop(ind, rank, mpd)
+    keep = np.empty(ind.size, dtype=np.uint8)
+    import ctypes as C
+    rc = lib.bpmf_suppress_peaks(ind.ctypes.data_as(C.POINTER(C.c_int64)),
+                                 rank.ctypes.data_as(C.POINTER(C.c_int64)), ind.size, float(mpd),
+                                 keep.ctypes.data_as(C.POINTER(C.c_uint8)))
+    _lib.check(rc, "bpmf_suppress_peaks")
+    return keep.astype(bool)
+
+
+def _suppress_reference_loop(ind, rank, mpd):
+    """Line-by-line restatement of BPMF/utils.py:2334-2345 (used to pin `_suppress`)."""
+    order = ind[rank]
+    dropped = np.zeros(order.size, dtype=bool)
+    for q in range(order.size):
+        if dropped[q]:
+            continue
+        near = (order >= order[q] - mpd) & (order <= order[q] + mpd)
+        dropped |= near
+        dropped[q] = False
+    keep = np.zeros(ind.size, dtype=bool)
+    keep[rank[~dropped]] = True
+    return keep
 
 
 def find_beam_detections(maxbeam, maxbeam_sources, threshold, mpd):

@@ -131,3 +131,22 @@ def test_numpy_order_sum_matches_numpy_bit_for_bit():
         want = np.sum(x, axis=(-1, -2))
         got = numpy_order_sum(torch.as_tensor(x).reshape(37, S * C)).numpy()
         assert np.array_equal(got, want), (S, C)
+
+
+def test_fast_peak_suppression_equals_the_reference_loop():
+    """bpmf_suppress_peaks (host routine of the library) against the restated NumPy loop of
+    BPMF/utils.py:2334-2345, ties and fractional mpd included."""
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(21)
+    for trial in range(30):
+        n = int(rng.integers(50, 4000))
+        x = rng.integers(0, 12, n).astype(np.float64) if trial % 3 == 0 else rng.standard_normal(n)
+        mpd = [2, 3, 7.5, 25, 100, 2.0001][trial % 6]
+        dx = np.diff(x)
+        ind = np.flatnonzero((np.append(dx, 0.0) <= 0) & (np.insert(dx, 0, 0.0) > 0))
+        ind = ind[(ind > 0) & (ind < n - 1)]
+        rank = np.argsort(x[ind])[::-1]
+        want = pp._suppress_reference_loop(ind.astype(np.int64), rank.astype(np.int64), mpd)
+        got = pp._suppress(ind, rank, mpd)
+        assert np.array_equal(got, want), (trial, n, mpd)
+        assert np.array_equal(pp.detect_peaks(x, mpd=mpd), ind[want])
