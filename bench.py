@@ -100,14 +100,44 @@ def bp_inputs(cfg, device, seed, rank, world):
     bump = torch.as_tensor(8.0 * np.exp(-0.5 * (np.arange(-half, half + 1) / sig) ** 2),
                            dtype=torch.float32, device=device)
     tau = geo["moveouts"]
+    planted = []
     for _ in range(20):
         k0 = int(rng.integers(0, tau.shape[0]))
         t0 = int(rng.integers(half, N - int(tau.max()) - 2 * half))
+        planted.append((k0, t0))
         for s in range(S):
             for c in range(C):
                 x = t0 + int(tau[k0, s, 0 if c == 0 else 1])
                 feat[s, c, x - half:x + half + 1] += bump
+    geo["planted"] = planted
     return geo, feat, wp
+
+
+def bp_detection_stage(beam, arg, geo, bcfg):
+    """What follows the beamformer in BPMF (template_search.py:574-627), untimed: sliding
+    median/MAD threshold, peaks at least 5 s apart, snap + unique, source of each peak -- on the
+    full day, with the host mirror of the reference's Python.  Every planted event must come out
+    within the half-width of its bump, located at the planted source or one with an equal beam."""
+    from seismic_bpmf_amd import postprocess as pp
+    t0 = time.perf_counter()
+    maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
+    t1 = time.perf_counter()
+    window = int(pp.sec_to_samp(1800.0, bcfg["sr"]))
+    thr = pp.bp_time_dependent_threshold(maxbeam, window, 15.0, overlap=0.75)
+    t2 = time.perf_counter()
+    mpd = int(pp.sec_to_samp(5.0, bcfg["sr"]))
+    peaks, peak_sources = pp.find_beam_detections(maxbeam, sources, thr, mpd)
+    t3 = time.perf_counter()
+    found = same_source = 0
+    for k0, ts in geo["planted"]:
+        hit = np.flatnonzero(np.abs(peaks - ts) <= 5)
+        if hit.size:
+            found += 1
+            same_source += int(peak_sources[hit[0]] == k0)
+    return {"d2h_ms": round((t1 - t0) * 1e3, 1), "threshold_ms": round((t2 - t1) * 1e3, 1),
+            "peaks_ms": round((t3 - t2) * 1e3, 1), "detections": int(peaks.size),
+            "planted": len(geo["planted"]), "planted_found_within_5_samples": found,
+            "planted_located_at_planted_source": same_source}
 
 
 # ----------------------------------------------------------------------- CPU baseline ---
@@ -366,6 +396,8 @@ def main():
                                "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+        if rank == 0:
+            bp_obj["detection"] = bp_detection_stage(beam, arg, geo, bcfg)
         bf.close()
         if rank == 0 and world == 1 and not args.skip_cpu:
             bp_obj["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
