@@ -384,6 +384,13 @@ def main():
         # LDS rate of the gather instruction the plan dispatches to (MI355X_MICROARCH.md, LDS table):
         # ds_read_b64 256 B/clk/CU on dual windows, 4-byte gathers 128 B/clk/CU
         lds_peak = LDS_B32_PEAK_TBS * (2.0 if pinfo["gather_bytes"] == 8 else 1.0)
+        bp_traffic = None
+        bp_pmc = os.path.join(ROOT, "profiles", "bp_beam_pmc.json")
+        if os.path.exists(bp_pmc) and args.bp_config == "cfg3":
+            try:  # separate rocprofv3 --pmc passes over this same launch (tools/pmc_bp_traffic.sh)
+                bp_traffic = json.load(open(bp_pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                bp_traffic = None
         bp_obj = {"metric": "grid-points x samples / s", "value": world * K_all * Nb * args.steps / bp_dt,
                   "ms_per_step": round(bp_dt / args.steps * 1e3, 3),
                   "config": {"workload": f"BASELINE configs[2]: {K_all} sources x {bcfg['S']} stations x "
@@ -393,7 +400,7 @@ def main():
                                "peak": round(lds_peak, 1), "unit": "TB/s",
                                "frac": round(gather_tbs / lds_peak, 4),
                                "frac_of_4byte_gather_rate": round(gather_tbs / LDS_B32_PEAK_TBS, 4),
-                               "plan": pinfo, "avg_launch_ms": round(bk, 3),
+                               "traffic": bp_traffic, "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
         if rank == 0:

@@ -665,7 +665,12 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = tid >> 8;        // staging sub-group of 256 threads
     const int stid = tid & 255;
-    const long long t0 = (long long)blockIdx.x * TILE;
+    // Consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each): give every XCD a
+    // contiguous run of tiles, so that each L2 stages its own eighth of the prestack instead of
+    // all of it.  (The grid is rounded up to a multiple of 8; tiles past N see only zero fill.)
+    const long long tiles_per_xcd = (gridDim.x + 7) >> 3;
+    const long long t0 = ((long long)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)) * TILE;
+    if (t0 >= N) return;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     const char* lds_l = (const char*)lds + lane * (B64 ? 8 : 4);
@@ -1469,7 +1474,7 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    dim3 grid((unsigned)((N + 511) / 512));
+    dim3 grid((unsigned)(((N + 511) / 512 + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
     profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
                                                 (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,

@@ -183,6 +183,28 @@ __host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L
 
 // MAXR / MAXT: per-thread staging registers for the data window / the Toeplitz band
 // (window <= 256 * MAXR floats, band <= 256 * MAXT floats).
+// Workgroup -> (template, lag block).  The hardware deals consecutive workgroup ids round-robin
+// to the 8 XCDs, each with its own L2.  With the plain order (template fastest) every XCD walks
+// ALL lag blocks and streams the whole day of data and norms from HBM itself (8 x 4 GB at cfg2,
+// plus what the ~60 resident workgroups per XCD re-fetch as they drift apart).  XCD-aware order:
+// XCD x owns the contiguous lag blocks [x * per_xcd, (x + 1) * per_xcd); inside an XCD the template
+// index is fastest, so the workgroups in flight on one L2 share one or two lag blocks' windows.
+// The grid is 8 * per_xcd * T workgroups; the ones past the last lag block exit at once.
+__device__ __forceinline__ bool mf_tile_of_block(unsigned bid, int T, int n_lag_blocks, int xcd_map,
+                                                 int& t, long long& lag_block)
+{
+    if (!xcd_map) {
+        t = (int)(bid % (unsigned)T);
+        lag_block = bid / (unsigned)T;
+        return true;
+    }
+    const unsigned xcd = bid & 7u, i = bid >> 3;
+    const int per_xcd = (n_lag_blocks + 7) >> 3;
+    t = (int)(i % (unsigned)T);
+    lag_block = (long long)xcd * per_xcd + (long long)(i / (unsigned)T);
+    return lag_block < n_lag_blocks;
+}
+
 template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
@@ -205,12 +227,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     // Workgroup order: templates in batches of t_batch; inside a batch the template index is
     // fastest, then the lag block: the workgroups in flight share a few lag blocks' data
     // windows (L2) while touching at most t_batch rows of the output at a time.
-    const long long per_batch = (long long)t_batch * n_lag_blocks;
-    const int batch = (int)(blockIdx.x / per_batch);
-    const int rem = (int)(blockIdx.x - batch * per_batch);
-    const int tb = min(t_batch, T - batch * t_batch);
-    const int t = batch * t_batch + rem % tb;
-    const long long lag0 = (long long)(rem / tb) * MF_LAGS_PER_WG;
+    int t;
+    long long lag0;
+    if (t_batch >= T) {  // default: XCD-aware order (mf_tile_of_block)
+        long long lag_block;
+        if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
+        lag0 = lag_block * MF_LAGS_PER_WG;
+    } else {
+        const long long per_batch = (long long)t_batch * n_lag_blocks;
+        const int batch = (int)(blockIdx.x / per_batch);
+        const int rem = (int)(blockIdx.x - batch * per_batch);
+        if (batch * t_batch >= T) return;
+        const int tb = min(t_batch, T - batch * t_batch);
+        t = batch * t_batch + rem % tb;
+        lag0 = (long long)(rem / tb) * MF_LAGS_PER_WG;
+    }
     // `range` holds CC indices; the kernel works on data-sample offsets (lag = index * step) and
     // simply skips the offsets that are not multiples of step
     const int2 rgi = range[t];
@@ -444,12 +475,13 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const int a = lane & 15;
     const int kq = lane >> 4;
 
-    const int t = blockIdx.x % T;
-    const long long lag0 = (long long)(blockIdx.x / T) * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
+    int t;
+    long long lag_block;
+    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
+    const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rgi = range[t];
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
-    (void)n_lag_blocks;
 
     f32x4 sum[4];
 #pragma unroll
@@ -810,9 +842,10 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const char* mse = getenv("BPMF_MF_MAX_MFMA_STEP");
     const size_t max_mfma_step = mse ? (size_t)atoi(mse) : 64;  // beyond this the direct kernel wins
     const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
-                          need_t <= 9 && T * n_lag_blocks < 0x7fffffffull;
+                          need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull;
     if (use_mfma) {
-        dim3 grid((unsigned)(T * n_lag_blocks));
+        // 8 XCDs x ceil(n_lag_blocks / 8) lag blocks x T templates (mf_tile_of_block)
+        dim3 grid((unsigned)(T * 8 * ((n_lag_blocks + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
         const char* abl = getenv("BPMF_MF_ABLATE");  // kernel-phase ablation, profiling only
         const int ablate = abl ? atoi(abl) : 0;
