@@ -253,6 +253,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     const bool wg_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WG - 1 < rg.x);
+    const bool wg_inside = lag0 >= rg.x && lag0 + MF_LAGS_PER_WG - 1 <= rg.y;  // no range tests needed
     // result (tile u, register r) of this lane is lag  lag_w + 256 u + r
     const long long lag_w = lag0 + (long long)wv * MF_LAGS_PER_WAVE + 16 * a + 4 * kq;
 
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                 // the epilogue (`ok`).
                 if (ablate & 8) {
                     ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (lag + 3 >= rg.x && lag <= rg.y) {
+                } else if (wg_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
                     ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -405,6 +406,18 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 #undef MF_REQ
 #undef MF_STEP
 
+            if (NETWORK_SUM && STEP1 && wg_inside && !(ablate & 1)) {
+                // every lag of this workgroup is inside the template's valid range: no range tests
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float nrm = et * ed[u][r];  // r_t * r_d
+                        const float cc = nrm < MAX_NORM ? acc[u][r] * nrm : 0.0f;
+                        sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -422,6 +435,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                     }
                     if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                 }
+            }
             }
             rec = rec1;
             rec1 = rec2;
@@ -488,6 +502,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     const bool wave_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WAVE - 1 < rg.x);
+    const bool wave_inside = lag0 >= rg.x && lag0 + MF_LAGS_PER_WAVE - 1 <= rg.y;
     const long long lag_w = lag0 + 16 * a + 4 * kq;
 
     if (wave_valid) {
@@ -513,11 +528,20 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                       rs_t, (lane + 64 * r - 15) * 4, 0, 0));
         };
+        const bool full_window = Ww == 64 * MAXR;  // L = 241..257: every staging register is used
         auto write_stage = [&]() {
+            if (full_window) {
 #pragma unroll
-            for (int r = 0; r < MAXR; ++r) {
-                const int x = lane + 64 * r;
-                if (x < Ww) dw[x + 2 * (x >> 4)] = rd[r];
+                for (int r = 0; r < MAXR; ++r) {
+                    const int x = lane + 64 * r;
+                    dw[x + 2 * (x >> 4)] = rd[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int x = lane + 64 * r;
+                    if (x < Ww) dw[x + 2 * (x >> 4)] = rd[r];
+                }
             }
 #pragma unroll
             for (int r = 0; r < MAXT; ++r) {
@@ -548,7 +572,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 // the epilogue (`ok`).
                 if (ablate & 8) {
                     ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (lag + 3 >= rg.x && lag <= rg.y) {
+                } else if (wave_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
                     ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -618,6 +642,19 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #undef MF_REQ
 #undef MF_STEP
 
+            if (NETWORK_SUM && STEP1 && wave_inside && !(ablate & 1)) {
+                // every lag of this wave is inside the template's valid range (wave-uniform, all
+                // but the first and last tiles of a day): no per-lag range tests
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float nrm = et * ed[u][r];  // r_t * r_d
+                        const float cc = nrm < MAX_NORM ? acc[u][r] * nrm : 0.0f;
+                        sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -635,6 +672,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                     }
                     if (NETWORK_SUM) sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                 }
+            }
             }
             rec = rec1;
             rec1 = rec2;

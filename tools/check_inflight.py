@@ -48,10 +48,9 @@ def split_kernels(text):
                 kernels[name] = body
                 name, body = None, []
             continue
-        body.append(t)
-        if t.startswith('s_endpgm'):
-            kernels[name] = body
-            name, body = None, []
+        body.append(t)   # a kernel may hold several s_endpgm (early exits): .Lfunc_end closes it
+    if name is not None:
+        kernels[name] = body
     return kernels
 
 
