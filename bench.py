@@ -164,10 +164,24 @@ def cpu_baseline(cfg, target_seconds):
     n = int(min(cfg["N"], max(120_000, rate * target_seconds / T)))
     n -= n % 1000
     smp = syn.make_mf_inputs(T, S, C, L, n, seed=8, n_events=0)
-    t0 = time.perf_counter()
-    oracle.matched_filter(smp["templates"], smp["moveouts"], smp["weights"], smp["data"], 1, lib=lib)
-    dt = time.perf_counter() - t0
-    value = T * (n - L + 1) / dt / 1e6
+    # all hardware threads, and one per physical core when SMT is on (FMA-bound code usually
+    # prefers the latter); the better of the two is the baseline
+    trials = [cores]
+    try:
+        if open("/sys/devices/system/cpu/smt/active").read().strip() == "1" and cores >= 4:
+            trials.append(cores // 2)
+    except Exception:
+        pass
+    value, dt, used = 0.0, 0.0, cores
+    for nth in trials:
+        t0 = time.perf_counter()
+        oracle.matched_filter(smp["templates"], smp["moveouts"], smp["weights"], smp["data"], 1,
+                              num_threads=nth, lib=lib)
+        d = time.perf_counter() - t0
+        v = T * (n - L + 1) / d / 1e6
+        if v > value:
+            value, dt, used = v, d, nth
+    cores = used
     # one thread beside all threads, on the small probe: the kernel is linear in N
     t0 = time.perf_counter()
     oracle.matched_filter(probe["templates"][:2], probe["moveouts"][:2], probe["weights"][:2],
