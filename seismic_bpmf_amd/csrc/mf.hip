@@ -11,6 +11,11 @@
 // evaluated with the exact-fp32 v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain; the band's
 // zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
+#include <thread>
+#include <chrono>
+#include <vector>
+#include <cstring>
+#include <algorithm>
 #include "../../include/bpmf_hip.h"
 
 #include <cstdlib>
@@ -945,6 +950,32 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     return 0;
 }
 
+// Host-pointer call: the CC matrix (17 GB at cfg2) does not have to exist on the device, and its
+// way back to pageable host memory (16 GB/s through the runtime's own staging, measured) would
+// cost as much as computing it.  Templates run in batches of ~1 GB of output on one stream; a
+// second stream drains the previous batch in 64 MB pieces into two pinned buffers, from which a
+// few host threads copy into the caller's array while the next piece is in flight: the call takes
+// about max(compute, transfer) instead of their sum.
+namespace {
+void parallel_copy(char* dst, const char* src, size_t bytes)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
+    if (bytes < (8u << 20) || nth == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (bytes / nth + 4095) & ~(size_t)4095;
+    for (size_t i = 0; i < nth; ++i) {
+        const size_t o = i * per;
+        if (o >= bytes) break;
+        th.emplace_back([=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); });
+    }
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
 extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, const float* weights,
                            const float* data, size_t step, size_t L, size_t N, size_t T, size_t S,
                            size_t C, size_t n_corr, int network_sum, int flags, int device,
@@ -957,33 +988,99 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     if (int rc = mf_check_sizes(step, L, N, T, S, C, n_corr)) return rc;
     BPMF_HIP_CHECK(hipSetDevice(device));
     const size_t n_ch = S * C;
+    const size_t row_bytes = n_corr * (network_sum ? 1 : n_ch) * sizeof(float);   // per template
+    size_t TB = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(row_bytes, 1));
+    TB = std::min(T, std::max<size_t>(TB, std::min<size_t>(T, 8)));
+    const size_t n_batch = (T + TB - 1) / TB;
+    const size_t PIECE = (size_t)64 << 20;
     const size_t b_tp = T * n_ch * L * sizeof(float), b_mv = T * n_ch * sizeof(int32_t),
                  b_w = T * n_ch * sizeof(float), b_d = n_ch * N * sizeof(float),
-                 b_out = T * n_corr * (network_sum ? 1 : n_ch) * sizeof(float),
-                 b_ws = bpmf_mf_workspace_bytes(L, N, T, S, C);
+                 b_out = TB * row_bytes, b_ws = bpmf_mf_workspace_bytes(L, N, TB, S, C);
     char* base = nullptr;
+    char* pinned[2] = {nullptr, nullptr};
+    hipStream_t s_run = nullptr, s_copy = nullptr;
+    hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_piece[2] = {nullptr, nullptr};
     size_t o_tp = 0, o_mv = o_tp + align_up(b_tp, 256), o_w = o_mv + align_up(b_mv, 256),
-           o_d = o_w + align_up(b_w, 256), o_out = o_d + align_up(b_d, 256),
-           o_ws = o_out + align_up(b_out, 256), total = o_ws + b_ws;
-    BPMF_HIP_CHECK(hipMalloc((void**)&base, total));
+           o_d = o_w + align_up(b_w, 256), o_out0 = o_d + align_up(b_d, 256),
+           o_out1 = o_out0 + align_up(b_out, 256),
+           o_ws = o_out1 + (n_batch > 1 ? align_up(b_out, 256) : 0), total = o_ws + b_ws;
     int rc = 0;
-    hipStream_t stream = nullptr;
     auto fail = [&](hipError_t e, const char* what) {
-        set_error("bpmf_mf_run: %s failed: %s", what, hipGetErrorString(e));
+        if (!rc) set_error("bpmf_mf_run: %s failed: %s", what, hipGetErrorString(e));
         rc = -2;
     };
-    hipError_t e;
-    if ((e = hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D templates");
-    if (!rc && (e = hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D moveouts");
-    if (!rc && (e = hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights");
-    if (!rc && (e = hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D data");
+#define MF_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) fail(e_, what); } while (0)
+    MF_TRY(hipMalloc((void**)&base, total), "hipMalloc");
+    if (!rc) MF_TRY(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), "stream");
+    if (!rc) MF_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking), "stream");
+    for (int i = 0; i < 2 && !rc; ++i) {
+        MF_TRY(hipHostMalloc((void**)&pinned[i], PIECE, hipHostMallocDefault), "hipHostMalloc");
+        if (!rc) MF_TRY(hipEventCreateWithFlags(&ev_batch[i], hipEventDisableTiming), "event");
+        if (!rc) MF_TRY(hipEventCreateWithFlags(&ev_piece[i], hipEventDisableTiming), "event");
+    }
+    if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
+    if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
+    if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
+    if (!rc) MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
     if (!rc)
-        rc = bpmf_mf_run_dev((const float*)(base + o_tp), (const int32_t*)(base + o_mv),
-                             (const float*)(base + o_w), (const float*)(base + o_d), step, L, N, T,
-                             S, C, n_corr, network_sum, flags & ~BPMF_MF_DATA_PREPARED,
-                             base + o_ws, b_ws, stream, (float*)(base + o_out));
-    if (!rc && (e = hipMemcpyAsync(cc_out, base + o_out, b_out, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H cc");
-    if (!rc && (e = hipStreamSynchronize(stream)) != hipSuccess) fail(e, "synchronize");
+        rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
+    auto launch = [&](size_t b) {
+        const size_t t0 = b * TB, nt = std::min(TB, T - t0);
+        char* d_out = base + ((b & 1) ? o_out1 : o_out0);
+        int r = bpmf_mf_run_dev((const float*)(base + o_tp) + t0 * n_ch * L,
+                                (const int32_t*)(base + o_mv) + t0 * n_ch,
+                                (const float*)(base + o_w) + t0 * n_ch, (const float*)(base + o_d),
+                                step, L, N, nt, S, C, n_corr, network_sum,
+                                (flags & ~BPMF_MF_DATA_PREPARED) | BPMF_MF_DATA_PREPARED,
+                                base + o_ws, b_ws, s_run, (float*)d_out);
+        if (!r) MF_TRY(hipEventRecord(ev_batch[b & 1], s_run), "event record");
+        return r;
+    };
+    const bool verbose = getenv("BPMF_MF_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    double t_wait = 0.0, t_copy = 0.0;
+    if (!rc) rc = launch(0);
+    for (size_t b = 0; b < n_batch && !rc; ++b) {
+        if (b + 1 < n_batch) rc = launch(b + 1);   // its buffer was drained one iteration ago
+        if (rc) break;
+        const size_t t0 = b * TB, nt = std::min(TB, T - t0), bytes = nt * row_bytes;
+        const char* d_out = base + ((b & 1) ? o_out1 : o_out0);
+        char* h_out = (char*)cc_out + t0 * row_bytes;
+        MF_TRY(hipStreamWaitEvent(s_copy, ev_batch[b & 1], 0), "wait event");
+        const size_t n_piece = (bytes + PIECE - 1) / PIECE;
+        auto enqueue = [&](size_t q) {
+            const size_t o = q * PIECE, len = std::min(PIECE, bytes - o);
+            MF_TRY(hipMemcpyAsync(pinned[q & 1], d_out + o, len, hipMemcpyDeviceToHost, s_copy), "D2H cc");
+            MF_TRY(hipEventRecord(ev_piece[q & 1], s_copy), "event record");
+        };
+        if (!rc && n_piece) enqueue(0);
+        for (size_t q = 0; q < n_piece && !rc; ++q) {
+            const double t0w = now();
+            MF_TRY(hipEventSynchronize(ev_piece[q & 1]), "event sync");
+            const double t1w = now();
+            if (q + 1 < n_piece && !rc) enqueue(q + 1);   // into the other pinned buffer
+            if (!rc) {
+                const size_t o = q * PIECE, len = std::min(PIECE, bytes - o);
+                parallel_copy(h_out + o, pinned[q & 1], len);
+            }
+            t_wait += t1w - t0w;
+            t_copy += now() - t1w;
+        }
+    }
+    if (s_run) (void)hipStreamSynchronize(s_run);
+    if (s_copy) (void)hipStreamSynchronize(s_copy);
+    if (verbose)
+        fprintf(stderr, "[bpmf] mf_run: %zu batches of %zu templates, %.3f s after setup: waiting for the "
+                        "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
+#undef MF_TRY
+    for (int i = 0; i < 2; ++i) {
+        if (ev_batch[i]) (void)hipEventDestroy(ev_batch[i]);
+        if (ev_piece[i]) (void)hipEventDestroy(ev_piece[i]);
+        if (pinned[i]) (void)hipHostFree(pinned[i]);
+    }
+    if (s_run) (void)hipStreamDestroy(s_run);
+    if (s_copy) (void)hipStreamDestroy(s_copy);
     (void)hipFree(base);
     return rc;
 }
