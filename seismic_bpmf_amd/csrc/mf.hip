@@ -989,10 +989,16 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     BPMF_HIP_CHECK(hipSetDevice(device));
     const size_t n_ch = S * C;
     const size_t row_bytes = n_corr * (network_sum ? 1 : n_ch) * sizeof(float);   // per template
-    size_t TB = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(row_bytes, 1));
-    TB = std::min(T, std::max<size_t>(TB, std::min<size_t>(T, 8)));
+    // BPMF_MF_HOST_BATCH_KB / BPMF_MF_HOST_PIECE_KB: sizes of a batch's output and of a pinned piece
+    // (defaults 1 GB / 64 MB; the tests shrink them to cross every batch and piece boundary)
+    const char* e_b = getenv("BPMF_MF_HOST_BATCH_KB");
+    const char* e_p = getenv("BPMF_MF_HOST_PIECE_KB");
+    const size_t batch_bytes = e_b && atoll(e_b) > 0 ? (size_t)atoll(e_b) << 10 : (size_t)1 << 30;
+    const size_t PIECE = e_p && atoll(e_p) > 0 ? (size_t)atoll(e_p) << 10 : (size_t)64 << 20;
+    size_t TB = std::max<size_t>(1, batch_bytes / std::max<size_t>(row_bytes, 1));
+    if (!e_b) TB = std::max<size_t>(TB, 8);   // a launch of fewer templates wastes the device
+    TB = std::min(T, TB);
     const size_t n_batch = (T + TB - 1) / TB;
-    const size_t PIECE = (size_t)64 << 20;
     const size_t b_tp = T * n_ch * L * sizeof(float), b_mv = T * n_ch * sizeof(int32_t),
                  b_w = T * n_ch * sizeof(float), b_d = n_ch * N * sizeof(float),
                  b_out = TB * row_bytes, b_ws = bpmf_mf_workspace_bytes(L, N, TB, S, C);

@@ -204,3 +204,23 @@ def test_device_resident_api_matches_host_api():
     p = bf.pack_max(x, k)
     assert p[1] > p[0] and p[2] > p[1] and p[0] > p[3]
     bf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_kb,piece_kb", [(64, 16), (200, 1000), (1, 1), (10_000, 7)])
+@pytest.mark.parametrize("network_sum", [True, False])
+def test_mf_host_api_batches_and_pieces(oracle_lib, batch_kb, piece_kb, network_sum, monkeypatch):
+    """bpmf_mf_run pipelines template batches and pinned pieces; shrink both so that a small case
+    crosses every boundary (last batch / last piece shorter, one template per batch, ...)."""
+    from seismic_bpmf_amd import matched_filter
+    monkeypatch.setenv("BPMF_MF_HOST_BATCH_KB", str(batch_kb))
+    monkeypatch.setenv("BPMF_MF_HOST_PIECE_KB", str(piece_kb))
+    rng = np.random.default_rng(batch_kb + piece_kb)
+    T, S, C, L, N = 7, 3, 2, 40, 9000 if network_sum else 2500
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    data = rng.standard_normal((S, C, N)).astype(np.float32)
+    mv = rng.integers(0, 60, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    got = matched_filter(tp, mv, w, data, 1, arch="gpu", network_sum=network_sum, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, data, 1, network_sum=network_sum)
+    _assert_same(got, want, f"host API batch {batch_kb} KB piece {piece_kb} KB")
