@@ -211,6 +211,24 @@ def main():
     thr = template_search.time_dependent_threshold(mb, 3000, overlap=0.75, CNR_threshold=15.0)
     np.savez_compressed(os.path.join(HERE, "bp_threshold.npz"), maxbeam=mb, window=3000, overlap=0.75,
                         n_dev=15.0, thr=np.asarray(thr))
+    # ---- template_search.saturated_envelopes (feature extraction in front of the beamformer) ----
+    # envelope_parallel is the same map over channels through a ProcessPoolExecutor; run serially
+    template_search.envelope_parallel = lambda tr: np.float32(
+        [template_search.envelope(x_) for x_ in tr.reshape(-1, tr.shape[-1])]).reshape(tr.shape)
+    env = {}
+    for j, n in enumerate((20_000, 14_999)):
+        tr = rng.standard_normal((3, 2, n)).astype(np.float32)
+        tr[0, 0] *= 1.0e-3
+        tr[0, 1, 5000:5200] = 0.0                 # a gap: the envelope is not zero there
+        tr[1, 0] = 0.0                            # dead channel -> dropped
+        tr[1, 1] *= 1.0e-13                       # MAD below the anomaly threshold -> dropped
+        tr[2, 0, 7000] = 3.0e6                    # spike -> saturates at max_dynamic_range
+        tr[2, 1] = np.cumsum(tr[2, 1]) * 0.01     # red noise
+        feat, avail = template_search.saturated_envelopes(tr.copy())
+        env.update({f"traces_{j}": tr, f"features_{j}": np.asarray(feat, dtype=np.float32),
+                    f"availability_{j}": np.asarray(avail, dtype=np.int32),
+                    f"envelope_{j}": np.float32([template_search.envelope(x_) for x_ in tr.reshape(-1, n)]).reshape(tr.shape)})
+    np.savez_compressed(os.path.join(HERE, "saturated_envelopes.npz"), n_cases=2, **env)
     print("goldens written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):

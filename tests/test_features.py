@@ -1,0 +1,92 @@
+"""Saturated envelopes (BPMF/template_search.py:1525-1617): the host restatement is pinned bit for
+bit to the reference's own output; the device version is compared with it on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "saturated_envelopes.npz")
+
+
+def test_host_restatement_equals_the_reference():
+    from seismic_bpmf_amd.features import envelope_host, saturated_envelopes_host
+    g = np.load(GOLD)
+    for j in range(int(g["n_cases"])):
+        tr = g[f"traces_{j}"]
+        env = np.float32([envelope_host(x) for x in tr.reshape(-1, tr.shape[-1])]).reshape(tr.shape)
+        assert np.array_equal(env, g[f"envelope_{j}"])
+        feat, avail = saturated_envelopes_host(tr.copy())
+        assert feat.dtype == np.float32 and np.array_equal(feat, g[f"features_{j}"])
+        assert np.array_equal(avail, g[f"availability_{j}"])
+        assert feat.max() == g[f"features_{j}"].max()
+        if j == 0:
+            assert feat.max() == np.float32(1.0e5)         # the spike saturates
+        assert not feat[1].any() and avail[1] == 0         # dead / anomalous channels dropped
+
+
+def test_device_path_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from seismic_bpmf_amd import _lib
+    from seismic_bpmf_amd.features import saturated_envelopes
+    with pytest.raises(_lib.BpmfHipError):
+        saturated_envelopes(np.zeros((1, 1, 16), np.float32))
+
+
+def _envelope_f64(tr):
+    from scipy.signal import hilbert
+    return np.abs(hilbert(tr.astype(np.float64), axis=-1))
+
+
+def test_reference_fft_is_single_precision():
+    """scipy.fft keeps the input precision, so the reference's hilbert(float32 trace) is a float32
+    FFT: its envelopes carry round-off of a few float32 ulp OF THE CHANNEL'S LARGEST VALUE
+    everywhere (a 3e6 spike puts +-0.5 on every sample).  This bounds how closely any other
+    implementation can agree with the golden file, and is the tolerance of the device test."""
+    g = np.load(GOLD)
+    for j in range(int(g["n_cases"])):
+        tr, gold = g[f"traces_{j}"], g[f"envelope_{j}"]
+        exact = _envelope_f64(tr)
+        ulp_max = np.spacing(np.abs(gold).max(axis=-1, keepdims=True).astype(np.float32))
+        err = np.abs(gold - exact) / ulp_max
+        assert err.max() <= 16.0
+        assert err.max() > 1.0          # not a correctly rounded float64 result
+
+
+@pytest.mark.gpu
+def test_device_envelopes_against_float64_and_the_reference_output():
+    """Tight: the device envelope (float64 hipFFT, cast to float32) equals the float64 SciPy
+    envelope rounded to float32 to within 1 ulp.  Loose: against the reference's float32-FFT
+    output the bound is the reference's own round-off, 16 ulp of the channel's largest envelope
+    value (see test_reference_fft_is_single_precision); the standardised features inherit it
+    divided by the channel's MAD.  Availability and the dropped channels match exactly."""
+    from scipy.stats import median_abs_deviation as scimad
+    from seismic_bpmf_amd.features import envelope, saturated_envelopes
+    g = np.load(GOLD)
+    for j in range(int(g["n_cases"])):
+        tr = g[f"traces_{j}"]
+        env = envelope(tr).cpu().numpy()
+        exact = _envelope_f64(tr)
+        assert np.all(np.abs(env - exact) <= np.spacing(np.float32(exact)) * 1.0001 + 1e-300), j
+        gold_env = g[f"envelope_{j}"]
+        ulp_max = np.spacing(np.abs(gold_env).max(axis=-1, keepdims=True).astype(np.float32))
+        assert np.all(np.abs(env.astype(np.float64) - gold_env) <= 16 * ulp_max), j
+        feat, avail = saturated_envelopes(tr)
+        feat = feat.cpu().numpy()
+        gold = g[f"features_{j}"]
+        assert np.array_equal(avail, g[f"availability_{j}"])
+        assert np.array_equal((feat != 0).any(axis=-1), (gold != 0).any(axis=-1))   # dropped channels
+        for s in range(tr.shape[0]):
+            for c in range(tr.shape[1]):
+                if not gold[s, c].any():
+                    continue
+                mad = scimad(gold_env[s, c][gold_env[s, c] != 0])
+                noise = 40 * ulp_max[s, c, 0] / mad      # the reference's FFT round-off in MAD units
+                # where that noise is large (the channel with the 3e6 spike: +-3 MAD on every
+                # sample) it also moves the reference's own median and MAD by a few per cent
+                rel = 1e-5 if noise < 1e-3 else 5e-2
+                bound = noise + rel * np.abs(gold[s, c])
+                assert np.all(np.abs(feat[s, c].astype(np.float64) - gold[s, c]) <= bound), (j, s, c)
+        if j == 0:
+            assert feat.max() == np.float32(1.0e5)
