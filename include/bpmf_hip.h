@@ -180,6 +180,16 @@ int bpmf_extract_candidates_dev(const float *d_series, const float *d_thr_window
                                 bpmf_stream_t stream, uint32_t *d_count,
                                 bpmf_candidate *d_records);
 
+/* ------------------------------------------------------------ running kurtosis --- */
+/*
+ * Device version of BPMF.clib.kurtosis (BPMF/clib.py:86-102 -> BPMF/libc.c:11-53): kurto[ch][n],
+ * n >= W, is the kurtosis of the W samples before n; written only where the window variance
+ * exceeds 1e-6 -- zero-initialise d_kurto like the reference wrapper does.
+ *   d_signal, d_kurto (n_channels, length) f32, n_channels = stations x components
+ */
+int bpmf_kurtosis_dev(const float *d_signal, int W, size_t n_channels, size_t length,
+                      bpmf_stream_t stream, float *d_kurto);
+
 /* ------------------------------------------------------ peak suppression (host) --- */
 /*
  * The height-ordered suppression loop of BPMF/utils.py:2334-2345 (`_detect_peaks`, mpd > 1), which

@@ -38,6 +38,7 @@ SIGNATURES = {
     "bpmf_mf_run": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int,
                               C.c_int, _f]),
     "bpmf_bp_plan_create": (C.c_int, [_i, _f, _sz, _sz, _sz, C.c_int, C.c_int32, C.POINTER(_vp)]),
+    "bpmf_kurtosis_dev": (C.c_int, [_vp, C.c_int, _sz, _sz, _vp, _vp]),
     "bpmf_suppress_peaks": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), _sz, C.c_double,
                                       C.POINTER(C.c_uint8)]),
     "bpmf_bp_plan_destroy": (None, [_vp]),

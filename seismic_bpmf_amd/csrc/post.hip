@@ -321,3 +321,63 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
     BPMF_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------ running kurtosis ---
+// BPMF/libc.c:11-53 (kurtosis; wrapper BPMF/clib.py:86-102), conventions of
+// oracle/adjacent_oracle.c:kurtosis_cpu: kurto[n] (n >= W) from the W samples before n, mean as a
+// sequential float sum, 2nd and 4th moments as float accumulators of double squares, written only
+// where the variance exceeds 1e-6 (other samples keep the caller's zeros).  One thread per output
+// sample; a workgroup stages its 256 + W input samples in LDS once.
+namespace bpmf {
+__global__ __launch_bounds__(256) void kurtosis_kernel(const float* __restrict__ x, int W,
+                                                       long long length, float* __restrict__ k)
+{
+    extern __shared__ float win[];   // x[n0 - W .. n0 + 255]
+    const long long ch = blockIdx.y;
+    const long long n0 = (long long)W + (long long)blockIdx.x * 256;
+    const float* xc = x + ch * length;
+    for (int i = threadIdx.x; i < W + 256; i += 256) {
+        const long long j = n0 - W + i;
+        win[i] = j < length ? xc[j] : 0.0f;
+    }
+    __syncthreads();
+    const long long n = n0 + threadIdx.x;
+    if (n >= length) return;
+    const float* w = win + threadIdx.x;   // samples n - W .. n - 1
+    const float Wf = (float)W;
+    float mean = 0.0f, m2 = 0.0f, m4 = 0.0f;
+    for (int i = 0; i < W; ++i) mean += w[i];
+    mean /= Wf;
+    for (int i = 0; i < W; ++i) {
+        const double d = (double)(w[i] - mean);
+        m2 = (float)((double)m2 + d * d);
+        m4 = (float)((double)m4 + (d * d) * (d * d));
+    }
+    m2 /= Wf;
+    m4 /= Wf;
+    if (m2 > 0.000001) {
+        const double Wd = (double)Wf, m2d = (double)m2;
+        k[ch * length + n] = (float)(1.0 / (double)((Wf - 2) * (Wf - 3)) *
+                                     ((Wd * Wd - 1.0) * (double)m4 / (m2d * m2d) -
+                                      3.0 * ((Wd - 1.0) * (Wd - 1.0))));
+    }
+}
+}  // namespace bpmf
+
+extern "C" int bpmf_kurtosis_dev(const float* d_signal, int W, size_t n_channels, size_t length,
+                                 bpmf_stream_t stream_, float* d_kurto)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_signal || !d_kurto || W < 4 || n_channels == 0 || n_channels > 65535 ||
+        (size_t)W > 32768) {
+        bpmf::set_error("bpmf_kurtosis_dev: bad argument (W=%d, channels=%zu)", W, n_channels);
+        return -1;
+    }
+    if (length <= (size_t)W) return 0;   // nothing to write
+    const size_t n_out = length - (size_t)W;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)n_channels);
+    bpmf::kurtosis_kernel<<<grid, dim3(256), ((size_t)W + 256) * sizeof(float), stream>>>(
+        d_signal, W, (long long)length, d_kurto);
+    BPMF_LAUNCH_CHECK();
+    return 0;
+}

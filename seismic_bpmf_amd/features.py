@@ -129,3 +129,21 @@ def saturated_envelopes(traces, anomaly_threshold=1.0e-11, max_dynamic_range=1.0
             wf[s, c] = torch.minimum(std, cap)
             availability[s] += 1
     return wf, availability
+
+
+def kurtosis(signal, W, device=None):
+    """Device version of BPMF.clib.kurtosis(signal, W) (BPMF/clib.py:86-102): running kurtosis of
+    `signal (n_stations, n_components, length)` over the W samples before each sample.  Returns a
+    float32 device tensor of the same shape, zero where the reference leaves its zeros."""
+    import ctypes as C
+    torch, dev = _torch_device(device)
+    x = signal if isinstance(signal, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(signal, dtype=np.float32))
+    x = x.to(device=dev, dtype=torch.float32).contiguous()
+    if x.dim() != 3:
+        raise ValueError("signal must be (n_stations, n_components, length)")
+    out = torch.zeros_like(x)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = _lib.lib().bpmf_kurtosis_dev(C.c_void_p(x.data_ptr()), int(W), x.shape[0] * x.shape[1], x.shape[2],
+                                      C.c_void_p(stream), C.c_void_p(out.data_ptr()))
+    _lib.check(rc, "bpmf_kurtosis_dev")
+    return out

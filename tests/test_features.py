@@ -90,3 +90,17 @@ def test_device_envelopes_against_float64_and_the_reference_output():
                 assert np.all(np.abs(feat[s, c].astype(np.float64) - gold[s, c]) <= bound), (j, s, c)
         if j == 0:
             assert feat.max() == np.float32(1.0e5)
+
+
+@pytest.mark.gpu
+def test_device_kurtosis_equals_the_reference_output(oracle_lib):
+    """bpmf_kurtosis_dev against the golden produced by the reference's compiled libc.c, and
+    against the oracle on a second shape (W not a multiple of anything, short trailing block)."""
+    from seismic_bpmf_amd.features import kurtosis
+    g = np.load(os.path.join(os.path.dirname(GOLD), "kurtosis.npz"))
+    got = kurtosis(g["signal"], int(g["W"])).cpu().numpy()
+    want = [g[k] for k in g.files if k not in ("signal", "W")][0]
+    assert got.shape == want.shape and np.array_equal(got, want)
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((2, 3, 3001)) * np.array([1.0, 1e-4, 30.0])[None, :, None]).astype(np.float32)
+    assert np.array_equal(kurtosis(x, 37).cpu().numpy(), oracle_lib.kurtosis(x, 37))
