@@ -1,0 +1,72 @@
+// Micro-benchmark: fp32 MFMA stream (4 independent 16x16x4 tiles per wave, 4 waves/SIMD) with
+// the K-loop's LDS operand reads placed between the MFMAs, as in mf_mfma_wave_kernel.
+//   MODE 0: no LDS reads            MODE 1: 5 ds_read_b32 per k-step (4 MFMAs)
+//   MODE 2: 5 ds_read2_b32 per 2 k-steps (same bytes, half the LDS instructions)
+// hipcc --offload-arch=gfx950 -O3 mfma_lds.hip -o mfma_lds.bin && ./mfma_lds.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define SB __builtin_amdgcn_sched_barrier(0)
+#define RD(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define RD2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+#define MF(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void k(float* out, int iters)
+{
+    __shared__ float lds[4 * 1664];
+    for (int i = threadIdx.x; i < 4 * 1664; i += 256) lds[i] = (float)(i & 7);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned ap = (unsigned)(size_t)(lds + wv * 1664 + (lane & 15));
+    unsigned bp = (unsigned)(size_t)(lds + wv * 1664 + 64 + 18 * (lane & 15) + (lane >> 4));
+    f32x4 acc[4];
+    for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0, 0, 0, 0};
+    if (MODE == 0) {
+        float a = lane, b[4] = {1.f, 2.f, 3.f, 4.f};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MF(a, b[0], acc[0]); MF(a, b[1], acc[1]); MF(a, b[2], acc[2]); MF(a, b[3], acc[3]); }
+    } else if (MODE == 1) {
+        float sa[4], sb[4][4];
+#define REQ(s, ao, bo) RD(sa[s], ap, ao); RD(sb[s][0], bp, bo); RD(sb[s][1], bp, (bo) + 1152); RD(sb[s][2], bp, (bo) + 2304); RD(sb[s][3], bp, (bo) + 3456)
+#define STEP(cur, req, ao, bo) \
+    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); SB; MF(sa[cur], sb[cur][0], acc[0]); SB; RD(sa[req], ap, ao); SB; \
+    MF(sa[cur], sb[cur][1], acc[1]); SB; RD(sb[req][0], bp, bo); SB; MF(sa[cur], sb[cur][2], acc[2]); SB; RD(sb[req][1], bp, (bo) + 1152); SB; \
+    MF(sa[cur], sb[cur][3], acc[3]); SB; RD(sb[req][2], bp, (bo) + 2304); RD(sb[req][3], bp, (bo) + 3456); SB
+        REQ(0, 0, 0); REQ(1, 16, 16);
+        for (int i = 0; i < iters; ++i) { STEP(0, 2, 32, 32); STEP(1, 3, 48, 48); STEP(2, 0, 0, 0); STEP(3, 1, 16, 16); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        f32x2 sa[2], sb[2][4];
+        unsigned b1 = bp + 1152, b2 = bp + 2304, b3 = bp + 3456;
+#define REQ2(s, o) RD2(sa[s], ap, o, (o) + 4); RD2(sb[s][0], bp, o, (o) + 4); RD2(sb[s][1], b1, o, (o) + 4); RD2(sb[s][2], b2, o, (o) + 4); RD2(sb[s][3], b3, o, (o) + 4)
+#define PAIR(cur, nxt, o) \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB; MF(sa[cur][0], sb[cur][0][0], acc[0]); SB; RD2(sa[nxt], ap, o, (o) + 4); SB; \
+    MF(sa[cur][0], sb[cur][1][0], acc[1]); SB; RD2(sb[nxt][0], bp, o, (o) + 4); SB; MF(sa[cur][0], sb[cur][2][0], acc[2]); SB; RD2(sb[nxt][1], b1, o, (o) + 4); SB; \
+    MF(sa[cur][0], sb[cur][3][0], acc[3]); SB; RD2(sb[nxt][2], b2, o, (o) + 4); SB; MF(sa[cur][1], sb[cur][0][1], acc[0]); SB; RD2(sb[nxt][3], b3, o, (o) + 4); SB; \
+    MF(sa[cur][1], sb[cur][1][1], acc[1]); MF(sa[cur][1], sb[cur][2][1], acc[2]); MF(sa[cur][1], sb[cur][3][1], acc[3]); SB
+        REQ2(0, 0);
+        for (int i = 0; i < iters; ++i) { PAIR(0, 1, 8); PAIR(1, 0, 0); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float s = 0;
+    for (int u = 0; u < 4; ++u) s += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MODE>
+void run()
+{
+    float* d; hipMalloc(&d, 256 * 4 * 256 * sizeof(float));
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<256 * 4, 256>>>(d, 10);
+    hipEventRecord(e0);
+    k<MODE><<<256 * 4, 256>>>(d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 256.0 * 4 * 4 * iters * 16 * 2048.0;
+    printf("mode %d: %.1f TFLOP/s (%.1f%% of 157.3)\n", MODE, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100);
+    hipFree(d);
+}
+int main() { run<0>(); run<1>(); run<2>(); return 0; }
