@@ -109,3 +109,25 @@ def test_bp_full_day_shard_merge_and_planted_events():
         assert maxbeam[peaks[hit[0]]] >= maxbeam[t0] >= 8.0      # 20 terms x 0.1 x (8 + noise)
     for b in (full, r0, r1):
         b.close()
+
+
+def test_mf_baseline_config0_whole_against_oracle_and_float64(oracle_lib):
+    """BASELINE.json configs[0], the reference's own CPU-runnable case, in full: 4 templates x 8
+    stations x 3 components, 128-sample templates, 1 h @ 50 Hz.  Bit-exact against the oracle in
+    both output layouts, within the float32 tolerance of a float64 brute force on a sample of lags,
+    and every planted event detected at its planted index."""
+    from oracle import ref_numpy
+    from seismic_bpmf_amd import matched_filter
+    from seismic_bpmf_amd import synthetic as syn
+    cfg = syn.MF_CONFIGS["cfg1"]
+    mf = syn.make_mf_inputs(cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"], seed=20260929)
+    args = (mf["templates"], mf["moveouts"], mf["weights"], mf["data"], 1)
+    cc = matched_filter(*args, arch="gpu", check_zeros=False)
+    assert np.array_equal(cc, oracle_lib.matched_filter(*args))
+    per = matched_filter(*args, arch="gpu", network_sum=False)
+    assert np.array_equal(per, oracle_lib.matched_filter(*args, network_sum=False))
+    for t, i0 in mf["planted"]:
+        lo = max(0, i0 - 300)
+        assert lo + int(cc[t, lo:i0 + 300].argmax()) == i0
+    exact = ref_numpy.matched_filter_f64(*args)       # float64 brute force, no summation-order care
+    assert np.abs(cc - exact).max() < 2e-5            # the float32 tolerance on CC values
