@@ -193,7 +193,7 @@ def cpu_baseline(cfg, target_seconds):
             model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
     except Exception:
         pass
-    return {"value": round(value, 4), "unit": "million network-CC-samples/s", "cores": cores,
+    return {"value": round(value, 4), "unit": "M CC-samples/s", "cores": cores,
             "kind": "port",
             "value_1_thread": round(2 * (60_000 - L + 1) / dt1 / 1e6, 5), "cpu_model": model,
             "sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n} samples of the "
