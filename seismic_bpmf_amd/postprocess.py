@@ -103,13 +103,8 @@ def _suppress(ind, rank, mpd):
     neighbours of each kept peak instead (same order, same result)."""
     ind = np.ascontiguousarray(ind, dtype=np.int64)
     rank = np.ascontiguousarray(rank, dtype=np.int64)
-    try:
-        from . import _lib
-        lib = _lib.lib()
-    except Exception:
-        lib = None
-    if lib is None:                               # library not built: the reference's own loop
-        return _suppress_reference_loop(ind, rank, mpd)
+    from . import _lib
+    lib = _lib.lib()                              # raises if the library has not been built
     keep = np.empty(ind.size, dtype=np.uint8)
     import ctypes as C
     rc = lib.bpmf_suppress_peaks(ind.ctypes.data_as(C.POINTER(C.c_int64)),
