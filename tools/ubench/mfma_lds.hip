@@ -12,7 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define RD2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
 #define MF(a, b, c) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 template <int MODE, bool RANDOM_DATA>
-__global__ __launch_bounds__(256, 4) void k(float* out, int iters)
+__global__ __launch_bounds__(256, 4) void k(float* out, int iters, const float* __restrict__ gsrc)
 {
     __shared__ float lds[4 * 1664];
     for (int i = threadIdx.x; i < 4 * 1664; i += 256) { unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; lds[i] = RANDOM_DATA ? (float)(int)(h & 0xffff) * 3.0517578e-5f - 1.0f : (float)(i & 7); }
@@ -57,7 +57,13 @@ __global__ __launch_bounds__(256, 4) void k(float* out, int iters)
             for (int i = 0; i < 17; ++i) { STEP(0, 2, 32, 32); STEP(1, 3, 48, 48); STEP(2, 0, 0, 0); STEP(3, 1, 16, 16); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SB;
-            if (MODE == 3 || MODE == 7) {
+            if (MODE == 13) {  // DMA issued first, epilogue overlaps its latency
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+                __builtin_amdgcn_global_load_lds(gsrc + ((c * 7 + r) & 255) * 256 + lane * 4,
+                                                 (__attribute__((address_space(3))) void*)(lds + wv * 1664 + 80 + 256 * (r % 5)), 16, 0, 0);
+            }
+            if (MODE == 3 || MODE == 7 || MODE == 13) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -71,6 +77,21 @@ __global__ __launch_bounds__(256, 4) void k(float* out, int iters)
             if (MODE == 3 || MODE == 8) {
 #pragma unroll
             for (int r = 0; r < 25; ++r) ((volatile float*)lds)[wv * 1664 + 80 + lane + 64 * (r % 20)] = extra[r & 15];
+            }
+            if (MODE == 13) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (MODE == 11) {  // LDS-DMA: global -> LDS without VGPRs (25 x 256 B per wave)
+#pragma unroll
+            for (int r = 0; r < 25; ++r)
+                __builtin_amdgcn_global_load_lds(gsrc + ((c * 25 + r) & 1023) * 64 + lane,
+                                                 (__attribute__((address_space(3))) void*)(lds + wv * 1664 + 80 + 64 * (r % 20)), 4, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (MODE == 12) {  // LDS-DMA, 16 bytes per lane (7 x 1 KB per wave)
+#pragma unroll
+            for (int r = 0; r < 7; ++r)
+                __builtin_amdgcn_global_load_lds(gsrc + ((c * 7 + r) & 255) * 256 + lane * 4,
+                                                 (__attribute__((address_space(3))) void*)(lds + wv * 1664 + 80 + 256 * (r % 5)), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (MODE == 9) {   // same bytes as 8-byte stores
 #pragma unroll
@@ -108,13 +129,13 @@ void run(int wps = 4)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t dyn = wps >= 4 ? 0 : (wps == 3 ? 24 : (wps == 2 ? 50 : 110)) * 1024;  // limit workgroups per CU
     hipFuncSetAttribute((const void*)k<MODE, RANDOM_DATA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4 * 1664 * 4);
-    k<MODE, RANDOM_DATA><<<256 * wps, 256, dyn>>>(d, 10);
+    k<MODE, RANDOM_DATA><<<256 * wps, 256, dyn>>>(d, 10, d);
     hipEventRecord(e0);
-    k<MODE, RANDOM_DATA><<<256 * wps, 256, dyn>>>(d, iters);
+    k<MODE, RANDOM_DATA><<<256 * wps, 256, dyn>>>(d, iters, d);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = 256.0 * wps * 4 * iters * 16 * 2048.0;
     printf("waves/SIMD=%d random=%d mode %d: %.1f TFLOP/s (%.1f%% of 157.3)\n", wps, (int)RANDOM_DATA, MODE, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100);
     hipFree(d);
 }
-int main() { run<6, true>(4); run<6, true>(4); run<8, true>(4); run<9, true>(4); run<10, true>(4); return 0; }
+int main() { run<6, true>(4); run<3, true>(4); run<13, true>(4); run<3, true>(3); run<13, true>(3); return 0; }
