@@ -26,8 +26,14 @@ if __name__ == "__main__":
     d, tag = sys.argv[1], sys.argv[2]
     os.makedirs("profiles", exist_ok=True)
     ks = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("kernel_stats.csv")]
-    if ks:
-        kernel_stats(ks[0], f"profiles/{tag}_kernel_stats.csv")
+    if ks:  # the directory may hold earlier runs as well: newest file wins
+        kernel_stats(max(ks, key=os.path.getmtime), f"profiles/{tag}_kernel_stats.csv")
     pm = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
     if pm:
+        newest = {}   # one counter file per pass directory: the newest
+        for f in pm:
+            d_ = os.path.dirname(os.path.dirname(f))
+            if d_ not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d_]):
+                newest[d_] = f
+        pm = list(newest.values())
         print(json.dumps(pmc(pm, ["mf_mfma", "bp_beam", "mf_csum_local", "bp_prestack", "tdt_window"], f"profiles/{tag}_pmc.json"), indent=1))
