@@ -3,11 +3,9 @@ BPMF/template_search.py:1525-1617 (`envelope`, `envelope_parallel`, `saturated_e
 `waveform_features (S, C, N)` that `Beamformer.backproject` hands to `beampower.beamform`
 ("next" row 4).
 
-Two implementations with the same signature and return values:
+The semantics are pinned by a NumPy/SciPy restatement under oracle/ (oracle/features_host.py, test
+infrastructure; bit for bit equal to the reference's own output, tests/golden/saturated_envelopes.npz).
 
-* :func:`saturated_envelopes_host` -- NumPy/SciPy restatement, pinned bit for bit to the
-  reference's own output (tests/golden/saturated_envelopes.npz).  Test infrastructure and
-  documentation of the semantics; it is not used by the device path.
 * :func:`saturated_envelopes` -- on the MI355X: the analytic signal through a float64 FFT
   (hipFFT behind ``torch.fft``), the per-channel median / MAD by a device sort, everything else
   element-wise.  Median, MAD, standardisation and clipping reproduce NumPy's float32 arithmetic
@@ -37,38 +35,6 @@ def _analytic_weights(n, xp, **kw):
         h[0] = 1.0
         h[1:(n + 1) // 2] = 2.0
     return h
-
-
-# ------------------------------------------------------------------------ host mirror ---
-def envelope_host(trace):
-    """BPMF/template_search.py:1599-1617: np.float32(np.abs(hilbert(trace)))."""
-    from scipy.signal import hilbert
-    return np.float32(np.abs(hilbert(trace)))
-
-
-def saturated_envelopes_host(traces, anomaly_threshold=1.0e-11, max_dynamic_range=1.0e5):
-    """Line-by-line restatement of BPMF/template_search.py:1525-1572."""
-    from scipy.stats import median_abs_deviation as scimad
-    traces = np.asarray(traces)
-    n_stations, n_components, n_samples = traces.shape
-    wf = np.float32([envelope_host(x) for x in traces.reshape(-1, n_samples)]).reshape(traces.shape)
-    availability = np.zeros(n_stations, dtype=np.int32)
-    for s in range(n_stations):
-        for c in range(n_components):
-            missing = wf[s, c, :] == 0.0
-            if np.sum(missing) > n_samples / 2:
-                wf[s, c, :] = 0.0
-                continue
-            median = np.median(wf[s, c, ~missing])
-            mad = scimad(wf[s, c, ~missing])
-            if mad < anomaly_threshold:
-                wf[s, c, :] = 0.0
-                continue
-            wf[s, c, :] = (wf[s, c, :] - median) / mad
-            wf[s, c, missing] = 0.0
-            wf[s, c, :] = np.clip(wf[s, c, :], wf[s, c, :], max_dynamic_range)
-            availability[s] += 1
-    return wf, availability
 
 
 # ------------------------------------------------------------------------ device path ---

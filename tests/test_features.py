@@ -9,7 +9,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "satur
 
 
 def test_host_restatement_equals_the_reference():
-    from seismic_bpmf_amd.features import envelope_host, saturated_envelopes_host
+    from oracle.features_host import envelope_host, saturated_envelopes_host
     g = np.load(GOLD)
     for j in range(int(g["n_cases"])):
         tr = g[f"traces_{j}"]
