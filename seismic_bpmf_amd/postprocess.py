@@ -114,21 +114,6 @@ def _suppress(ind, rank, mpd):
     return keep.astype(bool)
 
 
-def _suppress_reference_loop(ind, rank, mpd):
-    """Line-by-line restatement of BPMF/utils.py:2334-2345 (used to pin `_suppress`)."""
-    order = ind[rank]
-    dropped = np.zeros(order.size, dtype=bool)
-    for q in range(order.size):
-        if dropped[q]:
-            continue
-        near = (order >= order[q] - mpd) & (order <= order[q] + mpd)
-        dropped |= near
-        dropped[q] = False
-    keep = np.zeros(ind.size, dtype=bool)
-    keep[rank[~dropped]] = True
-    return keep
-
-
 def find_beam_detections(maxbeam, maxbeam_sources, threshold, mpd):
     """Peak logic of Beamformer.find_detections (BP-6), BPMF/template_search.py:604-627.
 

@@ -133,6 +133,21 @@ def test_numpy_order_sum_matches_numpy_bit_for_bit():
         assert np.array_equal(got, want), (S, C)
 
 
+def _suppress_reference_loop(ind, rank, mpd):
+    """Restatement of the O(peaks^2) loop of BPMF/utils.py:2334-2345 (pins postprocess._suppress)."""
+    order = ind[rank]
+    dropped = np.zeros(order.size, dtype=bool)
+    for q in range(order.size):
+        if dropped[q]:
+            continue
+        near = (order >= order[q] - mpd) & (order <= order[q] + mpd)
+        dropped |= near
+        dropped[q] = False
+    keep = np.zeros(ind.size, dtype=bool)
+    keep[rank[~dropped]] = True
+    return keep
+
+
 def test_fast_peak_suppression_equals_the_reference_loop():
     """bpmf_suppress_peaks (host routine of the library) against the restated NumPy loop of
     BPMF/utils.py:2334-2345, ties and fractional mpd included."""
@@ -146,7 +161,7 @@ def test_fast_peak_suppression_equals_the_reference_loop():
         ind = np.flatnonzero((np.append(dx, 0.0) <= 0) & (np.insert(dx, 0, 0.0) > 0))
         ind = ind[(ind > 0) & (ind < n - 1)]
         rank = np.argsort(x[ind])[::-1]
-        want = pp._suppress_reference_loop(ind.astype(np.int64), rank.astype(np.int64), mpd)
+        want = _suppress_reference_loop(ind.astype(np.int64), rank.astype(np.int64), mpd)
         got = pp._suppress(ind, rank, mpd)
         assert np.array_equal(got, want), (trial, n, mpd)
         assert np.array_equal(pp.detect_peaks(x, mpd=mpd), ind[want])
