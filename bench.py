@@ -115,15 +115,16 @@ def bp_inputs(cfg, device, seed, rank, world):
 
 def bp_detection_stage(beam, arg, geo, bcfg):
     """What follows the beamformer in BPMF (template_search.py:574-627), untimed: sliding
-    median/MAD threshold, peaks at least 5 s apart, snap + unique, source of each peak -- on the
-    full day, with the host mirror of the reference's Python.  Every planted event must come out
+    median/MAD threshold (window medians by device sorts), peaks at least 5 s apart, snap + unique,
+    source of each peak -- on the full day, with the mirror of the reference's Python.  Every planted event must come out
     within the half-width of its bump, located at the planted source or one with an equal beam."""
     from seismic_bpmf_amd import postprocess as pp
     t0 = time.perf_counter()
     maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
     t1 = time.perf_counter()
     window = int(pp.sec_to_samp(1800.0, bcfg["sr"]))
-    thr = pp.bp_time_dependent_threshold(maxbeam, window, 15.0, overlap=0.75)
+    from seismic_bpmf_amd.workflow import bp_time_dependent_threshold_device
+    thr = bp_time_dependent_threshold_device(beam, window, 15.0, overlap=0.75)
     t2 = time.perf_counter()
     mpd = int(pp.sec_to_samp(5.0, bcfg["sr"]))
     peaks, peak_sources = pp.find_beam_detections(maxbeam, sources, thr, mpd)

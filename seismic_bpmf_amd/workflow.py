@@ -67,6 +67,49 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     return out, cc
 
 
+def bp_time_dependent_threshold_device(beam, window, n_dev, overlap=0.75):
+    """postprocess.bp_time_dependent_threshold (BPMF/template_search.py:1418-1487) with the
+    per-window medians and MADs computed on the device: `beam` is the (N,) float32 device tensor
+    the beamformer returned; all windows are sorted in one batched call.  Same float32 arithmetic
+    (median of an even count = float32 mean of the two middle values), so the result is
+    bit-identical to the host version; only the n_windows + 2 window values come back, and the
+    float64 interpolation to N samples runs on the host like the reference's interp1d."""
+    import torch
+    x = beam.reshape(-1)
+    n = x.numel()
+    shift = int((1.0 - overlap) * window)
+    n_windows = int((n - window) // shift) + 1
+
+    def median_rows(rows):                     # np.median along the last axis, float32
+        srt = torch.sort(rows, dim=-1).values
+        m = rows.shape[-1]
+        return srt[..., m // 2] if m % 2 else (srt[..., m // 2 - 1] + srt[..., m // 2]) / 2
+
+    med = torch.zeros(n_windows + 2, dtype=torch.float32, device=x.device)
+    mad = torch.zeros_like(med)
+    centre = np.zeros(n_windows + 2, dtype=np.float32)
+    # windows q = 1 .. n_windows start at q * shift; those that fit entirely are rows of one view
+    n_full = min(n_windows, (n - window) // shift)          # q with q*shift + window <= n
+    if n_full >= 1:
+        rows = x.unfold(0, window, shift)[1:n_full + 1]
+        m = median_rows(rows)
+        med[1:n_full + 1] = m
+        mad[1:n_full + 1] = median_rows((rows - m[:, None]).abs())
+    for q in range(n_full + 1, n_windows + 1):              # shorter windows at the end of the day
+        seg = x[q * shift:min(n, q * shift + window)]
+        m = median_rows(seg)
+        med[q] = m
+        mad[q] = median_rows((seg - m).abs())
+    for q in range(1, n_windows + 1):
+        i1 = q * shift
+        centre[q] = (i1 + min(n, i1 + window)) / 2.0
+    med[0], mad[0], centre[0] = med[1], mad[1], 0.0
+    med[-1], mad[-1], centre[-1] = med[-2], mad[-2], n
+    thr = (med + n_dev * mad).cpu().numpy()
+    return np.interp(np.arange(n, dtype=np.float64), centre.astype(np.float64), thr.astype(np.float64),
+                     left=thr[0], right=thr[-1])
+
+
 def backprojection_detections(features, moveouts, weights_phases, weights_sources, *, sr,
                               minimum_interevent_time, threshold_window_dur=None, n_dev=15.0,
                               overlap=0.75, threshold=None, out_of_bounds="strict", device=None):
@@ -74,10 +117,10 @@ def backprojection_detections(features, moveouts, weights_phases, weights_source
     bf = BeamformerGPU(moveouts, weights_sources, device=device)
     beam, arg = bf.run(features, weights_phases, "max", out_of_bounds)
     maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
-    bf.close()
     if threshold is None:
         window = int(pp.sec_to_samp(threshold_window_dur, sr))
-        threshold = pp.bp_time_dependent_threshold(maxbeam, window, n_dev, overlap=overlap)
+        threshold = bp_time_dependent_threshold_device(beam, window, n_dev, overlap=overlap)
+    bf.close()
     mpd = int(pp.sec_to_samp(minimum_interevent_time, sr))
     peaks, peak_sources = pp.find_beam_detections(maxbeam, sources, threshold, mpd)
     return peaks, peak_sources, maxbeam, sources

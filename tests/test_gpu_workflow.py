@@ -56,3 +56,26 @@ def test_intertemplate_cc_against_oracle(oracle_lib):
     want = (want + want.T) / 2.0
     assert np.array_equal(got, want)
     assert got[1, 3] > 0.85 and abs(got[0, 0] - 1.0) < 1e-5
+
+
+def test_bp_threshold_on_device_equals_the_host_mirror():
+    """Sliding median/MAD threshold of the max beam: device sorts vs the host mirror that is pinned
+    to the reference's golden (tests/golden/bp_threshold.npz), bit for bit, including windows cut
+    short at the end of the trace and even/odd window lengths."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.workflow import bp_time_dependent_threshold_device
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bp_threshold.npz"))
+    got = bp_time_dependent_threshold_device(torch.as_tensor(g["maxbeam"], device="cuda"), int(g["window"]),
+                                             float(g["n_dev"]), overlap=float(g["overlap"]))
+    # the golden comes from scipy's interp1d, which differs from np.interp in operation order only
+    assert np.abs(got - g["thr"]).max() <= 1e-12 * np.abs(g["thr"]).max()
+    assert np.array_equal(got, pp.bp_time_dependent_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]),
+                                                              float(g["overlap"])))
+    rng = np.random.default_rng(8)
+    for n, window, overlap in [(50_001, 3001, 0.75), (40_000, 3000, 0.5), (12_345, 1000, 0.9), (9_000, 9_000, 0.75)]:
+        x = (np.abs(rng.standard_normal(n)) * (1 + 5 * (rng.random(n) > 0.999))).astype(np.float32)
+        want = pp.bp_time_dependent_threshold(x, window, 15.0, overlap=overlap)
+        got = bp_time_dependent_threshold_device(torch.as_tensor(x, device="cuda"), window, 15.0, overlap=overlap)
+        assert np.array_equal(got, want), (n, window, overlap)
