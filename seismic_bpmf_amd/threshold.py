@@ -67,6 +67,53 @@ class ThresholdGPU:
         self._keep = (cc, g)
         return thr_win, full
 
+    def time_dependent_threshold_mad(self, cc_row, sliding_window_samp, num_dev, overlap=0.66,
+                                     white_noise=None):
+        """MAD variant of the detection threshold (BPMF/similarity_search.py:1079-1113) for one CC
+        time series that lives on the device: the global and per-window medians / MADs come from
+        device sorts, every float32 operation in NumPy's order, so the result equals
+        postprocess.time_dependent_threshold_mad bit for bit.  Returns the (n,) float32 threshold
+        as a device tensor (compare with `cc_row > thr` on the device)."""
+        t = self.torch
+        x = cc_row.reshape(-1).to(device=self.device, dtype=t.float32)
+        n = x.numel()
+        W = int(sliding_window_samp)
+        half = W // 2
+        shift = int((1.0 - overlap) * W)
+
+        def median_last(rows):                  # np.median along the last axis, float32
+            srt = t.sort(rows, dim=-1).values
+            m = rows.shape[-1]
+            return srt[..., m // 2] if m % 2 else (srt[..., m // 2 - 1] + srt[..., m // 2]) / 2
+
+        zeros = x == 0.0
+        n_zeros = int(zeros.sum())
+        if white_noise is None:
+            white_noise = np.random.normal(size=n_zeros).astype("float32")
+        nz = x[~zeros]
+        centre0 = median_last(nz)
+        dev0 = median_last((nz - centre0).abs())
+        ts = x.clone()
+        if n_zeros:
+            wn = t.as_tensor(np.ascontiguousarray(white_noise[:n_zeros], dtype=np.float32), device=self.device)
+            ts[zeros] = wn * dev0 + centre0
+        wins = ts.unfold(0, W, shift)           # sliding_window_view(ts, W)[::shift]
+        centre = t.empty(wins.shape[0], dtype=t.float32, device=self.device)
+        dev = t.empty_like(centre)
+        rows_per_batch = max(1, (1 << 27) // W)  # bounds the sort work space (~0.5 GB of keys)
+        for i in range(0, wins.shape[0], rows_per_batch):
+            w_ = wins[i:i + rows_per_batch]
+            c_ = median_last(w_)
+            centre[i:i + rows_per_batch] = c_
+            dev[i:i + rows_per_batch] = median_last((w_ - c_[:, None]).abs())
+        thr = centre + num_dev * dev
+        thr[1:] = t.maximum(thr[:-1], thr[1:]).clone()
+        thr[:-1] = t.maximum(thr[:-1], thr[1:]).clone()
+        where = t.arange(half, n - (W - half), device=self.device) // shift
+        where = t.clamp(where, max=thr.numel() - 1)
+        mid = thr[where]   # the reference pads with the ends of the INDEXED array
+        return t.cat((mid[0].expand(half), mid, mid[-1].expand(W - half)))
+
     def extract_candidates(self, cc, thr_windows, sliding_window_samp, overlap=0.66, row_cap=None,
                            capacity=1 << 20):
         """Records (row, index, cc, threshold) of every sample above min(threshold, row_cap)."""

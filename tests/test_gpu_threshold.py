@@ -85,3 +85,27 @@ def test_end_to_end_planted_events_are_detected_at_exact_samples(oracle_lib):
         assert np.array_equal(got, want)
         planted = sorted(i0 for tt, i0 in mf_in["planted"] if tt == t)
         assert list(got) == planted, (t, got, planted)
+
+
+def test_mad_threshold_on_device_equals_the_host_mirror_and_the_reference_golden():
+    """threshold_type="mad" (BPMF/similarity_search.py:1079-1113): device sorts vs the host mirror
+    (pinned to tests/golden/tdt_mad.npz, the reference's own output), bit for bit."""
+    import os
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tdt_mad.npz"))
+    th = ThresholdGPU()
+    got = th.time_dependent_threshold_mad(torch.as_tensor(g["x"], device="cuda"), int(g["window"]), float(g["n_dev"]),
+                                          overlap=float(g["overlap"]), white_noise=g["white_noise"]).cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, g["thr"])
+    rng = np.random.default_rng(3)
+    for n, W, ov in [(30_001, 2001, 0.66), (20_000, 1000, 0.25), (7_777, 500, 0.9)]:
+        x = (rng.standard_normal(n) * 0.05).astype(np.float32)
+        x[rng.random(n) < 0.02] = 0.0
+        x[1000:1400] = 0.0
+        wn = rng.standard_normal(int((x == 0).sum())).astype(np.float32)
+        want = pp.time_dependent_threshold_mad(x, W, 8.0, overlap=ov, white_noise=wn)
+        got = th.time_dependent_threshold_mad(torch.as_tensor(x, device="cuda"), W, 8.0, overlap=ov,
+                                              white_noise=wn).cpu().numpy()
+        assert np.array_equal(got, want), (n, W, ov)
