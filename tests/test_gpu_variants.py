@@ -114,7 +114,8 @@ def _bp_check(oracle_lib, f, tau, wp, ws, what):
           f"{what} full beam")
 
 
-@pytest.mark.parametrize("S,P,density,label", [(6, 2, 0.6, "wps <=8..16 terms"), (14, 2, 1.0, "wps 28 terms"),
+@pytest.mark.parametrize("S,P,density,label", [(2, 2, 1.0, "2 stations"), (4, 2, 1.0, "4 stations"), (3, 2, 0.7, "<= 3 stations"),
+                                               (6, 2, 0.6, "wps <=8..16 terms"), (14, 2, 1.0, "wps 28 terms"),
                                                (20, 2, 1.0, "readlane 40 terms"), (40, 2, 1.0, "readlane 80 terms"),
                                                (45, 3, 1.0, "readlane 135 terms"), (9, 1, 0.8, "P=1"),
                                                (6, 5, 1.0, "P=5 prestack_any")])
