@@ -16,6 +16,8 @@
 //      (max, arg-max) per time sample: no atomics, no cross-workgroup merge, and the
 //      sequential source order gives the "lowest index wins ties" rule for free.
 #include "common.h"
+#include <mutex>
+#include <cstring>
 #include <type_traits>
 #include "../../include/bpmf_hip.h"
 
@@ -1598,6 +1600,30 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
     }
 }
 
+namespace {
+struct PlanCacheEntry { uint64_t key; size_t K, S, P; int device; bpmf_bp_plan* pl; };
+PlanCacheEntry g_plan_cache[2] = {{0, 0, 0, 0, 0, nullptr}, {0, 0, 0, 0, 0, nullptr}};
+unsigned g_plan_cache_next = 0;
+std::mutex g_plan_cache_mutex;
+// 64-bit multiply-xorshift over the bytes of a table, 8 at a time (not cryptographic: a cache key)
+uint64_t hash_words(const void* p, size_t bytes, uint64_t seed)
+{
+    const unsigned char* b = (const unsigned char*)p;
+    uint64_t h = seed ^ (bytes * 0x9e3779b97f4a7c15ull);
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    uint64_t w = 0;
+    if (i < bytes) memcpy(&w, b + i, bytes - i);
+    h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 29);
+}
+}  // namespace
+
 extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const float* w_phases,
                            const float* w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
                            int out_of_bounds, int reduce, int device, float* beam_out,
@@ -1607,8 +1633,29 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
         set_error("bpmf_bp_run: null pointer");
         return -1;
     }
+    // BPMF calls beamform once per day with the same moveout table and source weights
+    // (template_search.py:549-558); building the plan costs 0.04 s for 50 000 sources but 3 s for a
+    // million, so the last plans are kept, keyed by a hash of both tables.
     bpmf_bp_plan* pl = nullptr;
-    if (int rc = bpmf_bp_plan_create(moveouts, w_sources, K, S, P, device, 0, &pl)) return rc;
+    const uint64_t key = hash_words(moveouts, K * S * P * sizeof(int32_t), 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
+                         hash_words(w_sources, K * S * sizeof(float), 0xc2b2ae3d27d4eb4full + (uint64_t)device);
+    {
+        std::lock_guard<std::mutex> g(g_plan_cache_mutex);
+        for (auto& e : g_plan_cache)
+            if (e.pl && e.key == key && e.K == K && e.S == S && e.P == P && e.device == device) {
+                pl = e.pl;
+                e.pl = nullptr;            // taken out while in use; put back below
+                break;
+            }
+    }
+    if (!pl)
+        if (int rc = bpmf_bp_plan_create(moveouts, w_sources, K, S, P, device, 0, &pl)) return rc;
+    auto release_plan = [&]() {
+        std::lock_guard<std::mutex> g(g_plan_cache_mutex);
+        PlanCacheEntry& slot = g_plan_cache[g_plan_cache_next++ % 2];
+        if (slot.pl) bpmf_bp_plan_destroy(slot.pl);
+        slot = PlanCacheEntry{key, K, S, P, device, pl};
+    };
     const size_t b_f = S * C * N * sizeof(float), b_wp = S * C * P * sizeof(float),
                  b_ws = bpmf_bp_workspace_bytes(pl, N, C),
                  b_beam = (reduce == BPMF_BP_REDUCE_MAX ? N : K * N) * sizeof(float),
@@ -1620,7 +1667,7 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     hipError_t e = hipMalloc((void**)&base, total);
     if (e != hipSuccess) {
         set_error("bpmf_bp_run: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
-        bpmf_bp_plan_destroy(pl);
+        release_plan();
         return -2;
     }
     int rc = 0;
@@ -1642,7 +1689,7 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
         (e = hipMemcpyAsync(arg_out, base + o_arg, b_arg, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H argmax");
     if (!rc && (e = hipStreamSynchronize(stream)) != hipSuccess) fail(e, "synchronize");
     (void)hipFree(base);
-    bpmf_bp_plan_destroy(pl);
+    release_plan();
     return rc;
 }
 
