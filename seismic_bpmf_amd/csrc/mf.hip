@@ -122,7 +122,19 @@ __global__ void mf_csum_offsets_kernel(const double* __restrict__ tot, size_t n_
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
     double acc = 0.0;
-    for (size_t q = 0; q < nq; ++q) {
+    // the additions are one dependent chain; the loads are not: fetch 16 totals at a time
+    size_t q = 0;
+    for (; q + 16 <= nq; q += 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = tot[ch * nq + q + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            off[ch * nq + q + i] = acc;
+            acc = acc + v[i];
+        }
+    }
+    for (; q < nq; ++q) {
         off[ch * nq + q] = acc;
         acc = acc + tot[ch * nq + q];
     }
