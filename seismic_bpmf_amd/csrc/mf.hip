@@ -97,10 +97,37 @@ __global__ void mf_csum_local_kernel(const float* __restrict__ data, size_t n_ch
     typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
     typedef double f64x2a __attribute__((ext_vector_type(2), aligned(8)));
     size_t n = n0;
+    // one 128-byte line (8 x 16 B) per batch, the next batch in flight while this one is summed
+    constexpr int NB = 8;
+    f32x4a cur[NB], nxt[NB];
+    const size_t nbatch = (n1 - n0) / (4 * NB);
+    if (nbatch) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cur[i] = *(const f32x4a*)(d + n + 4 * i);
+    }
+    for (size_t b = 0; b < nbatch; ++b, n += 4 * NB) {
+        if (b + 1 < nbatch) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) nxt[i] = *(const f32x4a*)(d + n + 4 * NB + 4 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const f32x4a v = cur[i];
+            f64x2a o0, o1;
+            double x = (double)v[0]; acc = acc + x * x; o0[0] = acc;  // squares are exact in double
+            x = (double)v[1]; acc = acc + x * x; o0[1] = acc;
+            x = (double)v[2]; acc = acc + x * x; o1[0] = acc;
+            x = (double)v[3]; acc = acc + x * x; o1[1] = acc;
+            *(f64x2a*)(lo + n + 4 * i) = o0;
+            *(f64x2a*)(lo + n + 4 * i + 2) = o1;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cur[i] = nxt[i];
+    }
     for (; n + 4 <= n1; n += 4) {
         const f32x4a v = *(const f32x4a*)(d + n);
         f64x2a o0, o1;
-        double x = (double)v[0]; acc = acc + x * x; o0[0] = acc;  // squares are exact in double
+        double x = (double)v[0]; acc = acc + x * x; o0[0] = acc;
         x = (double)v[1]; acc = acc + x * x; o0[1] = acc;
         x = (double)v[2]; acc = acc + x * x; o1[0] = acc;
         x = (double)v[3]; acc = acc + x * x; o1[1] = acc;
