@@ -184,21 +184,46 @@ __global__ void tdt_expand_kernel(const float* __restrict__ thr_win, size_t n_ro
 // Candidate extraction: every sample with cc > min(threshold, cap[row]) becomes one record
 // (row, index, cc, threshold).  BPMF/similarity_search.py:629 (cap) and :231-232 (test).
 // Records are appended in arbitrary order; the host sorts the (few thousand) survivors.
-__global__ void cand_extract_kernel(const float* __restrict__ x, const float* __restrict__ thr_win,
-                                    const float* __restrict__ row_cap, size_t n_rows, size_t n,
-                                    size_t shift, size_t n_win, unsigned capacity,
-                                    unsigned* __restrict__ count, int4* __restrict__ records)
+__global__ __launch_bounds__(256) void cand_extract_kernel(
+    const float* __restrict__ x, const float* __restrict__ thr_win, const float* __restrict__ row_cap,
+    size_t n_rows, size_t n, size_t shift, size_t n_win, unsigned capacity,
+    unsigned* __restrict__ count, int4* __restrict__ records)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t row = blockIdx.y;
-    if (i >= n) return;
-    float t = thr_win[row * n_win + tdt_window_of(i, n, shift, n_win)];
-    if (row_cap) t = fminf(row_cap[row], t);
-    const float v = x[row * n + i];
-    if (v > t) {
-        unsigned slot = atomicAdd(count, 1u);
-        if (slot < capacity)
-            records[slot] = make_int4((int)row, (int)i, __float_as_int(v), __float_as_int(t));
+    // 4 consecutive samples per thread (one 16-byte load); the window of a sample costs a division,
+    // so it is looked up for the first and the last of the four and only recomputed in between
+    // when they differ (n < 2^31: 32-bit arithmetic)
+    const size_t row = blockIdx.y;
+    const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const unsigned nn = (unsigned)n, sh = (unsigned)shift, nw = (unsigned)n_win;
+    if (i0 >= nn) return;
+    auto window_of = [&](unsigned i) -> unsigned {
+        if (i < sh) return 0u;
+        if (i >= nn - sh) return nw - 1;
+        const unsigned q = i / sh;
+        return q > nw - 1 ? nw - 1 : q;   // clamp: documented deviation (tdt_window_of)
+    };
+    const float* xr = x + row * n;
+    const float* tw = thr_win + row * n_win;
+    const float cap = row_cap ? row_cap[row] : INFINITY;
+    const unsigned cnt = nn - i0 < 4u ? nn - i0 : 4u;
+    float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (cnt == 4) {
+        const f32x4a v4 = *(const f32x4a*)(xr + i0);
+        v[0] = v4[0]; v[1] = v4[1]; v[2] = v4[2]; v[3] = v4[3];
+    } else {
+        for (unsigned e = 0; e < cnt; ++e) v[e] = xr[i0 + e];
+    }
+    const unsigned w_first = window_of(i0), w_last = window_of(i0 + cnt - 1);
+#pragma unroll
+    for (unsigned e = 0; e < 4; ++e) {
+        if (e >= cnt) break;
+        const unsigned w = w_first == w_last ? w_first : window_of(i0 + e);
+        const float t = fminf(cap, tw[w]);
+        if (v[e] > t) {
+            unsigned slot = atomicAdd(count, 1u);
+            if (slot < capacity)
+                records[slot] = make_int4((int)row, (int)(i0 + e), __float_as_int(v[e]), __float_as_int(t));
+        }
     }
 }
 
@@ -315,7 +340,7 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
         return -1;
     }
     BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-    cand_extract_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n_rows), dim3(256), 0, stream>>>(
+    cand_extract_kernel<<<dim3((unsigned)((n + 1023) / 1024), (unsigned)n_rows), dim3(256), 0, stream>>>(
         d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, capacity, d_count,
         (int4*)d_records);
     BPMF_LAUNCH_CHECK();
