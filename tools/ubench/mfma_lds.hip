@@ -138,4 +138,4 @@ void run(int wps = 4)
     printf("waves/SIMD=%d random=%d mode %d: %.1f TFLOP/s (%.1f%% of 157.3)\n", wps, (int)RANDOM_DATA, MODE, flop / ms / 1e9, flop / ms / 1e9 / 157.3 * 100);
     hipFree(d);
 }
-int main() { run<6, true>(4); run<3, true>(4); run<13, true>(4); run<3, true>(3); run<13, true>(3); return 0; }
+int main() { run<1, true>(4); run<1, true>(4); run<1, true>(2); run<1, true>(1); run<6, true>(4); run<7, true>(4); run<8, true>(4); run<9, true>(4); run<10, true>(4); run<3, true>(4); run<12, true>(4); run<13, true>(4); return 0; }
