@@ -68,8 +68,48 @@ def _report_zeros(cc_sums, check_zeros):
                   "(try to increase the gain).")
 
 
+def _device_list(devices):
+    """None -> every visible GPU (what the upstream GPU back-end does), int -> that one, or a list."""
+    if devices is None:
+        n = _lib.lib().bpmf_device_count()
+        if n <= 0:
+            raise _lib.BpmfHipError("no HIP device visible")
+        return list(range(n))
+    if isinstance(devices, (int, np.integer)):
+        return [int(devices)]
+    return [int(d) for d in devices]
+
+
+def _run_blocks(n_items, devices, call):
+    """Split range(n_items) into contiguous blocks, one per device, and run `call(lo, hi, device)`
+    for each block on its own host thread (the C entry points release the GIL and bind their
+    thread to the device).  Returns when all are done; the first error is re-raised."""
+    devices = devices[:max(1, min(len(devices), n_items))]
+    bounds = np.linspace(0, n_items, len(devices) + 1).astype(np.int64)
+    if len(devices) == 1:
+        call(0, n_items, devices[0])
+        return
+    import threading
+    errors = []
+
+    def work(lo, hi, dev):
+        try:
+            call(lo, hi, dev)
+        except BaseException as exc:   # noqa: BLE001 - re-raised in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]), d))
+               for i, d in enumerate(devices) if bounds[i + 1] > bounds[i]]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+
+
 def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_zeros="first",
-                   normalize="short", network_sum=True, device=0, force_direct=False):
+                   normalize="short", network_sum=True, device=None, force_direct=False):
     """Sliding normalised cross-correlation of every template against the data.
 
     Parameters follow fast_matched_filter: ``templates (T,S,C,L)``, ``moveouts (T,S[,C])`` in
@@ -77,6 +117,10 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
     Returns ``cc_sums (T, n_corr)`` float32, or ``cc (T, n_corr, S, C)`` when
     ``network_sum=False``; ``n_corr = (N - L)//step + 1`` and lag ``i`` is data sample
     ``i*step`` (BPMF/similarity_search.py:275).
+
+    ``device``: None (default) = all visible GPUs, the templates block-partitioned among them
+    (one host thread per GPU; templates are independent, so no data crosses GPUs); an int or a list
+    selects devices.
     """
     if str(arch).lower() not in GPU_ARCHS:
         raise ValueError(
@@ -98,10 +142,15 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
     out = np.empty(shape, dtype=np.float32)
     f, i = _lib._f, _lib._i
     flags = FLAG_FORCE_DIRECT if force_direct else 0
-    rc = _lib.lib().bpmf_mf_run(tp.ctypes.data_as(f), mv.ctypes.data_as(i), w.ctypes.data_as(f),
-                                d.ctypes.data_as(f), step, L, N, T, S, Cc, n_corr,
-                                int(bool(network_sum)), flags, int(device), out.ctypes.data_as(f))
-    _lib.check(rc, "bpmf_mf_run")
+    lib = _lib.lib()
+
+    def block(lo, hi, dev):
+        rc = lib.bpmf_mf_run(tp[lo:hi].ctypes.data_as(f), mv[lo:hi].ctypes.data_as(i),
+                             w[lo:hi].ctypes.data_as(f), d.ctypes.data_as(f), step, L, N, hi - lo, S, Cc,
+                             n_corr, int(bool(network_sum)), flags, dev, out[lo:hi].ctypes.data_as(f))
+        _lib.check(rc, "bpmf_mf_run")
+
+    _run_blocks(T, _device_list(device), block)
     if network_sum and check_zeros in ("first", "all"):
         _report_zeros(out, check_zeros)
     return out

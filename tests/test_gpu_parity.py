@@ -224,3 +224,34 @@ def test_mf_host_api_batches_and_pieces(oracle_lib, batch_kb, piece_kb, network_
     got = matched_filter(tp, mv, w, data, 1, arch="gpu", network_sum=network_sum, check_zeros=False)
     want = oracle_lib.matched_filter(tp, mv, w, data, 1, network_sum=network_sum)
     _assert_same(got, want, f"host API batch {batch_kb} KB piece {piece_kb} KB")
+
+
+@pytest.mark.gpu
+def test_host_apis_split_work_over_a_device_list(oracle_lib):
+    """device=[...] block-partitions templates / sources over host threads, one per listed device
+    (the default None lists every visible GPU); listing the same GPU several times exercises the
+    split and the merge on a one-GPU box: results equal the single pass and the oracle, ties and the
+    (0, source 0) start included."""
+    from seismic_bpmf_amd import beamform, matched_filter
+    rng = np.random.default_rng(12)
+    T, S, C, L, N = 7, 3, 2, 50, 6000
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    data = rng.standard_normal((S, C, N)).astype(np.float32)
+    mv = rng.integers(0, 80, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    want = oracle_lib.matched_filter(tp, mv, w, data, 1)
+    for dev in (0, [0, 0], [0, 0, 0], [0] * 9, None):
+        got = matched_filter(tp, mv, w, data, 1, arch="gpu", device=dev, check_zeros=False)
+        _assert_same(got, want, f"MF device={dev}")
+    f, tau, wp, ws = _bp_case(rng, 301, 6, 3, 2, 4000, 120)
+    f = np.round(f * 2).astype(np.float32)           # exact ties across blocks
+    tau[200] = tau[20]; ws[200] = ws[20]             # identical sources in different blocks
+    f[:, :, :40] = 0.0                               # samples where no beam is positive
+    for oob in ("strict", "flexible"):
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        for dev in (0, [0, 0], [0, 0, 0, 0, 0], None):
+            mb, ma = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds=oob, device_id=dev)
+            _assert_same(mb, ob, f"BP beam device_id={dev} {oob}")
+            assert ma.dtype == np.int32 and np.array_equal(ma, oa), (dev, oob)
+    full = oracle_lib.beamform(f, tau, wp, ws, "strict", "none")
+    _assert_same(beamform(f, tau, wp, ws, device="gpu", reduce="none", device_id=[0, 0, 0]), full, "BP none split")
