@@ -35,6 +35,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+MF_LABEL = {"cfg1": "configs[0]", "cfg2": "configs[1]", "cfg4_per_gpu": "configs[3], one GPU's share (5000 templates / 8)"}
+BP_LABEL = {"cfg3": "configs[2]", "cfg5_per_gpu": "configs[4], one GPU's share (1M sources / 8)"}
 LDS_B32_PEAK_TBS = 256 * 128 * 2.4e9 / 1e12   # ds_read_b32: 128 B/clk/CU x 256 CU x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
@@ -408,7 +410,7 @@ def main():
                 bp_traffic = None
         bp_obj = {"metric": "grid-points x samples / s", "value": world * K_all * Nb * args.steps / bp_dt,
                   "ms_per_step": round(bp_dt / args.steps * 1e3, 3),
-                  "config": {"workload": f"BASELINE configs[2]: {K_all} sources x {bcfg['S']} stations x "
+                  "config": {"workload": f"BASELINE {BP_LABEL.get(args.bp_config, args.bp_config)}: {K_all} sources x {bcfg['S']} stations x "
                                          f"{bcfg['C']} comp x {bcfg['P']} phases, N={Nb} (1 day @ {bcfg['sr']:g} Hz), "
                                          f"{s_act:.1f} active stations/source, reduce=max, strict"},
                   "roofline": {"kernel": "bp_beam_wps2_kernel", "bound": "lds-gather", "achieved": round(gather_tbs, 2),
@@ -436,7 +438,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(mf_dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {T} templates x {S} stations x {C} comp, "
+            "config": {"workload": f"BASELINE {MF_LABEL.get(args.mf_config, args.mf_config)}: {T} templates x {S} stations x {C} comp, "
                                    f"L={L}, N={N} (1 day @ 100 Hz), step 1, per GPU",
                        "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
                        "parallelism": f"templates sharded x{world}" if world > 1 else "single GPU",
