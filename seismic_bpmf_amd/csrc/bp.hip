@@ -699,41 +699,58 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
 #pragma unroll
             for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
         }
-        if constexpr (SMETA) {
-            // not kept in flight across the staging below: once per group, nothing to hide
-            if (k_first <= k_last) { m0.issue(srcs4, recs, k_first); m0.wait(); }
-        } else {
-            m0.load(srcs4, recs, min(k_first, k_last), vzero);
-        }
+        if constexpr (!SMETA) m0.load(srcs4, recs, min(k_first, k_last), vzero);
         __syncthreads();  // previous group's gathers are done
-        for (int cb = 0; cb < grp.n_chunk; cb += 64) {
-            const int nb = min(64, grp.n_chunk - cb);
-            int4 d = make_int4(0, 0, 0, 0);
-            if (lane < nb) d = chunks[grp.first_chunk + cb + lane];
-            // 256-thread sub-groups take alternate blocks of 4 chunks; a trailing partial
-            // sub-group (WPB = 6) only computes
-            constexpr int NSUB = NTHREADS / 256;
-            for (int c = 4 * sub; c < nb && sub < NSUB; c += 4 * NSUB) {
-                int row[4], dd[4], n[4];
-                long long gi[4];
+        // Staging, one chunk per wave and 16 bytes per lane: a chunk is <= 256 consecutive floats
+        // of one prestacked row (the plan cuts windows to multiples of 4 floats at 16-byte
+        // aligned LDS offsets), so it is one unaligned global_load_dwordx4 + one ds_write_b128
+        // per lane.  Each wave issues the loads of STG_R chunks before it writes any of them:
+        // a group of ~240 chunks is two memory round trips for the 16 waves, where the former
+        // 256-thread / 4-byte version paid fifteen (staging was 7 % of the kernel at cfg3 and a
+        // quarter at 80 station-phase rows).  Chunks that reach outside [0, N) -- the first and
+        // last tiles of a trace -- take a per-element path with zero fill.
+        {
+            constexpr int STG_R = WPB >= 16 ? 8 : 4;   // 12-wave workgroups run under an 80-VGPR cap
+            typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float f32x4v __attribute__((ext_vector_type(4)));
+            const int nck = grp.n_chunk;
+            for (int c0 = wv; c0 < nck; c0 += WPB * STG_R) {
+                int4 dsc[STG_R];
+                f32x4v v[STG_R];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = min(c + u, nb - 1);
-                    row[u] = lane_bcast(d.x, cc);
-                    gi[u] = t0 + lane_bcast(d.y, cc) + stid;
-                    dd[u] = lane_bcast(d.z, cc);
-                    n[u] = c + u < nb ? lane_bcast(d.w, cc) : 0;
+                for (int r = 0; r < STG_R; ++r) {
+                    const int c = c0 + r * WPB;
+                    // wave-uniform, but fetched with a vector load (index through the opaque zero):
+                    // eight descriptors in SGPRs on top of the metadata set make the compiler
+                    // spill in-flight scalar loads (tools/check_inflight.py)
+                    dsc[r] = chunks[grp.first_chunk + min(c, nck - 1) + vzero];
+                    if (c >= nck) dsc[r].w = 0;
                 }
-                float v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long gc = gi[u] < 0 ? 0 : (gi[u] >= N ? N - 1 : gi[u]);
-                    v[u] = U[(size_t)row[u] * (size_t)N + gc];
+                for (int r = 0; r < STG_R; ++r) {
+                    const long long g0 = t0 + dsc[r].y;
+                    const float* src = U + (size_t)dsc[r].x * (size_t)N;
+                    v[r] = (f32x4v){0.0f, 0.0f, 0.0f, 0.0f};
+                    if (4 * lane < dsc[r].w) {
+                        if (g0 >= 0 && g0 + 256 <= N) {     // wave-uniform: whole chunk span inside
+                            v[r] = *(const f32x4u4*)(src + g0 + 4 * lane);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const long long gi = g0 + 4 * lane + e;
+                                if (gi >= 0 && gi < N) v[r][e] = src[gi];
+                            }
+                        }
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (stid < n[u]) lds[dd[u] + stid] = (gi[u] >= 0 && gi[u] < N) ? v[u] : 0.0f;
+                for (int r = 0; r < STG_R; ++r)
+                    if (4 * lane < dsc[r].w) *(f32x4v*)(lds + dsc[r].z + 4 * lane) = v[r];
             }
+        }
+        if constexpr (SMETA) {
+            // the first source's metadata: once per group, nothing to hide it behind
+            if (k_first <= k_last) { m0.issue(srcs4, recs, k_first); m0.wait(); }
         }
         __syncthreads();
 
@@ -1043,10 +1060,10 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                 int chunk, size_t soft_floats, const size_t hard_floats, int max_group, bool reorder,
                 int32_t id_offset, bool dual, PlanHost& ph)
 {
-    auto row_cost = [&](int spread) -> size_t {
-        const size_t len = (size_t)tile + (size_t)spread;
-        return dual ? 2 * ((len + 1) & ~(size_t)1) : len;
-    };
+    // a window is staged in 16-byte lanes: its length is rounded up to a multiple of 4 floats
+    // (the extra samples are real data or zero fill, never addressed by a term)
+    auto row_len = [&](int spread) -> size_t { return ((size_t)tile + (size_t)spread + 3) & ~(size_t)3; };
+    auto row_cost = [&](int spread) -> size_t { return dual ? 2 * row_len(spread) : row_len(spread); };
     const size_t SP = S * P;
     std::vector<int> order(K);
     for (size_t k = 0; k < K; ++k) order[k] = (int)k;
@@ -1132,16 +1149,15 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
         for (size_t r = 0; r < SP; ++r) {
             base[r] = -1;
             if (!used[r]) continue;
-            const int len = tile + (gmax[r] - gmin[r]);
+            const int len = (int)row_len(gmax[r] - gmin[r]);
             base[r] = (int)o;
             for (int x0 = 0; x0 < len; x0 += BP_THREADS)
                 ph.chunks.push_back(BpChunk{(int)r, gmin[r] + x0, (int)o + x0,
                                             std::min(BP_THREADS, len - x0)});
-            if (dual) {  // the copy shifted by one sample, right behind (both bases even)
-                const int half = (int)(row_cost(gmax[r] - gmin[r]) / 2);
-                for (int x0 = 0; x0 < len - 1; x0 += BP_THREADS)
-                    ph.chunks.push_back(BpChunk{(int)r, gmin[r] + 1 + x0, (int)o + half + x0,
-                                                std::min(BP_THREADS, len - 1 - x0)});
+            if (dual) {  // the copy shifted by one sample, right behind (both bases multiples of 4)
+                for (int x0 = 0; x0 < len; x0 += BP_THREADS)
+                    ph.chunks.push_back(BpChunk{(int)r, gmin[r] + 1 + x0, (int)o + len + x0,
+                                                std::min(BP_THREADS, len - x0)});
             }
             o += row_cost(gmax[r] - gmin[r]);
         }
@@ -1160,7 +1176,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
                     const size_t r = s * P + p;
                     const int rel = mv[(k * S + s) * P + p] - gmin[r];
                     if (dual && (rel & 1))
-                        ph.off[qq * NT + j] = base[r] + (int)(row_cost(gmax[r] - gmin[r]) / 2) + rel - 1;
+                        ph.off[qq * NT + j] = base[r] + (int)row_len(gmax[r] - gmin[r]) + rel - 1;
                     else
                         ph.off[qq * NT + j] = base[r] + rel;
                     ph.beta[qq * NT + j] = ws[k * S + s];
