@@ -701,6 +701,10 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
         }
         if constexpr (!SMETA) m0.load(srcs4, recs, min(k_first, k_last), vzero);
         __syncthreads();  // previous group's gathers are done
+        // the first source's metadata travels while the windows are staged (the staging uses no
+        // scalar registers of its own, so nothing tempts the compiler to spill this set in flight:
+        // tools/check_inflight.py)
+        if constexpr (SMETA) { if (k_first <= k_last) m0.issue(srcs4, recs, k_first); }
         // Staging, one chunk per wave and 16 bytes per lane: a chunk is <= 256 consecutive floats
         // of one prestacked row (the plan cuts windows to multiples of 4 floats at 16-byte
         // aligned LDS offsets), so it is one unaligned global_load_dwordx4 + one ds_write_b128
@@ -748,10 +752,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                     if (4 * lane < dsc[r].w) *(f32x4v*)(lds + dsc[r].z + 4 * lane) = v[r];
             }
         }
-        if constexpr (SMETA) {
-            // the first source's metadata: once per group, nothing to hide it behind
-            if (k_first <= k_last) { m0.issue(srcs4, recs, k_first); m0.wait(); }
-        }
+        if constexpr (SMETA) { if (k_first <= k_last) m0.wait(); }
         __syncthreads();
 
         // Gathers of one station (2 phases x 8 samples = 8 ds_read2st64_b32) are inline asm with
