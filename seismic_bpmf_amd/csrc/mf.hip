@@ -11,9 +11,6 @@
 // evaluated with the exact-fp32 v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain; the band's
 // zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
-#ifndef MF_ABLATE
-#define MF_ABLATE 0   // bits: 1 trivial epilogue, 2 no staging loads, 4 no K loop, 8 no norm loads, 16 plain grid order
-#endif
 #include <thread>
 #include <chrono>
 #include <vector>
@@ -257,11 +254,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate_unused, int t_batch, int n_lag_blocks)
+    float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
 {
-    (void)ablate_unused;
-    constexpr int ablate = MF_ABLATE;   // phase ablations are compile-time (-DMF_ABLATE=bits): a runtime
-                                        // test costs VALU/SALU in every channel
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
     const int tp_len = mf_band_len(L);
@@ -525,10 +519,8 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate_unused, int n_lag_blocks)
+    float* __restrict__ out, int ablate, int n_lag_blocks)
 {
-    (void)ablate_unused;
-    constexpr int ablate = MF_ABLATE;   // compile-time, see mf_mfma_kernel
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
     const int tp_len = mf_band_len(L);
@@ -632,8 +624,10 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
             if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
 
-            f32x4 acc[4];   // started by the first k-step (MF_MFMA_Z: C = 0), never zeroed with v_mov
-            const int nq = Kpad >> 4;
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const int nq = (ablate & 4) ? 0 : Kpad >> 4;
             unsigned ap = (unsigned)(size_t)(tp + a_base), bp = (unsigned)(size_t)(dw + b_base);
             float sa[4], sb[4][4];
             // counted waits as in mf_mfma_kernel; the ds_writes above are older than every read
@@ -674,45 +668,13 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     MF_LDS_READ(sb[req][2], bp, (boff) + 2304);                      \
     MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
     __builtin_amdgcn_sched_barrier(0)
-#define MF_MFMA_Z(slot, u) \
-    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0)
-#define MF_STEP_Z(cur, req, aoff, boff)                                \
-    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");               \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA_Z(cur, 0);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sa[req], ap, (aoff));                                \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA_Z(cur, 1);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][0], bp, (boff));                             \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA_Z(cur, 2);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][1], bp, (boff) + 1152);                      \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA_Z(cur, 3);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][2], bp, (boff) + 2304);                      \
-    MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
-    __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
-            // do-while: Kpad >= 16, so there is at least one trip, and a guarded loop makes the
-            // compiler zero the 16 accumulators twice (once more for the skipped-loop path)
-            // first trip peeled: its first k-step starts the accumulators from the constant 0
-            // (no v_mov zeroing: plain VALU instructions cost matrix-pipe issue time)
-            MF_STEP_Z(0, 2, 32, 32);
-            MF_STEP(1, 3, 48, 48);
-            MF_STEP(2, 0, 64, 72);   // requests k-step 0 of the next trip (past the end: slack)
-            MF_STEP(3, 1, 80, 88);
-            ap += 64;
-            bp += 72;
-            for (int q = 1; q < nq; ++q) {
+            for (int q = 0; q < nq; ++q) {
                 MF_STEP(0, 2, 32, 32);
                 MF_STEP(1, 3, 48, 48);
-                MF_STEP(2, 0, 64, 72);
+                MF_STEP(2, 0, 64, 72);   // requests k-step 0 of the next trip (past the end: slack)
                 MF_STEP(3, 1, 80, 88);
                 ap += 64;
                 bp += 72;
@@ -721,10 +683,8 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             __builtin_amdgcn_sched_barrier(0);
 #undef MF_LDS_READ
 #undef MF_MFMA
-#undef MF_MFMA_Z
 #undef MF_REQ
 #undef MF_STEP
-#undef MF_STEP_Z
 
             if (NETWORK_SUM && STEP1 && wave_inside && !(ablate & 1)) {
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
