@@ -253,6 +253,7 @@ def detection_stage(cc, planted, local_rank, dist, device):
     from seismic_bpmf_amd.threshold import ThresholdGPU
     th = ThresholdGPU(device=local_rank)
     window, overlap = 180_000, 0.25                       # 30 min @ 100 Hz
+    window = min(window, max(1000, cc.shape[1] // 8))     # short series (configs[0]): 8 windows
     wn = np.random.default_rng(5).standard_normal(500).astype(np.float32)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
