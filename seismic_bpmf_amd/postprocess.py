@@ -49,17 +49,186 @@ def normalize_weights(weights):
     return w / norm
 
 
+def normalize_templates(waveforms, method="rms"):
+    """TemplateGroup.normalize, BPMF/dataset.py:4152-4166: every (template, station, channel)
+    window divided by its standard deviation ("rms") or its peak amplitude ("max"); all-zero
+    windows stay zero."""
+    w = np.array(waveforms, dtype=np.float32, copy=True)
+    if method == "rms":
+        norm = np.std(w, axis=-1, keepdims=True)
+    elif method == "max":
+        norm = np.max(np.abs(w), axis=-1, keepdims=True)
+    else:
+        raise ValueError("method must be 'rms' or 'max'")
+    norm[norm == 0.0] = 1.0
+    w /= norm
+    return w
+
+
+def network_to_template_map(waveforms):
+    """BPMF/dataset.py:5001: a template channel counts as present unless its samples sum to 0."""
+    return ~(np.sum(np.asarray(waveforms), axis=-1) == 0.0)
+
+
+def station_density_weights(interstation_distances, cutoff_dist=None, lower_percentile=0.0,
+                            upper_percentile=100.0):
+    """Per-station weights that balance station density (BPMF/template_search.py:898-949, same
+    text at similarity_search.py:371-421): w_s = 1 / sum_j exp(-D_sj^2 / cutoff^2), cutoff = median
+    non-zero inter-station distance unless given, optionally clipped to percentiles.  Float64 sums
+    stored as float32, like the reference."""
+    D = np.asarray(interstation_distances, dtype=np.float64)
+    if cutoff_dist is None:
+        cutoff_dist = np.median(D[D != 0.0])
+    w = np.zeros(D.shape[0], dtype=np.float32)
+    for s in range(D.shape[0]):
+        w[s] = 1.0 / np.sum(np.exp(-(D[s] ** 2) / cutoff_dist ** 2))
+    if lower_percentile > 0.0:
+        w = np.clip(w, np.percentile(w, lower_percentile), w.max())
+    if upper_percentile < 100.0:
+        w = np.clip(w, w.min(), np.percentile(w, upper_percentile))
+    return w
+
+
+def _kth_smallest(mv, k):
+    """Largest of the k smallest values of every row (the reference's np.partition cut-off)."""
+    return np.partition(mv, k - 1, axis=1)[:, :k].max(axis=1, keepdims=True)
+
+
 def weights_sources_closest(moveouts, n_closest, online=None):
-    """Source weights of BP-4, BPMF/template_search.py:779-798: 1 for the `n_closest` stations
-    with the smallest first-phase moveout of each source (ties at the cut-off included), 0 for
-    offline stations."""
+    """Source weights of BP-4, BPMF/template_search.py:779-798: 1 for the stations whose
+    first-phase moveout is not larger than the `n_closest`-th smallest one *among the operational
+    stations* of each source (ties at the cut-off included), 0 for offline stations.  With
+    `n_closest` 0 or >= the number of stations every operational station keeps weight 1."""
     first = np.asarray(moveouts)[:, :, 0]
     K, S = first.shape
-    n_closest = min(int(n_closest), S)
-    cut = np.partition(first, n_closest - 1, axis=1)[:, n_closest - 1]
-    w = (first <= cut[:, None]).astype(np.float32)
+    online = np.ones(S, dtype=bool) if online is None else np.asarray(online, dtype=bool)
+    w = np.ones((K, S), dtype=np.float32)
+    n = min(int(online.sum()), int(n_closest))
+    if 0 < n < S:
+        w[first > _kth_smallest(first[:, online], n)] = 0.0
+    w[:, ~online] = 0.0
+    return w
+
+
+def weights_sources_max_moveout(moveouts, max_moveout, online=None):
+    """BPMF/template_search.py:800-814: 1 where the earliest phase of a station arrives less than
+    `max_moveout` samples after the source's first arrival, 0 for offline stations."""
+    earliest = np.min(np.asarray(moveouts), axis=-1)
+    w = np.zeros(earliest.shape, dtype=np.float32)
+    w[earliest < max_moveout] = 1.0
     if online is not None:
         w[:, ~np.asarray(online, dtype=bool)] = 0.0
+    return w
+
+
+def set_weights_sources(moveouts, method="closest_stations", n_min_stations=0, normalize=False,
+                        online=None, density_weights=None, **kwargs):
+    """Beamformer.set_weights_sources (BP-4), BPMF/template_search.py:816-895.
+
+    `online` replaces `data.availability_per_sta`; `density_weights` (S,) replaces the
+    `weight_station_density=True` branch (build it with station_density_weights)."""
+    if method == "closest_stations":
+        if kwargs.get("num_closest_stations") is None:
+            raise TypeError("method 'closest_stations' needs num_closest_stations")
+        w = weights_sources_closest(moveouts, kwargs["num_closest_stations"], online)
+    elif method == "max_moveout":
+        if kwargs.get("max_moveout") is None:
+            raise TypeError("method 'max_moveout' needs max_moveout")
+        w = weights_sources_max_moveout(moveouts, kwargs["max_moveout"], online)
+    else:
+        raise ValueError("method must be 'closest_stations' or 'max_moveout'")
+    if n_min_stations > 0:
+        w[np.sum(w > 0.0, axis=-1) < n_min_stations, :] = 0.0
+    if density_weights is not None:
+        w *= np.asarray(density_weights)[None, :]
+    if normalize:
+        norm = np.sum(w, axis=1, keepdims=True)
+        norm[norm == 0.0] = 1.0
+        w /= norm
+    return w
+
+
+def weights_channels_simple(present, min_channels=6, min_stations=3):
+    """MatchedFilter._weights_channels_simple, BPMF/similarity_search.py:288-296: weight 1 on
+    every present template channel; templates with fewer than `min_channels` channels or
+    `min_stations` stations get all-zero weights."""
+    w = np.float32(present)
+    too_few = (np.sum(w != 0.0, axis=(1, 2)) < min_channels) | \
+              (np.sum(np.sum(w, axis=2) > 0.0, axis=1) < min_stations)
+    w[too_few] = 0.0
+    return w
+
+
+def _operational(availability, data_channels_ok):
+    ok = np.asarray(availability, dtype=bool)
+    if data_channels_ok is not None:
+        ok = np.logical_and(ok, np.asarray(data_channels_ok, dtype=bool)[None, :, :])
+    return ok
+
+
+def weights_channels_closest(moveouts, availability, num_closest_stations, data_channels_ok=None):
+    """MatchedFilter._weights_channels_closest, BPMF/similarity_search.py:298-332.  Stations
+    without any operational channel are pushed to the end of the ranking; the cut-off is the
+    `num_closest_stations`-th smallest first-phase moveout; offline channels get 0."""
+    mv_all = np.asarray(moveouts)
+    T, S = mv_all.shape[:2]
+    ok = _operational(availability, data_channels_ok)
+    w = np.ones(ok.shape, dtype=np.float32)
+    first = np.array(mv_all[..., 0], copy=True)
+    first[~np.any(ok, axis=-1)] = np.iinfo(np.int32).max
+    n = min(S, int(num_closest_stations))
+    if 0 < n < S:
+        w[mv_all[:, :, 0] > _kth_smallest(first, n), :] = 0.0
+    w[~ok] = 0.0
+    return w
+
+
+def weights_channels_max_moveout(moveouts, availability, max_moveout_sec, sr, n_min_stations=0,
+                                 max_moveout2_sec=None, data_channels_ok=None):
+    """MatchedFilter._weights_channels_max_moveout, BPMF/similarity_search.py:334-367 (including
+    its fall-back: when fewer than `n_min_stations` (template, station) pairs qualify in total,
+    the second radius is applied without the availability mask)."""
+    ok = _operational(availability, data_channels_ok)
+    w = np.zeros(ok.shape, dtype=np.float32)
+    earliest = np.min(np.asarray(moveouts), axis=-1)
+    valid = (earliest < int(max_moveout_sec * sr)) & np.any(ok, axis=-1)
+    if np.sum(valid) < n_min_stations and max_moveout2_sec is not None:
+        valid = earliest < int(max_moveout2_sec * sr)
+    w[valid, :] = 1.0
+    w[~ok] = 0.0
+    return w
+
+
+def set_weights_channels(method="simple", n_min_stations=0, normalize=True, density_weights=None,
+                         *, present=None, moveouts=None, availability=None, sr=None,
+                         min_channels=6, min_stations=3, data_channels_ok=None, **kwargs):
+    """MatchedFilter.set_weights_channels (MF-6), BPMF/similarity_search.py:423-474.  The
+    template-group attributes the reference reads are passed explicitly: `present` =
+    network_to_template_map, `moveouts` = moveouts_arr (T,S,P), `availability` =
+    availability_arr (T,S,C), `sr` = template sampling rate."""
+    if method == "simple":
+        w = weights_channels_simple(present, min_channels, min_stations)
+    elif method == "closest_stations":
+        if kwargs.get("num_closest_stations") is None:
+            raise TypeError("method 'closest_stations' needs num_closest_stations")
+        w = weights_channels_closest(moveouts, availability, kwargs["num_closest_stations"],
+                                     data_channels_ok)
+    elif method == "max_moveout":
+        if kwargs.get("max_moveout_sec") is None:
+            raise TypeError("method 'max_moveout' needs max_moveout_sec")
+        w = weights_channels_max_moveout(moveouts, availability, kwargs["max_moveout_sec"], sr,
+                                         n_min_stations, kwargs.get("max_moveout2_sec"),
+                                         data_channels_ok)
+    else:
+        raise ValueError("method must be 'simple', 'closest_stations' or 'max_moveout'")
+    if n_min_stations > 0:
+        w[np.sum(np.any(w > 0.0, axis=-1), axis=1) < n_min_stations, :] = 0.0
+    if density_weights is not None:
+        w *= np.asarray(density_weights)[None, :, None]
+    if normalize:
+        norm = np.sum(w, axis=(1, 2), keepdims=True)
+        norm[norm == 0.0] = 1.0
+        w /= norm
     return w
 
 

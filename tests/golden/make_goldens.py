@@ -229,6 +229,158 @@ def main():
                     f"availability_{j}": np.asarray(avail, dtype=np.int32),
                     f"envelope_{j}": np.float32([template_search.envelope(x_) for x_ in tr.reshape(-1, n)]).reshape(tr.shape)})
     np.savez_compressed(os.path.join(HERE, "saturated_envelopes.npz"), n_cases=2, **env)
+    # ---- BP-4: Beamformer source-weight builders (template_search.py:779-895) ---------------
+    # and MF-6: MatchedFilter channel-weight builders / set_data / TemplateGroup.normalize
+    # (similarity_search.py:163-185, 288-474; dataset.py:4152-4166, 4996-5001), through fake
+    # `self` objects that carry only the attributes those methods read.
+    import pandas as pd
+    import types
+
+    def density_frame(names, rng_):
+        xy = rng_.uniform(0.0, 80.0, (len(names), 2))
+        d = np.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1))
+        return pd.DataFrame(d, index=names, columns=names)
+
+    wts = {}
+    K, S, P = 400, 9, 2
+    names = [f"S{j:02d}" for j in range(S)]
+    mv_bp = rng.integers(0, 900, (K, S, P)).astype(np.int64)
+    mv_bp[:, :, 1] += mv_bp[:, :, 0] // 2
+    mv_bp[::7, 3, 0] = mv_bp[::7, 5, 0]                        # exact ties at the cut-off
+    mv_bp -= mv_bp.reshape(K, -1).min(axis=1)[:, None, None]
+    online = np.ones(S, dtype=bool)
+    online[[2, 6]] = False
+    dist_bp = density_frame(names, rng)
+
+    class _BF:
+        pass
+    for name in ("_weights_sources_closest", "_weights_sources_max_moveout", "set_weights_sources",
+                 "_station_density_weights"):
+        setattr(_BF, name, getattr(template_search.Beamformer, name))
+
+    def fake_bf(with_availability):
+        bf = _BF()
+        bf.n_sources, bf.n_stations, bf.stations, bf.moveouts = K, S, names, mv_bp
+        bf.network = types.SimpleNamespace(n_stations=S, stations=names,
+                                           interstation_distances=dist_bp)
+        bf.data = types.SimpleNamespace(set_availability=lambda stations: None)
+        if with_availability:
+            bf.data.availability = True
+            bf.data.availability_per_sta = pd.Series(online, index=names)
+        return bf
+
+    wts.update(bp_moveouts=mv_bp, bp_online=online, bp_dist=dist_bp.values)
+    bp_cases = [
+        dict(avail=False, kw=dict(method="closest_stations", num_closest_stations=4)),
+        dict(avail=True, kw=dict(method="closest_stations", num_closest_stations=4)),
+        dict(avail=True, kw=dict(method="closest_stations", num_closest_stations=8)),   # > online
+        dict(avail=True, kw=dict(method="closest_stations", num_closest_stations=0)),
+        dict(avail=True, kw=dict(method="closest_stations", num_closest_stations=5, normalize=True,
+                                 n_min_stations=5)),
+        dict(avail=True, kw=dict(method="max_moveout", max_moveout=350.0, n_min_stations=3,
+                                 normalize=True)),
+        dict(avail=False, kw=dict(method="max_moveout", max_moveout=200.0)),
+        dict(avail=True, kw=dict(method="closest_stations", num_closest_stations=5,
+                                 weight_station_density=True, normalize=True)),
+        dict(avail=False, kw=dict(method="closest_stations", num_closest_stations=6,
+                                  weight_station_density=True, cutoff_dist=25.0,
+                                  lower_percentile=10.0, upper_percentile=80.0)),
+    ]
+    for j, c in enumerate(bp_cases):
+        bf = fake_bf(c["avail"])
+        bf.set_weights_sources(**c["kw"])
+        wts[f"bp_w_{j}"] = np.asarray(bf.weights_sources)
+        wts[f"bp_avail_{j}"] = c["avail"]
+        for k_, v_ in c["kw"].items():
+            wts[f"bp_kw_{j}_{k_}"] = v_
+    wts["bp_n_cases"] = len(bp_cases)
+    wts["bp_density_default"] = fake_bf(False)._station_density_weights()
+
+    T, S, C = 30, 8, 3
+    names = [f"N{j:02d}" for j in range(S)]
+    comps = ["N", "E", "Z"]
+    wav = rng.standard_normal((T, S, C, 64)).astype(np.float32)
+    wav[rng.random((T, S, C)) < 0.25] = 0.0                   # missing channels are zero-filled
+    wav[3] = 0.0
+    wav[4, 1:] = 0.0
+    n2t = ~(np.sum(wav, axis=-1) == 0.0)                      # dataset.py:5001
+    avail_arr = n2t.copy()
+    mv_mf = rng.integers(0, 700, (T, S, 2)).astype(np.int32)
+    mv_mf[::5, 2, 0] = mv_mf[::5, 4, 0]
+    cha_ok = pd.DataFrame(rng.random((S, C)) > 0.2, index=names, columns=comps)
+    dist_mf = density_frame(names, rng)
+
+    class _MF:
+        pass
+    for name in ("_weights_channels_simple", "_weights_channels_closest",
+                 "_weights_channels_max_moveout", "set_weights_channels",
+                 "_station_density_weights"):
+        setattr(_MF, name, getattr(similarity_search.MatchedFilter, name))
+
+    def fake_mf():
+        mf = _MF()
+        mf.min_channels, mf.min_stations = 6, 3
+        mf.template_group = types.SimpleNamespace(
+            network_to_template_map=n2t, n_templates=T, availability_arr=avail_arr,
+            stations=names, moveouts_arr=mv_mf.copy(), templates=[types.SimpleNamespace(sr=25.0)])
+        mf.network = types.SimpleNamespace(n_stations=S, n_components=C, stations=names,
+                                           interstation_distances=dist_mf)
+        mf.data = types.SimpleNamespace()
+        return mf
+
+    wts.update(mf_waveforms=wav, mf_moveouts=mv_mf, mf_availability=avail_arr, mf_dist=dist_mf.values,
+               mf_sr=25.0, mf_min_channels=6, mf_min_stations=3)
+    mf_cases = [
+        dict(method="simple"),
+        dict(method="simple", normalize=False, n_min_stations=5),
+        dict(method="closest_stations", num_closest_stations=4),
+        dict(method="closest_stations", num_closest_stations=4, n_min_stations=4, normalize=False),
+        dict(method="closest_stations", num_closest_stations=20),
+        dict(method="max_moveout", max_moveout_sec=12.0),
+        dict(method="max_moveout", max_moveout_sec=2.0, n_min_stations=40, max_moveout2_sec=20.0),
+        dict(method="closest_stations", num_closest_stations=5, weight_station_density=True),
+        dict(method="simple", weight_station_density=True, cutoff_dist=30.0, lower_percentile=20.0,
+             upper_percentile=90.0),
+    ]
+    for j, kw in enumerate(mf_cases):
+        mf = fake_mf()
+        mf.set_weights_channels(**kw)
+        wts[f"mf_w_{j}"] = np.asarray(mf.weights_channels)
+        for k_, v_ in kw.items():
+            wts[f"mf_kw_{j}_{k_}"] = v_
+    wts["mf_n_cases"] = len(mf_cases)
+    try:   # data-side channel availability: np.logical_and((T,S,C) ndarray, (S,C) DataFrame)
+        mf = fake_mf()
+        mf.data.availability_per_cha = cha_ok
+        mf.set_weights_channels(method="closest_stations", num_closest_stations=4)
+        wts["mf_w_cha"] = np.asarray(mf.weights_channels)
+        wts["mf_cha_ok"] = cha_ok.values
+    except Exception as exc:  # the reference itself cannot run this combination
+        print("  (reference fails with data.availability_per_cha:", type(exc).__name__, exc, ")")
+
+    # set_data conditioning and TemplateGroup.normalize
+    class _SD:
+        pass
+    _SD.set_data = similarity_search.MatchedFilter.set_data
+    d_arr = rng.standard_normal((S, C, 5000)).astype(np.float32) * rng.uniform(0.1, 30, (S, C, 1)).astype(np.float32)
+    d_arr[2, 1] = 0.0
+    sd = _SD()
+    sd.stations, sd.components, sd.normalize = names, comps, True
+    sd.offset_win_peak_amp_sec, sd.duration_win_peak_amp_sec = 1.0, 3.0
+    sd.set_data(types.SimpleNamespace(sr=25.0, get_np_array=lambda st, components=None: d_arr.copy()))
+    wts.update(sd_data=d_arr, sd_data_arr=np.asarray(sd.data_arr), sd_data_norm=np.asarray(sd.data_norm))
+
+    class _TG:
+        pass
+    _TG.normalize = BPMF.dataset.TemplateGroup.normalize
+    for method in ("rms", "max"):
+        tg = _TG()
+        tg.waveforms_arr = tg._waveforms_arr = wav.copy()
+        tg._remember = lambda name: None
+        tg.normalize(method=method)
+        wts[f"tg_norm_{method}"] = np.asarray(tg._waveforms_arr)
+    np.savez_compressed(os.path.join(HERE, "weights.npz"), **wts)
+
     print("goldens written to", HERE)
     for fn in sorted(os.listdir(HERE)):
         if fn.endswith(".npz"):

@@ -165,3 +165,61 @@ def test_fast_peak_suppression_equals_the_reference_loop():
         got = pp._suppress(ind, rank, mpd)
         assert np.array_equal(got, want), (trial, n, mpd)
         assert np.array_equal(pp.detect_peaks(x, mpd=mpd), ind[want])
+
+
+# ------------------------------------------------------------------ BP-4 / MF-6 weight builders ---
+def _kwargs(g, prefix, j):
+    pre = f"{prefix}_kw_{j}_"
+    return {k[len(pre):]: g[k].item() for k in g.files if k.startswith(pre)}
+
+
+def test_weights_sources_match_reference():
+    """Beamformer.set_weights_sources and its two builders (template_search.py:779-895), with and
+    without offline stations, ties at the cut-off, n_min_stations, density weights, normalisation."""
+    g = load("weights.npz")
+    mv, online, dist = g["bp_moveouts"], g["bp_online"], g["bp_dist"]
+    for j in range(int(g["bp_n_cases"])):
+        kw = _kwargs(g, "bp", j)
+        dens = None
+        if kw.pop("weight_station_density", False):
+            dens = pp.station_density_weights(dist, kw.pop("cutoff_dist", None),
+                                              kw.pop("lower_percentile", 0.0),
+                                              kw.pop("upper_percentile", 100.0))
+        w = pp.set_weights_sources(mv, online=online if bool(g[f"bp_avail_{j}"]) else None,
+                                   density_weights=dens, **kw)
+        assert w.dtype == np.float32 and np.array_equal(w, g[f"bp_w_{j}"]), (j, kw)
+    assert np.array_equal(pp.station_density_weights(dist), g["bp_density_default"])
+    # the cut-off is taken over the operational stations only (template_search.py:786-795)
+    w = pp.weights_sources_closest(mv, 4, online)
+    assert (w[:, ~online] == 0).all() and (w.sum(axis=1) >= 4).all()
+
+
+def test_weights_channels_match_reference():
+    """MatchedFilter.set_weights_channels and its three builders (similarity_search.py:288-474)."""
+    g = load("weights.npz")
+    wav, mv, avail, dist = g["mf_waveforms"], g["mf_moveouts"], g["mf_availability"], g["mf_dist"]
+    present = pp.network_to_template_map(wav)
+    common = dict(present=present, moveouts=mv, availability=avail, sr=float(g["mf_sr"]),
+                  min_channels=int(g["mf_min_channels"]), min_stations=int(g["mf_min_stations"]))
+    for j in range(int(g["mf_n_cases"])):
+        kw = _kwargs(g, "mf", j)
+        dens = None
+        if kw.pop("weight_station_density", False):
+            dens = pp.station_density_weights(dist, kw.pop("cutoff_dist", None),
+                                              kw.pop("lower_percentile", 0.0),
+                                              kw.pop("upper_percentile", 100.0))
+        w = pp.set_weights_channels(density_weights=dens, **common, **kw)
+        assert w.dtype == np.float32 and np.array_equal(w, g[f"mf_w_{j}"]), (j, kw)
+    if "mf_w_cha" in g.files:
+        w = pp.set_weights_channels(method="closest_stations", num_closest_stations=4,
+                                    data_channels_ok=g["mf_cha_ok"], **common)
+        assert np.array_equal(w, g["mf_w_cha"])
+
+
+def test_input_conditioning_matches_reference():
+    """MatchedFilter.set_data (similarity_search.py:181-185) and TemplateGroup.normalize
+    (dataset.py:4152-4166)."""
+    g = load("weights.npz")
+    assert np.array_equal(pp.normalize_data(g["sd_data"]), g["sd_data_arr"])
+    for method in ("rms", "max"):
+        assert np.array_equal(pp.normalize_templates(g["mf_waveforms"], method), g[f"tg_norm_{method}"])

@@ -1,0 +1,157 @@
+// Micro-benchmark #2 of the BP gather loop (round 2): the address of a unit comes from SALU only
+// (as in the beam kernel: one SGPR offset + one v_add per unit), so that the loop body is exactly
+// what the kernel issues.  One workgroup per CU, WPB waves, LDS 140 KB.
+//   KIND 0: 4 ds_read_b64 per unit, s_waitcnt lgkmcnt(12) per unit (ring of 4 units), no fma
+//   KIND 1: KIND 0 + 4 v_pk_fma_f32 (SGPR-pair weight)              -- the production loop
+//   KIND 2: reads only, one s_waitcnt lgkmcnt(0) per 4 units (16 reads per wait)
+//   KIND 3: KIND 1 with 8 plain v_fma_f32 instead of 4 v_pk_fma_f32
+//   KIND 4: 2 ds_read_b128 per unit + 4 v_pk_fma_f32 (what 16-byte aligned gathers would give)
+//   KIND 5: 8 ds_read_b64 per unit (16 samples per lane), ring of 2 units, + 8 v_pk_fma_f32
+//   KIND 6: KIND 1 + every 20 units an epilogue of 8 v_cmp + 16 v_cndmask (the max/arg-max update)
+//   KIND 7: KIND 6 with the epilogue as 8 v_max_f32 + 8 v_cmp + 8 v_cndmask ... same count, less deps
+//   KIND 8: KIND 1 without the per-unit v_add (address VGPR fixed; offsets immediate): issue floor
+//   KIND 9: fma only (4 v_pk_fma_f32 + v_add per unit)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define RD64(dst, addr, o) asm volatile("ds_read_b64 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
+#define RD128(dst, addr, o) asm volatile("ds_read_b128 %0, %1 offset:" #o : "=v"(dst) : "v"(addr))
+#define PKFMA_S(acc, sp, x) \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(sp), "v"(x))
+#define FMA_S(acc, s, x) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "s"(s), "v"(x))
+#define WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+template <int KIND, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int stride)
+{
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 35840; i += 64 * WPB) lds[i] = (float)(i & 15);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned base = (unsigned)(size_t)lds + lane * (KIND == 4 ? 16 : 8);
+    // scalar offset walk: even float offsets (8-byte aligned), 16-byte aligned for KIND 4
+    unsigned so = (unsigned)(wv * 1237 + blockIdx.x * 77) & 0x3ffeu;
+    i32x2 sp;
+    sp[0] = 0; sp[1] = __float_as_int(0.5f);
+    asm volatile("" : "+s"(sp));
+    f32x2 ac[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ac[j] = (f32x2){0, 0};
+    float best[8]; int arg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -1.0f; arg[j] = 0; }
+
+    if constexpr (KIND == 5) {
+        f32x2 X[2][8];
+#define ISSUE5(u) { so = (so + stride) & 0x3ffeu; const unsigned a_ = base + so * 4; \
+        RD64(X[u][0], a_, 0); RD64(X[u][1], a_, 512); RD64(X[u][2], a_, 1024); RD64(X[u][3], a_, 1536); \
+        RD64(X[u][4], a_, 2048); RD64(X[u][5], a_, 2560); RD64(X[u][6], a_, 3072); RD64(X[u][7], a_, 3584); }
+#define FMA5(u) { _Pragma("unroll") for (int j = 0; j < 8; ++j) PKFMA_S(ac[j], sp, X[u][j]); }
+        ISSUE5(0)
+        for (int i = 0; i < n_units; i += 2) {
+            ISSUE5(1) WAIT(8); FMA5(0)
+            ISSUE5(0) WAIT(8); FMA5(1)
+        }
+        WAIT(0); FMA5(0)
+    } else if constexpr (KIND == 4) {
+        f32x4 X[4][2];
+#define ISSUE4(u) { so = (so + stride) & 0x3ffcu; const unsigned a_ = base + so * 4; \
+        RD128(X[u][0], a_, 0); RD128(X[u][1], a_, 1024); }
+#define FMA4(u) { f32x2 lo0 = {X[u][0][0], X[u][0][1]}, hi0 = {X[u][0][2], X[u][0][3]}, lo1 = {X[u][1][0], X[u][1][1]}, hi1 = {X[u][1][2], X[u][1][3]}; \
+        PKFMA_S(ac[0], sp, lo0); PKFMA_S(ac[1], sp, hi0); PKFMA_S(ac[2], sp, lo1); PKFMA_S(ac[3], sp, hi1); }
+        ISSUE4(0) ISSUE4(1) ISSUE4(2)
+        for (int i = 0; i < n_units; i += 4) {
+            ISSUE4(3) WAIT(6); FMA4(0)
+            ISSUE4(0) WAIT(6); FMA4(1)
+            ISSUE4(1) WAIT(6); FMA4(2)
+            ISSUE4(2) WAIT(6); FMA4(3)
+        }
+        WAIT(0); FMA4(0) FMA4(1) FMA4(2)
+    } else {
+        f32x2 X[4][4];
+#define ISSUE(u) { so = (so + stride) & 0x3ffeu; unsigned a_ = base; if (KIND != 8) a_ = base + so * 4; else asm volatile("" : "+v"(a_)); \
+        if (KIND != 9) { RD64(X[u][0], a_, 0); RD64(X[u][1], a_, 512); RD64(X[u][2], a_, 1024); RD64(X[u][3], a_, 1536); } \
+        else asm volatile("" :: "v"(a_)); }
+#define FMA(u) { if (KIND == 0 || KIND == 2) asm volatile("" :: "v"(X[u][0]), "v"(X[u][1]), "v"(X[u][2]), "v"(X[u][3])); \
+        else if (KIND == 3) { _Pragma("unroll") for (int j = 0; j < 4; ++j) { FMA_S(ac[j][0], sp[1], X[u][j][0]); FMA_S(ac[j][1], sp[1], X[u][j][1]); } } \
+        else { _Pragma("unroll") for (int j = 0; j < 4; ++j) PKFMA_S(ac[j], sp, X[u][j]); } }
+#define W12 { if (KIND != 2 && KIND != 9) WAIT(12); }
+        if (KIND == 9) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) X[u][j] = (f32x2){1.f, 2.f};
+        }
+        ISSUE(0) ISSUE(1) ISSUE(2)
+        int since = 0;
+        for (int i = 0; i < n_units; i += 4) {
+            ISSUE(3) W12 if (KIND == 2) WAIT(0); FMA(0)
+            ISSUE(0) W12 FMA(1)
+            ISSUE(1) W12 FMA(2)
+            ISSUE(2) W12 FMA(3)
+            if (KIND == 6 || KIND == 7) {
+                since += 4;
+                if (since == 20) {  // wave-uniform: one "source" done
+                    since = 0;
+                    const int sid = i;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float a = ac[j >> 1][j & 1];
+                        if (KIND == 6) {
+                            const bool take = a > best[j];
+                            best[j] = take ? a : best[j];
+                            arg[j] = take ? sid : arg[j];
+                        } else {
+                            const bool take = a > best[j];
+                            best[j] = fmaxf(a, best[j]);
+                            arg[j] = take ? sid : arg[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ac[j] = (f32x2){0, 0};
+                }
+            }
+        }
+        WAIT(0);
+        FMA(0) FMA(1) FMA(2)
+    }
+    float r = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += ac[j][0] + ac[j][1] + best[j] + (float)arg[j];
+    out[blockIdx.x * 64 * WPB + threadIdx.x] = r;
+}
+
+template <int KIND, int WPB>
+void run(int stride)
+{
+    float* d; hipMalloc(&d, 256 * 2048 * sizeof(float));
+    const int n = 200000;
+    hipFuncSetAttribute((const void*)k<KIND, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, 1000, stride);
+    hipEventRecord(e0);
+    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, n, stride);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per_unit = (KIND == 5 ? 8 : 4) * 512.0;   // bytes gathered per unit and wave
+    const double bytes = 256.0 * WPB * (double)n * per_unit;
+    printf("kind %d, %2d waves/CU, stride %4d: %.1f TB/s gathered (%.1f%% of 157.3), %.1f ms\n", KIND, WPB, stride,
+           bytes / ms / 1e9, bytes / ms / 1e9 / 157.3 * 100, ms);
+    fflush(stdout);
+    hipFree(d);
+}
+int main()
+{
+    const int st = 338;
+    run<0, 16>(st); run<1, 16>(st); run<2, 16>(st); run<3, 16>(st); run<4, 16>(st); run<5, 16>(st);
+    run<6, 16>(st); run<7, 16>(st); run<8, 16>(st); run<9, 16>(st);
+    run<0, 8>(st); run<1, 8>(st); run<4, 8>(st); run<5, 8>(st);
+    run<0, 20>(st); run<1, 20>(st); run<6, 20>(st);
+    run<0, 24>(st); run<1, 24>(st); run<6, 24>(st);
+    run<1, 12>(st); run<4, 4>(st); run<4, 12>(st);
+    return 0;
+}
