@@ -87,6 +87,15 @@ int bpmf_mf_run(const float *templates, const int32_t *moveouts, const float *we
                 size_t C, size_t n_corr, int network_sum, int flags, int device,
                 float *cc_out);
 
+/* The same call with the templates block-partitioned over several GPUs inside the library
+ * (one host thread per device, the whole `data` copied to each, no traffic between devices):
+ * what upstream's `arch="gpu"` back-end does with every visible device.
+ *   n_devices <= 0: all visible devices; devices == NULL: devices 0 .. n_devices-1. */
+int bpmf_mf_run_multi(const float *templates, const int32_t *moveouts, const float *weights,
+                      const float *data, size_t step, size_t L, size_t N, size_t T, size_t S,
+                      size_t C, size_t n_corr, int network_sum, int flags, int n_devices,
+                      const int *devices, float *cc_out);
+
 /* ------------------------------------------------------------ backprojection --- */
 /*
  * Serves beampower.beampower.beamform(waveform_features, moveouts, weights_phases,
@@ -133,6 +142,15 @@ int bpmf_bp_run_dev(const bpmf_bp_plan *plan, const float *d_features,
 int bpmf_bp_run(const float *features, const int32_t *moveouts, const float *w_phases,
                 const float *w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
                 int out_of_bounds, int reduce, int device, float *beam_out, int32_t *arg_out);
+
+/* The same call with the source grid block-partitioned over several GPUs inside the library.
+ * reduce max: the per-device maxima are merged on the host in ascending block order with a
+ * strict >, so ties keep the lowest source index exactly like one sequential scan;
+ * reduce none: every device fills its own rows of beam_out.  n_devices / devices as above. */
+int bpmf_bp_run_multi(const float *features, const int32_t *moveouts, const float *w_phases,
+                      const float *w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
+                      int out_of_bounds, int reduce, int n_devices, const int *devices,
+                      float *beam_out, int32_t *arg_out);
 
 /* Multi-GPU exchange step of reduce="max": pack (beam, source id) into one uint64 whose
  * unsigned order is (beam ascending, then source id DEscending), so that an RCCL

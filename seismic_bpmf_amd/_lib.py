@@ -37,6 +37,10 @@ SIGNATURES = {
                                   C.c_int, _vp, _sz, _vp, _vp]),
     "bpmf_mf_run": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int,
                               C.c_int, _f]),
+    "bpmf_mf_run_multi": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int,
+                                    C.c_int, C.POINTER(C.c_int), _f]),
+    "bpmf_bp_run_multi": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int), _f, _i]),
     "bpmf_bp_plan_create": (C.c_int, [_i, _f, _sz, _sz, _sz, C.c_int, C.c_int32, C.POINTER(_vp)]),
     "bpmf_kurtosis_dev": (C.c_int, [_vp, C.c_int, _sz, _sz, _vp, _vp]),
     "bpmf_suppress_peaks": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), _sz, C.c_double,

@@ -49,9 +49,10 @@ def beamform(waveform_features, time_delays, weights_phases, weights_sources, de
     """Shift-and-stack beam power over a grid of sources (see module docstring).
 
     ``device_id``: None (default) = all visible GPUs, the source grid block-partitioned among them
-    (one host thread per GPU) and, for ``reduce="max"``, the per-GPU maxima merged in block order with
-    a strict ``>`` -- blocks hold ascending source indices, so ties keep the lowest index exactly
-    like a single pass; an int or a list selects devices."""
+    inside the library (``bpmf_bp_run_multi``: one host thread per GPU) and, for ``reduce="max"``,
+    the per-GPU maxima merged in block order with a strict ``>`` -- blocks hold ascending source
+    indices, so ties keep the lowest index exactly like a single pass; an int or a list selects
+    devices."""
     del num_threads  # CPU-only knob of the reference; accepted for call compatibility
     if str(device).lower() not in GPU_DEVICES:
         raise ValueError(
@@ -63,47 +64,25 @@ def beamform(waveform_features, time_delays, weights_phases, weights_sources, de
         raise ValueError("reduce should be 'max' or 'none'")
     if out_of_bounds not in _OOB:
         raise ValueError("out_of_bounds should be 'strict' or 'flexible'")
-    from .matched_filter import _device_list, _run_blocks
+    from .matched_filter import _device_array, _device_list
     f, mv, wp, ws = _check_shapes(waveform_features, time_delays, weights_phases, weights_sources)
     S, Cc, N = f.shape
     K, _, P = mv.shape
     pf, pi = _lib._f, _lib._i
     lib = _lib.lib()
-    devices = _device_list(device_id)
+    n_dev, dev_arr = _device_array(_device_list(device_id))
     if reduce == "none":
         beam = np.empty((K, N), dtype=np.float32)
-        dummy = np.empty(1, dtype=np.int32)
-
-        def block(lo, hi, dev):
-            rc = lib.bpmf_bp_run(f.ctypes.data_as(pf), mv[lo:hi].ctypes.data_as(pi), wp.ctypes.data_as(pf),
-                                 ws[lo:hi].ctypes.data_as(pf), N, hi - lo, S, Cc, P, _OOB[out_of_bounds],
-                                 _REDUCE[reduce], dev, beam[lo:hi].ctypes.data_as(pf), dummy.ctypes.data_as(pi))
-            _lib.check(rc, "bpmf_bp_run")
-
-        _run_blocks(K, devices, block)
-        return beam
-    parts = {}
-
-    def block(lo, hi, dev):
-        b = np.empty(N, dtype=np.float32)
-        a = np.empty(N, dtype=np.int32)
-        rc = lib.bpmf_bp_run(f.ctypes.data_as(pf), mv[lo:hi].ctypes.data_as(pi), wp.ctypes.data_as(pf),
-                             ws[lo:hi].ctypes.data_as(pf), N, hi - lo, S, Cc, P, _OOB[out_of_bounds],
-                             _REDUCE[reduce], dev, b.ctypes.data_as(pf), a.ctypes.data_as(pi))
-        _lib.check(rc, "bpmf_bp_run")
-        parts[lo] = (b, a)
-
-    _run_blocks(K, devices, block)
-    beam = arg = None
-    for lo in sorted(parts):           # ascending source blocks: strict > keeps the lowest index on ties
-        b, a = parts[lo]
-        if beam is None:
-            beam, arg = b, a           # block 0 carries the (0, source 0) starting point
-            continue
-        take = b > beam
-        beam = np.where(take, b, beam)
-        arg = np.where(take, a + np.int32(lo), arg).astype(np.int32)
-    return beam, arg
+        arg = None
+    else:
+        beam = np.empty(N, dtype=np.float32)
+        arg = np.empty(N, dtype=np.int32)
+    rc = lib.bpmf_bp_run_multi(f.ctypes.data_as(pf), mv.ctypes.data_as(pi), wp.ctypes.data_as(pf),
+                               ws.ctypes.data_as(pf), N, K, S, Cc, P, _OOB[out_of_bounds],
+                               _REDUCE[reduce], n_dev, dev_arr, beam.ctypes.data_as(pf),
+                               arg.ctypes.data_as(pi) if arg is not None else None)
+    _lib.check(rc, "bpmf_bp_run_multi")
+    return beam if reduce == "none" else (beam, arg)
 
 
 class BeamformerGPU:

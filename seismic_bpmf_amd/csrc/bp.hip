@@ -1267,7 +1267,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         set_error("bpmf_bp_plan_create: %d station-phase terms per source (max 256)", ph.NT);
         return -1;
     }
-    BPMF_HIP_CHECK(hipSetDevice(device));
+    BPMF_BIND_DEVICE(device);
     bpmf_bp_plan* pl = new bpmf_bp_plan();
     pl->device = device;
     pl->K = K; pl->S = S; pl->P = P;
@@ -1618,10 +1618,23 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
 }
 
 namespace {
-struct PlanCacheEntry { uint64_t key; size_t K, S, P; int device; bpmf_bp_plan* pl; };
-PlanCacheEntry g_plan_cache[2] = {{0, 0, 0, 0, 0, nullptr}, {0, 0, 0, 0, 0, nullptr}};
-unsigned g_plan_cache_next = 0;
+// Plans kept by the host-pointer entry point, keyed by (device, shapes, both tables).  A hit
+// compares the tables themselves (host copies are kept while they are small; above 1 GiB a
+// second, independent 64-bit hash stands in).  One slot per visible device and one spare each, so
+// that a process driving every GPU of a node keeps all of its plans from one day to the next.
+struct PlanCacheEntry {
+    uint64_t key = 0, key2 = 0;
+    size_t K = 0, S = 0, P = 0;
+    int device = 0;
+    std::vector<int32_t> mv;    // empty: table too large to keep, (key, key2) decide
+    std::vector<float> ws;
+    bpmf_bp_plan* pl = nullptr;
+    uint64_t stamp = 0;         // last use (eviction = least recently used)
+};
+std::vector<PlanCacheEntry> g_plan_cache;
+uint64_t g_plan_cache_clock = 0;
 std::mutex g_plan_cache_mutex;
+constexpr size_t PLAN_KEEP_BYTES = (size_t)1 << 30;
 // 64-bit multiply-xorshift over the bytes of a table, 8 at a time (not cryptographic: a cache key)
 uint64_t hash_words(const void* p, size_t bytes, uint64_t seed)
 {
@@ -1639,6 +1652,12 @@ uint64_t hash_words(const void* p, size_t bytes, uint64_t seed)
     h = (h ^ w) * 0xc4ceb9fe1a85ec53ull;
     return h ^ (h >> 29);
 }
+size_t plan_cache_capacity()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) n = 1;
+    return (size_t)std::max(4, 2 * n);
+}
 }  // namespace
 
 extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const float* w_phases,
@@ -1650,28 +1669,74 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
         set_error("bpmf_bp_run: null pointer");
         return -1;
     }
+    // Every call binds its thread to `device` first: the plan cache below may skip
+    // bpmf_bp_plan_create, and a fresh host thread starts on device 0.
+    BPMF_BIND_DEVICE(device);
     // BPMF calls beamform once per day with the same moveout table and source weights
     // (template_search.py:549-558); building the plan costs 0.04 s for 50 000 sources but 3 s for a
-    // million, so the last plans are kept, keyed by a hash of both tables.
+    // million, so the last plans are kept.
     bpmf_bp_plan* pl = nullptr;
-    const uint64_t key = hash_words(moveouts, K * S * P * sizeof(int32_t), 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
-                         hash_words(w_sources, K * S * sizeof(float), 0xc2b2ae3d27d4eb4full + (uint64_t)device);
+    const size_t b_mv = K * S * P * sizeof(int32_t), b_wsrc = K * S * sizeof(float);
+    const uint64_t key = hash_words(moveouts, b_mv, 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
+                         hash_words(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full);
+    const uint64_t key2 = hash_words(moveouts, b_mv, 0x165667b19e3779f9ull) +
+                          hash_words(w_sources, b_wsrc, 0x27d4eb2f165667c5ull);
+    const bool keep_tables = b_mv + b_wsrc <= PLAN_KEEP_BYTES;
     {
         std::lock_guard<std::mutex> g(g_plan_cache_mutex);
-        for (auto& e : g_plan_cache)
-            if (e.pl && e.key == key && e.K == K && e.S == S && e.P == P && e.device == device) {
-                pl = e.pl;
-                e.pl = nullptr;            // taken out while in use; put back below
-                break;
-            }
+        for (auto& e : g_plan_cache) {
+            if (!e.pl || e.key != key || e.key2 != key2 || e.K != K || e.S != S || e.P != P ||
+                e.device != device)
+                continue;
+            if (!e.mv.empty() && (memcmp(e.mv.data(), moveouts, b_mv) != 0 ||
+                                  memcmp(e.ws.data(), w_sources, b_wsrc) != 0))
+                continue;
+            pl = e.pl;
+            e.pl = nullptr;            // taken out while in use; put back below
+            e.stamp = ~0ull;           // ... into this very slot (marks it as reserved)
+            break;
+        }
     }
     if (!pl)
         if (int rc = bpmf_bp_plan_create(moveouts, w_sources, K, S, P, device, 0, &pl)) return rc;
     auto release_plan = [&]() {
         std::lock_guard<std::mutex> g(g_plan_cache_mutex);
-        PlanCacheEntry& slot = g_plan_cache[g_plan_cache_next++ % 2];
-        if (slot.pl) bpmf_bp_plan_destroy(slot.pl);
-        slot = PlanCacheEntry{key, K, S, P, device, pl};
+        const size_t cap = plan_cache_capacity();
+        PlanCacheEntry* slot = nullptr;
+        for (auto& e : g_plan_cache)   // the slot this plan came from still holds its tables
+            if (!e.pl && e.stamp == ~0ull && e.key == key && e.key2 == key2 && e.device == device &&
+                e.K == K && e.S == S && e.P == P) {
+                e.pl = pl;
+                e.stamp = ++g_plan_cache_clock;
+                return;
+            }
+        for (auto& e : g_plan_cache)
+            if (!e.pl && e.stamp != ~0ull) { slot = &e; break; }
+        if (!slot && g_plan_cache.size() < cap) {
+            g_plan_cache.emplace_back();
+            slot = &g_plan_cache.back();
+        }
+        if (!slot) {
+            for (auto& e : g_plan_cache)
+                if (e.pl && (!slot || e.stamp < slot->stamp)) slot = &e;
+            if (!slot) {               // every slot reserved by a concurrent call: do not cache
+                bpmf_bp_plan_destroy(pl);
+                return;
+            }
+            bpmf_bp_plan_destroy(slot->pl);
+        }
+        slot->key = key; slot->key2 = key2;
+        slot->K = K; slot->S = S; slot->P = P;
+        slot->device = device;
+        slot->pl = pl;
+        slot->stamp = ++g_plan_cache_clock;
+        if (keep_tables) {
+            slot->mv.assign(moveouts, moveouts + K * S * P);
+            slot->ws.assign(w_sources, w_sources + K * S);
+        } else {
+            slot->mv.clear(); slot->mv.shrink_to_fit();
+            slot->ws.clear(); slot->ws.shrink_to_fit();
+        }
     };
     const size_t b_f = S * C * N * sizeof(float), b_wp = S * C * P * sizeof(float),
                  b_ws = bpmf_bp_workspace_bytes(pl, N, C),

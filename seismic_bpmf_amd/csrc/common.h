@@ -19,6 +19,29 @@ void profile_mark(int which, int edge, hipStream_t stream);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Binds the calling thread to `device` for the lifetime of the guard and restores the device
+// that was current before: a host entry point must not change the caller's (or torch's)
+// current device as a side effect.  ok() is false if either runtime call failed.
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device)
+    {
+        err_ = hipGetDevice(&prev_);
+        if (err_ == hipSuccess && prev_ != device) {
+            err_ = hipSetDevice(device);
+            switched_ = err_ == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched_) (void)hipSetDevice(prev_); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+    hipError_t error() const { return err_; }
+private:
+    int prev_ = 0;
+    bool switched_ = false;
+    hipError_t err_ = hipSuccess;
+};
+
 }  // namespace bpmf
 
 #define BPMF_HIP_CHECK(expr)                                                          \
@@ -32,3 +55,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
     } while (0)
 
 #define BPMF_LAUNCH_CHECK() BPMF_HIP_CHECK(hipGetLastError())
+
+#define BPMF_BIND_DEVICE(device)                 \
+    bpmf::DeviceGuard _device_guard(device);     \
+    BPMF_HIP_CHECK(_device_guard.error())

@@ -192,7 +192,7 @@ extern "C" int bpmf_find_similar_sources(const float* moveouts, const float* sou
                   n_stations_for_diff, method);
         return -1;
     }
-    BPMF_HIP_CHECK(hipSetDevice(device));
+    BPMF_BIND_DEVICE(device);
     // threshold^2 * n_diff exactly as the reference: (float)n * pow(threshold, 2) -> float
     const float thr2 = (float)((double)(float)n_stations_for_diff * ((double)threshold * (double)threshold));
     hipStream_t stream = nullptr;

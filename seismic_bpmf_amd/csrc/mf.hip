@@ -923,8 +923,11 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
     const char* mse = getenv("BPMF_MF_MAX_MFMA_STEP");
     const size_t max_mfma_step = mse ? (size_t)atoi(mse) : 64;  // beyond this the direct kernel wins
+    // (the MFMA kernels address the data through buffer descriptors with 32-bit byte offsets:
+    // traces of 2^30 samples or more take the generic kernel)
     const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
-                          need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull;
+                          need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
+                          N < ((size_t)1 << 30) - 8192;
     if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks / 8) lag blocks x T templates (mf_tile_of_block)
         dim3 grid((unsigned)(T * 8 * ((n_lag_blocks + 7) / 8)));
@@ -1025,7 +1028,7 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
         return -1;
     }
     if (int rc = mf_check_sizes(step, L, N, T, S, C, n_corr)) return rc;
-    BPMF_HIP_CHECK(hipSetDevice(device));
+    BPMF_BIND_DEVICE(device);
     const size_t n_ch = S * C;
     const size_t row_bytes = n_corr * (network_sum ? 1 : n_ch) * sizeof(float);   // per template
     // BPMF_MF_HOST_BATCH_KB / BPMF_MF_HOST_PIECE_KB: sizes of a batch's output and of a pinned piece

@@ -1,0 +1,177 @@
+// Multi-device host entry points: one call, host pointers in / host pointers out, the work
+// block-partitioned over several GPUs of the node from inside the library (one host thread per
+// device) -- what a ctypes binding of the reference's third-party back-ends would call with
+// `n_devices`.  Upstream's GPU back-ends split the same way inside one
+// process: templates (matched filter) or sources (backprojection) dealt to the devices, the whole
+// day of data copied to each.
+//
+//   matched filter  templates are independent: device d computes rows [t_d, t_{d+1}) of the CC
+//                   matrix straight into the caller's array; nothing crosses devices.
+//   backprojection  sources are independent up to the per-sample max / arg-max: device d scans
+//                   the sources [k_d, k_{d+1}); the per-device maxima are merged on the host in
+//                   ascending block order with a strict >, so that ties keep the lowest source
+//                   index exactly like one sequential scan (oracle/bpmf_oracle.c:bp_cpu).
+//                   reduce="none": device d writes rows [k_d, k_{d+1}) of the (K, N) beam.
+#include "common.h"
+#include "../../include/bpmf_hip.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+using bpmf::set_error;
+
+// Device list of a call: `devices` (n_devices entries) or, when it is NULL, 0 .. n_devices-1;
+// n_devices <= 0 = every visible device.  Never more devices than work items.
+int resolve_devices(int n_devices, const int* devices, size_t n_items, std::vector<int>& out,
+                    const char* who)
+{
+    int visible = 0;
+    hipError_t e = hipGetDeviceCount(&visible);
+    if (e != hipSuccess || visible < 1) {
+        set_error("%s: no HIP device visible (%s)", who, hipGetErrorString(e));
+        return -2;
+    }
+    if (n_devices <= 0) { n_devices = visible; devices = nullptr; }
+    out.clear();
+    for (int i = 0; i < n_devices; ++i) {
+        const int d = devices ? devices[i] : i;
+        if (d < 0 || d >= visible) {
+            set_error("%s: device %d out of range (%d visible)", who, d, visible);
+            return -1;
+        }
+        out.push_back(d);
+    }
+    if (out.size() > n_items) out.resize(std::max<size_t>(1, n_items));
+    return 0;
+}
+
+// balanced contiguous partition of range(n) into `parts` blocks
+std::vector<size_t> block_bounds(size_t n, size_t parts)
+{
+    std::vector<size_t> b(parts + 1, 0);
+    const size_t base = n / parts, rem = n % parts;
+    for (size_t i = 0; i < parts; ++i) b[i + 1] = b[i] + base + (i < rem ? 1 : 0);
+    return b;
+}
+
+// Run fn(block) for every block on its own host thread; the error text of a failing block is
+// thread-local to its thread, so it is carried back and re-raised on the caller's thread.
+template <typename Fn>
+int run_blocks(size_t n_blocks, Fn fn)
+{
+    std::vector<int> rc(n_blocks, 0);
+    std::vector<std::string> msg(n_blocks);
+    auto work = [&](size_t i) {
+        rc[i] = fn(i);
+        if (rc[i]) msg[i] = bpmf_last_error();
+    };
+    if (n_blocks == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < n_blocks; ++i) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < n_blocks; ++i)
+        if (rc[i]) {
+            set_error("%s", msg[i].c_str());
+            return rc[i];
+        }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bpmf_mf_run_multi(const float* templates, const int32_t* moveouts,
+                                 const float* weights, const float* data, size_t step, size_t L,
+                                 size_t N, size_t T, size_t S, size_t C, size_t n_corr,
+                                 int network_sum, int flags, int n_devices, const int* devices,
+                                 float* cc_out)
+{
+    if (!templates || !moveouts || !weights || !data || !cc_out || T == 0) {
+        set_error("bpmf_mf_run_multi: bad argument");
+        return -1;
+    }
+    std::vector<int> dev;
+    if (int rc = resolve_devices(n_devices, devices, T, dev, "bpmf_mf_run_multi")) return rc;
+    const std::vector<size_t> b = block_bounds(T, dev.size());
+    const size_t n_ch = S * C;
+    const size_t row = n_corr * (network_sum ? 1 : n_ch);   // floats of output per template
+    return run_blocks(dev.size(), [&](size_t i) -> int {
+        const size_t t0 = b[i], nt = b[i + 1] - b[i];
+        if (nt == 0) return 0;
+        return bpmf_mf_run(templates + t0 * n_ch * L, moveouts + t0 * n_ch, weights + t0 * n_ch, data,
+                           step, L, N, nt, S, C, n_corr, network_sum, flags, dev[i],
+                           cc_out + t0 * row);
+    });
+}
+
+extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
+                                 const float* w_phases, const float* w_sources, size_t N, size_t K,
+                                 size_t S, size_t C, size_t P, int out_of_bounds, int reduce,
+                                 int n_devices, const int* devices, float* beam_out,
+                                 int32_t* arg_out)
+{
+    if (!features || !moveouts || !w_phases || !w_sources || !beam_out || K == 0) {
+        set_error("bpmf_bp_run_multi: bad argument");
+        return -1;
+    }
+    if (reduce == BPMF_BP_REDUCE_MAX && !arg_out) {
+        set_error("bpmf_bp_run_multi: reduce=max needs an arg-max output");
+        return -1;
+    }
+    std::vector<int> dev;
+    if (int rc = resolve_devices(n_devices, devices, K, dev, "bpmf_bp_run_multi")) return rc;
+    const std::vector<size_t> b = block_bounds(K, dev.size());
+    if (reduce != BPMF_BP_REDUCE_MAX) {
+        return run_blocks(dev.size(), [&](size_t i) -> int {
+            const size_t k0 = b[i], nk = b[i + 1] - b[i];
+            if (nk == 0) return 0;
+            return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S,
+                               C, P, out_of_bounds, reduce, dev[i], beam_out + k0 * N, nullptr);
+        });
+    }
+    if (dev.size() == 1)
+        return bpmf_bp_run(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds,
+                           reduce, dev[0], beam_out, arg_out);
+    // block 0 writes into the caller's arrays, the others into scratch vectors
+    std::vector<std::vector<float>> pb(dev.size());
+    std::vector<std::vector<int32_t>> pa(dev.size());
+    for (size_t i = 1; i < dev.size(); ++i) { pb[i].resize(N); pa[i].resize(N); }
+    int rc = run_blocks(dev.size(), [&](size_t i) -> int {
+        const size_t k0 = b[i], nk = b[i + 1] - b[i];
+        if (nk == 0) return 0;
+        return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S, C,
+                           P, out_of_bounds, reduce, dev[i], i ? pb[i].data() : beam_out,
+                           i ? pa[i].data() : arg_out);
+    });
+    if (rc) return rc;
+    // Ascending source blocks and a strict >: block 0 carries the (0, source 0) starting point of
+    // the sequential scan, and a later block only replaces a value it beats.
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(16, hw ? hw / 2 : 4));
+    const std::vector<size_t> tb = block_bounds(N, N < (1u << 20) ? 1 : nth);
+    std::vector<std::thread> th;
+    auto merge = [&](size_t lo, size_t hi) {
+        for (size_t i = 1; i < dev.size(); ++i) {
+            if (b[i + 1] == b[i]) continue;
+            const float* bb = pb[i].data();
+            const int32_t* aa = pa[i].data();
+            const int32_t k0 = (int32_t)b[i];
+            for (size_t t = lo; t < hi; ++t)
+                if (bb[t] > beam_out[t]) { beam_out[t] = bb[t]; arg_out[t] = aa[t] + k0; }
+        }
+    };
+    if (tb.size() == 2) {
+        merge(0, N);
+    } else {
+        for (size_t q = 0; q + 1 < tb.size(); ++q) th.emplace_back(merge, tb[q], tb[q + 1]);
+        for (auto& t : th) t.join();
+    }
+    return 0;
+}

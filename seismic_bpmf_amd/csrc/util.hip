@@ -3,6 +3,7 @@
 #include "../../include/bpmf_hip.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace bpmf {
 
@@ -33,12 +34,17 @@ struct ProfileLog {
     int count = 0;    // launches recorded since the last reset
     bool open = false;
 };
-static bool g_profile = false;
+// The log is shared by every host thread that launches (the multi-device entry points run one
+// thread per GPU): all accesses go through g_profile_mutex.  The enable flag is read without the
+// lock on the fast path (a launch with profiling off takes no lock at all).
+static volatile bool g_profile = false;
 static ProfileLog g_log[BPMF_KERNEL_COUNT];
+static std::mutex g_profile_mutex;
 
 void profile_mark(int which, int edge, hipStream_t stream)
 {
     if (!g_profile || which < 0 || which >= BPMF_KERNEL_COUNT) return;
+    std::lock_guard<std::mutex> lock(g_profile_mutex);
     ProfileLog& lg = g_log[which];
     if (edge == 0) {
         lg.open = false;
@@ -58,6 +64,7 @@ void profile_mark(int which, int edge, hipStream_t stream)
 
 extern "C" void bpmf_profile_enable(int enable)
 {
+    std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
     bpmf::g_profile = enable != 0;
     if (!enable) return;  // the log stays readable after the timed region is closed
     for (int k = 0; k < BPMF_KERNEL_COUNT; ++k) { bpmf::g_log[k].count = 0; bpmf::g_log[k].open = false; }
@@ -66,11 +73,13 @@ extern "C" void bpmf_profile_enable(int enable)
 extern "C" int bpmf_profile_count(int which)
 {
     if (which < 0 || which >= BPMF_KERNEL_COUNT) return -1;
+    std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
     return bpmf::g_log[which].count;
 }
 
 extern "C" int bpmf_profile_get_ms(int which, int index, float* ms)
 {
+    std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
     if (which < 0 || which >= BPMF_KERNEL_COUNT || !ms || index < 0 ||
         index >= bpmf::g_log[which].count) {
         bpmf::set_error("bpmf_profile_get_ms: no launch %d recorded for kernel %d", index, which);

@@ -80,32 +80,10 @@ def _device_list(devices):
     return [int(d) for d in devices]
 
 
-def _run_blocks(n_items, devices, call):
-    """Split range(n_items) into contiguous blocks, one per device, and run `call(lo, hi, device)`
-    for each block on its own host thread (the C entry points release the GIL and bind their
-    thread to the device).  Returns when all are done; the first error is re-raised."""
-    devices = devices[:max(1, min(len(devices), n_items))]
-    bounds = np.linspace(0, n_items, len(devices) + 1).astype(np.int64)
-    if len(devices) == 1:
-        call(0, n_items, devices[0])
-        return
-    import threading
-    errors = []
-
-    def work(lo, hi, dev):
-        try:
-            call(lo, hi, dev)
-        except BaseException as exc:   # noqa: BLE001 - re-raised in the caller's thread
-            errors.append(exc)
-
-    threads = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]), d))
-               for i, d in enumerate(devices) if bounds[i + 1] > bounds[i]]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    if errors:
-        raise errors[0]
+def _device_array(devices):
+    """ctypes (n_devices, int*) pair for the *_run_multi entry points."""
+    arr = (C.c_int * len(devices))(*devices)
+    return len(devices), arr
 
 
 def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_zeros="first",
@@ -119,8 +97,8 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
     ``i*step`` (BPMF/similarity_search.py:275).
 
     ``device``: None (default) = all visible GPUs, the templates block-partitioned among them
-    (one host thread per GPU; templates are independent, so no data crosses GPUs); an int or a list
-    selects devices.
+    inside the library (``bpmf_mf_run_multi``: one host thread per GPU; templates are independent,
+    so no data crosses GPUs); an int or a list selects devices.
     """
     if str(arch).lower() not in GPU_ARCHS:
         raise ValueError(
@@ -144,13 +122,11 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
     flags = FLAG_FORCE_DIRECT if force_direct else 0
     lib = _lib.lib()
 
-    def block(lo, hi, dev):
-        rc = lib.bpmf_mf_run(tp[lo:hi].ctypes.data_as(f), mv[lo:hi].ctypes.data_as(i),
-                             w[lo:hi].ctypes.data_as(f), d.ctypes.data_as(f), step, L, N, hi - lo, S, Cc,
-                             n_corr, int(bool(network_sum)), flags, dev, out[lo:hi].ctypes.data_as(f))
-        _lib.check(rc, "bpmf_mf_run")
-
-    _run_blocks(T, _device_list(device), block)
+    n_dev, dev_arr = _device_array(_device_list(device))
+    rc = lib.bpmf_mf_run_multi(tp.ctypes.data_as(f), mv.ctypes.data_as(i), w.ctypes.data_as(f),
+                               d.ctypes.data_as(f), step, L, N, T, S, Cc, n_corr,
+                               int(bool(network_sum)), flags, n_dev, dev_arr, out.ctypes.data_as(f))
+    _lib.check(rc, "bpmf_mf_run_multi")
     if network_sum and check_zeros in ("first", "all"):
         _report_zeros(out, check_zeros)
     return out

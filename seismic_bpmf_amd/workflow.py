@@ -44,8 +44,16 @@ def merge_candidates(index, cc, search_win):
 
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                               threshold_window_dur, minimum_interevent_time, n_dev=8.0,
-                              overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None):
-    """Matched-filter search of one day: returns ({template: cc indices}, cc device tensor)."""
+                              overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
+                              remove_edges=True, data_buffer_sec=None, data_duration_sec=None):
+    """Matched-filter search of one day: returns ({template: cc indices}, cc device tensor).
+
+    `remove_edges` (the reference's default, BPMF/similarity_search.py:274-285) drops detections
+    inside the `data_buffer_sec` margins the day was loaded with (`cfg.DATA_BUFFER_SEC`) and past
+    `data_duration_sec + data_buffer_sec`; it needs both durations and is skipped when
+    `data_buffer_sec` is None (a day loaded without margins).  The optional anomalous-CDF
+    validation of :253-272 is available through postprocess.select_cc_indexes on a downloaded
+    row; it is off in this device pipeline."""
     weights = np.asarray(weights, dtype=np.float32)
     mf = MatchedFilterGPU(device=device)
     mf.set_data(data)
@@ -63,7 +71,14 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     for t in range(weights.shape[0]):
         mine = cand[cand["row"] == t]
         win = search_window(mv[t].reshape(mv.shape[1], -1), min_iet, step)
-        out[t] = merge_candidates(mine["index"], mine["cc"], win)
+        idx = merge_candidates(mine["index"], mine["cc"], win)
+        if remove_edges and data_buffer_sec is not None:
+            samples = idx * step
+            idx = idx[samples >= pp.sec_to_samp(data_buffer_sec, sr)]
+            if data_duration_sec is not None:
+                samples = idx * step
+                idx = idx[samples < pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr)]
+        out[t] = idx
     return out, cc
 
 
