@@ -46,8 +46,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mf-config", default="cfg2")
-    ap.add_argument("--bp-config", default="cfg3")
+    ap.add_argument("--mf-config", default=None,
+                    help="default: cfg2 (configs[1]) on one GPU, cfg4_per_gpu (configs[3]'s share) on N > 1")
+    ap.add_argument("--bp-config", default=None,
+                    help="default: cfg3 (configs[2]) on one GPU, cfg5_per_gpu (configs[4]'s share) on N > 1")
+    ap.add_argument("--skip-e2e", action="store_true", help="skip the host-pointer end-to-end extra")
     ap.add_argument("--skip-bp", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
@@ -89,7 +92,9 @@ def mf_inputs_device(cfg, device, seed):
 
 def bp_inputs(cfg, device, seed, rank, world):
     from seismic_bpmf_amd import synthetic as syn
-    geo = syn.make_bp_geometry(cfg["grid"], cfg["S"], cfg["P"], cfg["sr"], seed=seed)
+    # one GPU's share of configs[4] is a depth slab of the 125 x 125 x 64 grid: rank r scans slab r
+    slab = (rank, 64) if cfg["grid"] == (125, 125, 8) else None
+    geo = syn.make_bp_geometry(cfg["grid"], cfg["S"], cfg["P"], cfg["sr"], seed=seed, depth_slab=slab)
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1)
     S, C, N = cfg["S"], cfg["C"], cfg["N"]
@@ -145,7 +150,9 @@ def bp_detection_stage(beam, arg, geo, bcfg):
 
 # ----------------------------------------------------------------------- CPU baseline ---
 def cpu_baseline(cfg, target_seconds):
-    """Time the CPU oracle (rebuilt -march=native for this host) on a bounded MF sample."""
+    """Time the CPU oracle (rebuilt -march=native for this host) on (1) a bounded sample of the
+    headline workload's shape -- `value` -- and (2) BASELINE configs[0], the reference's own
+    CPU-runnable case, in full, on all threads and on one thread."""
     from oracle import oracle
     from seismic_bpmf_amd import synthetic as syn
     try:
@@ -156,21 +163,19 @@ def cpu_baseline(cfg, target_seconds):
         march = "x86-64-v3"
     cores = lib.bpmf_oracle_max_threads()
     S, C, L = cfg["S"], cfg["C"], cfg["L"]
-    # calibrate on a tiny sample, then size N (whole hours of the same day) for ~target seconds
+
+    def run(inp, nth):
+        t0 = time.perf_counter()
+        oracle.matched_filter(inp["templates"], inp["moveouts"], inp["weights"], inp["data"], 1,
+                              num_threads=nth, lib=lib)
+        return time.perf_counter() - t0
+
+    # calibrate on 8 x 480 000 samples (a smaller probe is dominated by thread start-up on a
+    # 128-core host), then size N (whole seconds of the same day) for ~target seconds
     T = min(cfg["T"], 8)
-    probe = syn.make_mf_inputs(T, S, C, L, 60_000, seed=7, n_events=0)
-    t0 = time.perf_counter()
-    oracle.matched_filter(probe["templates"], probe["moveouts"], probe["weights"], probe["data"], 1,
-                          lib=lib)
-    dt = time.perf_counter() - t0
-    rate = T * (60_000 - L + 1) / dt
-    # the tiny probe is dominated by thread start-up on a 128-core host: calibrate again on 8x the
-    # samples before sizing the sample (the timed run should be ~target_seconds of CPU work)
-    probe2 = syn.make_mf_inputs(T, S, C, L, 480_000, seed=9, n_events=0)
-    t0 = time.perf_counter()
-    oracle.matched_filter(probe2["templates"], probe2["moveouts"], probe2["weights"], probe2["data"], 1,
-                          lib=lib)
-    rate = max(rate, T * (480_000 - L + 1) / (time.perf_counter() - t0))
+    probe = syn.make_mf_inputs(T, S, C, L, 480_000, seed=9, n_events=0)
+    run(probe, cores)                                   # warm the thread pool / page in
+    rate = T * (480_000 - L + 1) / run(probe, cores)
     n = int(min(cfg["N"], max(120_000, rate * target_seconds / T)))
     n -= n % 1000
     smp = syn.make_mf_inputs(T, S, C, L, n, seed=8, n_events=0)
@@ -184,32 +189,33 @@ def cpu_baseline(cfg, target_seconds):
         pass
     value, dt, used = 0.0, 0.0, cores
     for nth in trials:
-        t0 = time.perf_counter()
-        oracle.matched_filter(smp["templates"], smp["moveouts"], smp["weights"], smp["data"], 1,
-                              num_threads=nth, lib=lib)
-        d = time.perf_counter() - t0
+        d = run(smp, nth)
         v = T * (n - L + 1) / d / 1e6
         if v > value:
             value, dt, used = v, d, nth
-    cores = used
-    # one thread beside all threads, on the small probe: the kernel is linear in N
-    t0 = time.perf_counter()
-    oracle.matched_filter(probe["templates"][:2], probe["moveouts"][:2], probe["weights"][:2],
-                          probe["data"], 1, num_threads=1, lib=lib)
-    dt1 = time.perf_counter() - t0
+    # BASELINE configs[0] in full: 4 templates x 8 stations x 3 comp, L = 128, 1 h @ 50 Hz
+    c0 = syn.MF_CONFIGS["cfg1"]
+    inp0 = syn.make_mf_inputs(c0["T"], c0["S"], c0["C"], c0["L"], c0["N"], seed=20260929)
+    n0 = c0["T"] * (c0["N"] - c0["L"] + 1)
+    run(inp0, used)
+    d_all = min(run(inp0, used) for _ in range(3))
+    d_one = run(inp0, 1)                                # 4.4 GFLOP on one thread: seconds of work
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
     except Exception:
         pass
-    return {"value": round(value, 4), "unit": "M CC-samples/s", "cores": cores,
-            "kind": "port",
-            "value_1_thread": round(2 * (60_000 - L + 1) / dt1 / 1e6, 5), "cpu_model": model,
+    return {"value": round(value, 4), "unit": "M CC-samples/s", "cores": used,
+            "kind": "port", "cpu_model": model,
             "sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n} samples of the "
                       f"{cfg['N']}-sample day, step 1; oracle/bpmf_oracle.c mf_cpu (C99+OpenMP, "
-                      f"gcc -O3 -march={march}), {dt:.1f} s wall; 1-thread figure on 2 templates x "
-                      f"60000 samples, {dt1:.1f} s"}
+                      f"gcc -O3 -march={march}), {dt:.1f} s wall on {used} threads",
+            "configs0": {"workload": "BASELINE configs[0] in full: 4 templates x 8 stations x 3 comp, L=128, "
+                                     "N=180000 (1 h @ 50 Hz), step 1",
+                         "value": round(n0 / d_all / 1e6, 4), "cores": used, "seconds": round(d_all, 4),
+                         "value_1_thread": round(n0 / d_one / 1e6, 5), "seconds_1_thread": round(d_one, 3),
+                         "unit": "M CC-samples/s"}}
 
 
 def cpu_baseline_bp(bcfg, geo, target_seconds):
@@ -243,7 +249,7 @@ def cpu_baseline_bp(bcfg, geo, target_seconds):
 
 
 # ------------------------------------------------------- detection stage (untimed extra) ---
-def detection_stage(cc, planted, local_rank, dist, device):
+def detection_stage(cc, planted, local_rank, dist, device, t_offset=0):
     """What follows the hot path in BPMF (similarity_search.py:620-666), on the CC matrix that is
     still in HBM: RMS threshold on device, candidates above it, host merge, and -- for N > 1 -- the
     all-gather of the per-rank peak records (the path's only inter-GPU traffic).  Reported beside
@@ -264,34 +270,50 @@ def detection_stage(cc, planted, local_rank, dist, device):
     t2 = time.perf_counter()
     found = exact = 0
     n_det = 0
+    merged = []                                 # (template, cc index, cc bits, threshold bits)
     for t in range(planted.shape[0]):
         mine = cand[cand["row"] == t]
         idx = list(mine["index"])
         val = list(mine["cc"])
+        thr_v = list(mine["threshold"])
         q = 1                                   # pair-wise merge, similarity_search.py:240-251
         while q < len(idx):
             if idx[q] - idx[q - 1] < 512:
                 drop = q - 1 if val[q] > val[q - 1] else q
-                del idx[drop], val[drop]
+                del idx[drop], val[drop], thr_v[drop]
             else:
                 q += 1
         n_det += len(idx)
         exact += len(set(idx) & set(planted[t].tolist()))
         found += planted.shape[1]
+        merged.extend((t_offset + t, i, v, h) for i, v, h in zip(idx, val, thr_v))
     out = {"threshold_ms": round((t1 - t0) * 1e3, 1), "candidates_ms": round((t2 - t1) * 1e3, 1),
            "candidates": int(cand.size), "detections": n_det, "planted": found,
            "planted_found_at_exact_index": exact}
     if dist is not None:
-        rec = torch.zeros((8192, 4), dtype=torch.int32, device=device)
-        k = min(int(cand.size), 8192)
+        # "RCCL all-gather of CC peaks" (BASELINE configs[3]): every rank contributes its MERGED
+        # detections (global template id, CC index, cc, threshold) -- a few thousand 16-byte records,
+        # never the CC matrix.  The buffer is sized by the largest rank's count, nothing is dropped.
+        from seismic_bpmf_amd.threshold import candidate_dtype
+        mine = np.zeros(len(merged), dtype=candidate_dtype)
+        for q, (tid, i, v, h) in enumerate(merged):
+            mine[q] = (tid, i, v, h)
+        k = int(mine.size)
+        kmax = torch.tensor([k], dtype=torch.int64, device=device)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        cap = max(1, int(kmax.item()))
+        rec = torch.zeros((cap, 4), dtype=torch.int32, device=device)
         if k:
-            rec[:k] = torch.as_tensor(cand[:k].view(np.int32).reshape(-1, 4), device=device)
+            rec[:k] = torch.as_tensor(mine.view(np.int32).reshape(-1, 4), device=device)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         parts = parallel.allgather_records(rec, k)
         torch.cuda.synchronize()
         out["allgather_records_ms"] = round((time.perf_counter() - t3) * 1e3, 2)
         out["records_all_ranks"] = int(sum(len(p) for p in parts))
+        out["records_capacity_per_rank"] = cap
+        mine_back = parts[dist.get_rank()].cpu().numpy().view(candidate_dtype).reshape(-1)
+        out["own_records_round_trip_exact"] = bool(np.array_equal(mine_back, mine))
     return out
 
 
@@ -303,6 +325,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # N = 1: the single-GPU configurations BASELINE.json quotes the metric on (configs[1] / [2]).
+    # N > 1: every rank holds one GPU's share of the 8-GPU configurations (configs[3] / [4]:
+    # 5000 templates / 8 = 625 against 40 stations; 1M sources / 8 = 125 000 against 40 stations).
+    if args.mf_config is None:
+        args.mf_config = "cfg2" if args.gpus == 1 else "cfg4_per_gpu"
+    if args.bp_config is None:
+        args.bp_config = "cfg3" if args.gpus == 1 else "cfg5_per_gpu"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -371,14 +400,36 @@ def main():
             traffic = None
     roofline = {"kernel": "mf_mfma_wave_kernel", "bound": "mfma", "achieved": round(achieved, 2),
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
+                "traffic": traffic,
+                "traffic_source": ("profiles/mf_main_pmc.json: separate rocprofv3 --pmc passes over this launch, "
+                                   "committed, NOT measured in this run") if traffic is not None else None,
+                "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
                 "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",
                 "hbm_frac_informational": round(
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     peak = float(cc[0].max().item())
-    detect = detection_stage(cc, planted, local_rank, dist, device)
+    detect = detection_stage(cc, planted, local_rank, dist, device, t_offset=rank * T)
     del cc, mf
     torch.cuda.empty_cache()
+    # End to end through the host-pointer entry point (what the reference's call site sees:
+    # NumPy in, NumPy out): H2D of the day, kernels, D2H of the API-mandated (T, n_corr) matrix.
+    # Untimed extra, N = 1 only; the second call is reported (the first one also pays the first
+    # touch of the 17 GB result array).  Never `value`.
+    e2e = None
+    if world == 1 and dist is None and not args.skip_e2e and T * n_corr * 4 < 40e9:
+        h_t, h_mv, h_w, h_d = (x.cpu().numpy() for x in (tmpl, mv, w, data))
+        e2e_ms = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            h_cc = sb.matched_filter(h_t, h_mv, h_w, h_d, 1, arch="gpu", check_zeros=False,
+                                     device=[local_rank])
+            e2e_ms.append((time.perf_counter() - t0) * 1e3)
+        e2e = {"mf_ms": round(e2e_ms[1], 1), "mf_first_call_ms": round(e2e_ms[0], 1),
+               "mf_value": round(T * n_corr / (e2e_ms[1] * 1e-3) / 1e6, 1), "unit": "M CC-samples/s",
+               "moves": f"H2D {h_d.nbytes / 1e9:.2f} GB data + templates, D2H {h_cc.nbytes / 1e9:.2f} GB cc_sums "
+                        "(pageable host memory, pinned staging inside bpmf_mf_run)",
+               "row0_peak_cc": round(float(h_cc[0].max()), 4)}
+        del h_cc, h_t, h_mv, h_w, h_d
 
     # ---------------------------------------------------------------- backprojection
     bp_obj = None
@@ -386,7 +437,7 @@ def main():
         bcfg = dict(syn.BP_CONFIGS[args.bp_config])
         geo, feat, wp = bp_inputs(bcfg, device, 20260928, rank, world)
         K_all = geo["moveouts"].shape[0]
-        # weak scaling: every rank owns a full cfg3-sized tile of the (world x larger) grid
+        # weak scaling: every rank owns its own tile of the (world x larger) grid, global source ids
         bf = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"], device=local_rank,
                               source_id_offset=rank * K_all)
         Nb = bcfg["N"]
@@ -420,17 +471,38 @@ def main():
                   "ms_per_step": round(bp_dt / args.steps * 1e3, 3),
                   "config": {"workload": f"BASELINE {BP_LABEL.get(args.bp_config, args.bp_config)}: {K_all} sources x {bcfg['S']} stations x "
                                          f"{bcfg['C']} comp x {bcfg['P']} phases, N={Nb} (1 day @ {bcfg['sr']:g} Hz), "
-                                         f"{s_act:.1f} active stations/source, reduce=max, strict"},
+                                         f"{s_act:.1f} active stations/source, reduce=max, strict",
+                             "parallelism": (f"source grid tiled x{world}: every rank scans {K_all} sources (configs[4] = 8 x 125000) "
+                                             "with global ids, features replicated; one packed-key all-reduce(MAX) of 8 B per "
+                                             "time sample over RCCL per step" if world > 1 else "single GPU")},
                   "roofline": {"kernel": "bp_beam_wps2_kernel", "bound": "lds-gather", "achieved": round(gather_tbs, 2),
                                "peak": round(lds_peak, 1), "unit": "TB/s",
                                "frac": round(gather_tbs / lds_peak, 4),
                                "frac_of_4byte_gather_rate": round(gather_tbs / LDS_B32_PEAK_TBS, 4),
-                               "traffic": bp_traffic, "plan": pinfo, "avg_launch_ms": round(bk, 3),
+                               "traffic": bp_traffic,
+                               "traffic_source": ("profiles/bp_beam_pmc.json: separate rocprofv3 --pmc passes over this "
+                                                  "launch, committed, NOT measured in this run") if bp_traffic is not None else None,
+                               "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
         if rank == 0:
             bp_obj["detection"] = bp_detection_stage(beam, arg, geo, bcfg)
         bf.close()
+        if world == 1 and dist is None and not args.skip_e2e:
+            h_f, h_wp = feat.cpu().numpy(), wp.cpu().numpy()
+            ms = []
+            for _ in range(2):           # the second call finds its plan in the library's cache
+                t0 = time.perf_counter()
+                hb, ha = sb.beamform(h_f, geo["moveouts"], h_wp, geo["weights_sources"], device="gpu",
+                                     reduce="max", out_of_bounds="strict", device_id=[local_rank])
+                ms.append((time.perf_counter() - t0) * 1e3)
+            bp_obj["end_to_end"] = {"ms": round(ms[1], 1), "first_call_ms": round(ms[0], 1),
+                                    "value": K_all * Nb / (ms[1] * 1e-3),
+                                    "moves": f"H2D {h_f.nbytes / 1e9:.2f} GB features, D2H {(hb.nbytes + ha.nbytes) / 1e6:.0f} MB "
+                                             "maxbeam + argmax; first call also builds the plan",
+                                    "equals_resident_result": bool(np.array_equal(hb, beam.cpu().numpy()) and
+                                                                   np.array_equal(ha, arg.cpu().numpy()))}
+            del h_f, hb, ha
         if rank == 0 and world == 1 and not args.skip_cpu:
             bp_obj["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
 
@@ -449,9 +521,11 @@ def main():
             "config": {"workload": f"BASELINE {MF_LABEL.get(args.mf_config, args.mf_config)}: {T} templates x {S} stations x {C} comp, "
                                    f"L={L}, N={N} (1 day @ 100 Hz), step 1, per GPU",
                        "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
-                       "parallelism": f"templates sharded x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"templates sharded x{world}: every rank holds {T} templates (configs[3] = 8 x 625), "
+                                       "data replicated, no data-path collective; all-gather of merged peak records"
+                                       if world > 1 else "single GPU"),
                        "row0_peak_cc": round(peak, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "bp": bp_obj, "detection": detect,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "bp": bp_obj, "detection": detect,
         }
     if dist is not None:
         dist.destroy_process_group()

@@ -71,13 +71,20 @@ def make_mf_inputs(T, S, C, L, N, seed=20260928, max_moveout=1500, n_events=5, s
 
 
 def make_bp_geometry(grid, S, P=2, sr=50.0, seed=20260928, extent_km=(100.0, 100.0, 30.0),
-                     vp=6.0, vs=3.46, n_closest=10):
-    """Moveout table (K,S,P) int32 and source weights (K,S) float32 for a regular lattice."""
+                     vp=6.0, vs=3.46, n_closest=10, depth_slab=None):
+    """Moveout table (K,S,P) int32 and source weights (K,S) float32 for a regular lattice.
+
+    depth_slab = (index, n_levels_total): the lattice is depth levels
+    [index * nz, (index + 1) * nz) of a grid with n_levels_total levels (one GPU's tile of the
+    1M-source grid of BASELINE configs[4]: slab r of 125 x 125 x 64)."""
     rng = np.random.default_rng(seed)
     nx, ny, nz = grid
     xs = np.linspace(0.0, extent_km[0], nx)
     ys = np.linspace(0.0, extent_km[1], ny)
     zs = np.linspace(0.5, extent_km[2], nz)
+    if depth_slab is not None:
+        idx, total = depth_slab
+        zs = np.linspace(0.5, extent_km[2], total)[(idx * nz) % total:(idx * nz) % total + nz]
     X, Y, Z = np.meshgrid(xs, ys, zs, indexing="ij")  # depth fastest
     src = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
     sta = np.stack([rng.uniform(0, extent_km[0], S), rng.uniform(0, extent_km[1], S),

@@ -1,0 +1,153 @@
+"""GPU: the per-GPU shares of BASELINE.json configs[3] and configs[4] at their full sizes.
+
+configs[3] = 5000 templates x 40 stations x 3 components, 1 day @ 100 Hz, templates sharded over
+8 GPUs -> one rank holds 625 templates x 120 channels (`cfg4_per_gpu`); configs[4] = 1M sources x
+40 stations, 1 day @ 100 Hz, grid tiles sharded -> one rank scans 125 000 sources against 80
+station-phase rows (`cfg5_per_gpu`: a different plan regime from cfg3 -- ~300 LDS groups instead
+of ~50).  The CPU oracle cannot run a day, so the checks are the size-independent ones of
+test_gpu_fullsize.py: planted events at their exact index, block concatenation / 2-"rank" merge ==
+single pass bit for bit, determinism, and oracle spot-checks on random windows.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plant_mf(data, tmpl, mv, templates, lags_of, amp=3.0):
+    import torch
+    S, C = tmpl.shape[1:3]
+    L = tmpl.shape[-1]
+    for t in templates:
+        wf = torch.as_tensor(tmpl[t], device=data.device)
+        for i0 in lags_of[t]:
+            for s in range(S):
+                for c in range(C):
+                    j = int(i0 + mv[t, s, c])
+                    data[s, c, j:j + L] += amp * wf[s, c]
+
+
+def test_mf_cfg4_share_full_day(oracle_lib):
+    import torch
+    from seismic_bpmf_amd import MatchedFilterGPU, synthetic as syn
+    cfg = syn.MF_CONFIGS["cfg4_per_gpu"]
+    T, S, C, L, N = cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(41)
+    data = torch.randn((S, C, N), device="cuda", generator=g)
+    inp = syn.make_mf_inputs(T, S, C, L, 30_000, seed=44, n_events=0)    # templates / moveouts / weights
+    tmpl, mv, w = inp["templates"], inp["moveouts"] * 10, inp["weights"]   # moveouts up to 3000 samples
+    rng = np.random.default_rng(45)
+    probe = sorted(rng.choice(T, 16, replace=False).tolist() + [0, T - 1])
+    lags_of = {t: np.sort(rng.choice(np.arange(10_000, N - 20_000, 4096), 2, replace=False))
+               for t in probe}
+    _plant_mf(data, tmpl, mv, probe, lags_of)
+    data /= data.std(dim=-1, keepdim=True)
+    mf = MatchedFilterGPU()
+    mf.set_data(data)
+    cc = mf.run(tmpl, mv, w, 1)                                           # (625, 8 639 745): 21.6 GB
+    assert cc.shape == (T, N - L + 1)
+    assert float(cc.abs().max()) <= 1.0 + 1e-5
+    # template sharding: blocks computed separately (what 2 ranks of a finer split would do)
+    # concatenate to the single pass bit for bit
+    k = 313
+    lo_half = mf.run(tmpl[:k], mv[:k], w[:k], 1)
+    assert torch.equal(cc[:k], lo_half)
+    del lo_half
+    hi_half = mf.run(tmpl[k:], mv[k:], w[k:], 1)
+    assert torch.equal(cc[k:], hi_half)
+    del hi_half
+    for t in probe:
+        row = cc[t].cpu().numpy()
+        for i0 in lags_of[t]:
+            lo = int(i0) - 2000
+            assert lo + int(np.argmax(row[lo:int(i0) + 2000])) == i0, (t, i0)
+            assert row[i0] > 0.6
+    # oracle spot checks: random 2000-lag stretches of three templates (all 120 channels)
+    d_host = None
+    for t in (probe[0], probe[7], probe[-1]):
+        row = cc[t].cpu().numpy()
+        for i0 in rng.integers(0, N - L - 8000, 2):
+            i0 = int(i0)
+            n_seg = 2000 + L - 1 + int(mv[t].max())
+            seg = data[:, :, i0:i0 + n_seg].cpu().numpy()
+            want = oracle_lib.matched_filter(tmpl[t:t + 1], mv[t:t + 1], w[t:t + 1], seg, 1)[0, :2000]
+            assert np.array_equal(row[i0:i0 + 2000], want), (t, i0)
+    del d_host
+    # second run of SURVEY 8d: only the 10 "closest" stations of each template keep weight
+    sub = np.asarray(probe[:8])
+    w10 = w[sub].copy()
+    order = np.argsort(mv[sub][:, :, 0], axis=1)
+    for q in range(sub.size):
+        w10[q, order[q, 10:], :] = 0.0
+    w10 /= w10.sum(axis=(1, 2), keepdims=True)
+    cc10 = mf.run(tmpl[sub], mv[sub], w10, 1).cpu().numpy()
+    for q in (0, 5):
+        t = int(sub[q])
+        i0 = int(lags_of[t][0]) - 700
+        n_seg = 1500 + L - 1 + int(mv[t].max())
+        seg = data[:, :, i0:i0 + n_seg].cpu().numpy()
+        want = oracle_lib.matched_filter(tmpl[t:t + 1], mv[t:t + 1], w10[q:q + 1], seg, 1)[0, :1500]
+        assert np.array_equal(cc10[q, i0:i0 + 1500], want)
+        assert i0 + int(np.argmax(cc10[q, i0:i0 + 1500])) == lags_of[t][0]
+
+
+def test_bp_cfg5_share_full_day(oracle_lib):
+    import torch
+    from seismic_bpmf_amd import BeamformerGPU, parallel, postprocess as pp, synthetic as syn
+    cfg = syn.BP_CONFIGS["cfg5_per_gpu"]
+    S, C, P, N = cfg["S"], cfg["C"], cfg["P"], cfg["N"]
+    geo = syn.make_bp_geometry(cfg["grid"], S, P, cfg["sr"])
+    tau, ws = geo["moveouts"], geo["weights_sources"]
+    K = tau.shape[0]
+    assert K == 125_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(51)
+    feat = torch.randn((S, C, N), device="cuda", generator=g).abs_()
+    rng = np.random.default_rng(52)
+    sig, half = 20.0, 80                                                   # 0.2 s at 100 Hz
+    bump = torch.as_tensor(8.0 * np.exp(-0.5 * (np.arange(-half, half + 1) / sig) ** 2),
+                           dtype=torch.float32, device="cuda")
+    planted = []
+    for _ in range(10):
+        k0, t0 = int(rng.integers(0, K)), int(rng.integers(20_000, N - 20_000))
+        for s in range(S):
+            for c in range(C):
+                x = t0 + int(tau[k0, s, 0 if c == 0 else 1])
+                feat[s, c, x - half:x + half + 1] += bump
+        planted.append((k0, t0))
+    wp = syn.phase_weights(S, C, P)
+    full = BeamformerGPU(tau, ws)
+    info = full.plan_info()
+    assert info["gather_bytes"] == 8 and info["n_groups"] > 100            # the 80-row regime
+    beam, arg = full.run(feat, wp, "max", "strict")
+    b2, a2 = full.run(feat, wp, "max", "strict")
+    assert torch.equal(beam, b2) and torch.equal(arg, a2)
+    # two "ranks" with global ids, merged with the packed-key max (the all-reduce at world size 2)
+    k_half = K // 2
+    r0 = BeamformerGPU(tau[:k_half], ws[:k_half], source_id_offset=0)
+    r1 = BeamformerGPU(tau[k_half:], ws[k_half:], source_id_offset=k_half)
+    p0 = parallel.pack_max_keys(*r0.run(feat, wp, "max", "strict"))
+    p1 = parallel.pack_max_keys(*r1.run(feat, wp, "max", "strict"))
+    mb, ma = parallel.unpack_max_keys(torch.maximum(p0, p1))
+    assert torch.equal(mb, beam) and torch.equal(ma, arg)
+    assert torch.equal(r0.pack_max(beam, arg), parallel.pack_max_keys(beam, arg))
+    maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
+    tmax_used = np.where(ws[:, :, None] != 0, tau, -1).max(axis=(1, 2))
+    tail = N - int(tmax_used.min())
+    assert not maxbeam[tail:].any() and not sources[tail:].any() and maxbeam[tail - 1] > 0
+    # oracle spot checks: all 125 000 sources over three 150-sample windows (one around an event)
+    tmax = int(tau.max())
+    for i0 in (planted[0][1] - 60, int(rng.integers(0, N - tmax - 1000)), 0):
+        W = 150
+        seg = feat[:, :, i0:i0 + W + tmax + 1].cpu().numpy()
+        ob, oa = oracle_lib.beamform(seg, tau, wp, ws, "strict", "max")
+        assert np.array_equal(maxbeam[i0:i0 + W], ob[:W]), i0
+        assert np.array_equal(sources[i0:i0 + W], oa[:W]), i0
+    peaks, psrc = pp.find_beam_detections(maxbeam, sources, np.full(N, 5.0, np.float32), 1000)
+    for k0, t0 in planted:
+        hit = np.flatnonzero(np.abs(peaks - t0) <= 30)
+        assert hit.size == 1, (k0, t0, peaks[np.abs(peaks - t0) < 4000])
+        assert maxbeam[peaks[hit[0]]] >= maxbeam[t0] >= 8.0
+    for b in (full, r0, r1):
+        b.close()
