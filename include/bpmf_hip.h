@@ -163,6 +163,38 @@ int bpmf_bp_pack_max_dev(const float *d_beam, const int32_t *d_arg, size_t N, in
 int bpmf_bp_unpack_max_dev(const uint64_t *d_packed, size_t N, int as_signed,
                            bpmf_stream_t stream, float *d_beam, int32_t *d_arg);
 
+/* ------------------------------------------ detection stage behind the beamformer --- */
+/*
+ * Device version of the two full-length steps of Beamformer.find_detections
+ * (BPMF/template_search.py:574-627), so that the (N,) max-beam never leaves HBM:
+ *
+ * bpmf_bp_window_stats_dev: the per-window statistics of template_search.time_dependent_threshold
+ * (BPMF/template_search.py:1418-1487): for q = 1 .. n_windows, window q covers the samples
+ * [q*shift, min(n, q*shift + window)); d_median[q] / d_mad[q] receive np.median(window) and
+ * np.median(|window - median|) in float32, bit for bit (radix select, no sort).  Both arrays need
+ * n_windows + 2 entries; entries 0 and n_windows + 1 (the reference's end fills) are left to the
+ * caller.  n_windows = bpmf_bp_num_windows(n, window, shift) = (n - window) / shift + 1.
+ *
+ * bpmf_bp_extract_peaks_dev: every rising-edge local maximum of the max-beam (the peak rule of
+ * utils._detect_peaks, BPMF/utils.py:2292-2301: x[t] > x[t-1] and x[t+1] <= x[t], first and last
+ * sample excluded, samples next to a NaN excluded) whose value exceeds `floor_value`, as
+ * (sample, beam, source) records in arbitrary order.  *d_count receives the number found (may
+ * exceed `capacity`; only the first `capacity` are stored).  d_sources may be NULL (source = 0).
+ */
+typedef struct bpmf_bp_peak {
+    int32_t index;  /* time sample */
+    float beam;     /* maxbeam[index] */
+    int32_t source; /* maxbeam_sources[index] */
+    int32_t pad;
+} bpmf_bp_peak;
+
+size_t bpmf_bp_num_windows(size_t n, size_t window, size_t shift);
+int bpmf_bp_window_stats_dev(const float *d_beam, size_t n, size_t window, size_t shift,
+                             bpmf_stream_t stream, float *d_median, float *d_mad);
+int bpmf_bp_extract_peaks_dev(const float *d_beam, const int32_t *d_sources, size_t n,
+                              double floor_value, uint32_t capacity, bpmf_stream_t stream,
+                              uint32_t *d_count, bpmf_bp_peak *d_records);
+
 /* ------------------------------------------------ post-CC detection threshold --- */
 /*
  * Device version of the step right after the matched filter:

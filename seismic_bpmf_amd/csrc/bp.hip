@@ -15,11 +15,10 @@
 //      banks) and accumulate with the source weight in registers, keeping a running
 //      (max, arg-max) per time sample: no atomics, no cross-workgroup merge, and the
 //      sequential source order gives the "lowest index wins ties" rule for free.
-#include "common.h"
+#include "bp_plan.h"
 #include <mutex>
 #include <cstring>
 #include <type_traits>
-#include "../../include/bpmf_hip.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -27,9 +26,6 @@
 #include <vector>
 
 namespace bpmf {
-
-constexpr int BP_THREADS = 256;
-constexpr size_t BP_LDS_MAX = 160 * 1024;
 
 // ------------------------------------------------------------------- prestack ---
 // One thread per (station, time sample): reads the C components once, writes P phases.
@@ -72,19 +68,6 @@ __global__ void bp_prestack_any_kernel(const float* __restrict__ feat,
 }
 
 // ----------------------------------------------------------------------- beam ---
-struct BpGroup {  // one LDS residency: a run of sources and the staging work they need
-    int first_src, n_src, first_chunk, n_chunk;
-};
-struct BpChunk {  // <= BP_THREADS consecutive floats of one prestacked (station, phase) row
-    int row;   // row of U (s * P + p)
-    int gofs;  // first sample, relative to the tile start t0 (window moveout origin + x0)
-    int dst;   // LDS float offset
-    int n;     // floats in this chunk
-};
-struct BpSource {
-    int id, tmin, tmax, nterm;  // global id, extreme used moveouts, terms padded to the chunk (0 = unused)
-};
-
 template <int NBLK>
 struct BpMeta {  // one source's wave-uniform metadata, spread over the lanes of a wave
     int hd;
@@ -648,7 +631,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ recs, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg)
+    int* __restrict__ out_arg, long long tile_base, long long n_tiles)
 {
     extern __shared__ float lds[];
     constexpr int TPW = 8;
@@ -671,7 +654,9 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     // contiguous run of tiles, so that each L2 stages its own eighth of the prestack instead of
     // all of it.  (The grid is rounded up to a multiple of 8; tiles past N see only zero fill.)
     const long long tiles_per_xcd = (gridDim.x + 7) >> 3;
-    const long long t0 = ((long long)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3)) * TILE;
+    const long long tile_i = (long long)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile_i >= n_tiles) return;          // the launch covers the tiles [tile_base, tile_base + n_tiles)
+    const long long t0 = (tile_base + tile_i) * TILE;
     if (t0 >= N) return;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -987,30 +972,6 @@ __global__ void bp_unpack_kernel(const unsigned long long* __restrict__ packed, 
 using namespace bpmf;
 
 // ----------------------------------------------------------------------- plan ---
-struct bpmf_bp_plan {
-    int device = 0;
-    size_t K = 0, S = 0, P = 0;
-    int tpt = 2;           // time samples per thread -> tile = BP_THREADS * tpt
-    int chunk = 4;         // terms gathered side by side
-    int NT = 4;            // padded number of (station, phase) terms per source
-    int n_groups = 0;
-    size_t lds_bytes = 0;  // largest group
-    bool dual = false;     // dual (shifted) windows: every term offset is even
-    int id_offset = 0;
-    double mean_group = 0; // diagnostics
-    BpGroup* d_groups = nullptr;
-    BpChunk* d_chunks = nullptr;
-    BpSource* d_srcs = nullptr;
-    int* d_off = nullptr;
-    float* d_beta = nullptr;
-    int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
-    int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
-    int nsv = 0;                 // > 0: packed per-station records (P == 2), NSV stations padded
-    int4* d_recs = nullptr;      // [K, nsv/2]
-    int4* d_hdr2 = nullptr;      // [K] headers with the station count in .w
-    BpTermV* d_termsv = nullptr; // [K, ntv]
-};
-
 namespace {
 
 struct PlanHost {
@@ -1295,7 +1256,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         for (size_t q = 0; q < K; ++q)
             for (int j = 0; j < ph.NT; ++j)
                 tv[q * pl->ntv + j] = BpTermV{ph.off[q * ph.NT + j] * 4, ph.beta[q * ph.NT + j]};
-        if ((rc = upload(tv, &pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
+        if ((rc = upload(tv, (BpTermV**)&pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
     }
     // packed per-station records for the two-phase fast kernel
     if (P == 2 && ph.NT <= 64 && env_int("BPMF_BP_PACKED", 1)) {
@@ -1324,6 +1285,79 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             return rc;
         }
     }
+    // Interior-tile fast path (bp_fast.hip): the sources of every group once more, partitioned into
+    // runs of equal (even-padded) station count, one fixed-stride record each.
+    if (dual && pl->nsv && pl->nsv <= 16 && env_int("BPMF_BP_FAST", 1)) {
+        const int NT = ph.NT;
+        bool uniform = env_int("BPMF_BP_FAST_UNIFORM", 1) != 0;
+        int tmin_all = 0, tmax_all = 0;
+        bool any = false;
+        for (size_t q = 0; q < K; ++q) {
+            const BpSource& sr = ph.srcs[q];
+            if (sr.nterm <= 0) continue;
+            if (!any || sr.tmin < tmin_all) tmin_all = sr.tmin;
+            if (!any || sr.tmax > tmax_all) tmax_all = sr.tmax;
+            any = true;
+            float w0 = 0.0f;
+            for (int j = 0; j < NT; j += 2) {
+                const float b = ph.beta[q * NT + j];
+                if (b == 0.0f) continue;
+                if (w0 == 0.0f) w0 = b;
+                else if (b != w0) uniform = false;
+            }
+        }
+        const int rec_dw = (2 + 2 * std::max(pl->nsv, 4) + 3) / 4 * 4;
+        std::vector<BpFastGroup> fg;
+        std::vector<BpRun> fr;
+        std::vector<int> rec;
+        std::vector<int> order;
+        for (const BpGroup& g : ph.groups) {
+            BpFastGroup f{(int)fr.size(), 0, g.first_chunk, g.n_chunk};
+            for (int nst = 4; nst <= 16; nst += 2) {        // a group's sources are listed by ascending id
+                order.clear();                              // (1-2 stations: padded to 4 with zero-slab terms)
+                for (int q = g.first_src; q < g.first_src + g.n_src; ++q)
+                    if (ph.srcs[q].nterm == 2 * nst || (nst == 4 && ph.srcs[q].nterm > 0 && ph.srcs[q].nterm < 8))
+                        order.push_back(q);
+                if (order.empty()) continue;
+                fr.push_back(BpRun{(int)(rec.size() / rec_dw), (int)order.size(), nst, 0});
+                ++f.n_run;
+                for (int q : order) {
+                    const size_t r0 = rec.size();
+                    rec.resize(r0 + rec_dw, 0);
+                    float w0 = 0.0f;
+                    for (int j = 0; j < NT && w0 == 0.0f; j += 2) w0 = ph.beta[(size_t)q * NT + j];
+                    rec[r0] = ph.srcs[q].id;
+                    rec[r0 + 1] = uniform ? __builtin_bit_cast(int, w0) : 0;
+                    for (int st = 0; st < nst; ++st) {
+                        const bool real = 2 * st + 1 < NT;      // beyond the term table: the zero slab, weight 0
+                        const int oP = real ? ph.off[(size_t)q * NT + 2 * st] : 0, oS = real ? ph.off[(size_t)q * NT + 2 * st + 1] : 0;
+                        if (uniform) {                      // LDS byte addresses of the two windows
+                            rec[r0 + 2 + 2 * st] = oP * 4;
+                            rec[r0 + 3 + 2 * st] = oS * 4;
+                        } else {                            // {offs_P | offs_S << 16, weight}
+                            rec[r0 + 2 + 2 * st] = (int)((unsigned)oP | ((unsigned)oS << 16));
+                            rec[r0 + 3 + 2 * st] = real ? __builtin_bit_cast(int, ph.beta[(size_t)q * NT + 2 * st]) : 0;
+                        }
+                    }
+                }
+            }
+            fg.push_back(f);
+        }
+        rec.resize(rec.size() + (size_t)16 * rec_dw, 0);   // one round of records: the prefetch past the last source
+        if (any && ((rc = upload(fg, &pl->d_fgroups)) || (rc = upload(fr, &pl->d_fruns)) ||
+                    (rc = upload(rec, &pl->d_frecs)))) {
+            bpmf_bp_plan_destroy(pl);
+            return rc;
+        }
+        pl->fast = any;
+        pl->fast_uniform = uniform;
+        pl->fast_rec_dw = rec_dw;
+        pl->tmin_all = tmin_all;
+        pl->tmax_all = tmax_all;
+        if (env_int("BPMF_BP_VERBOSE", 0))
+            fprintf(stderr, "[bpmf] bp fast path: %zu runs, uniform=%d, rec=%d dwords, moveouts [%d, %d]\n",
+                    fr.size(), (int)uniform, rec_dw, tmin_all, tmax_all);
+    }
     if ((rc = upload(ph.groups, &pl->d_groups)) || (rc = upload(ph.chunks, &pl->d_chunks)) ||
         (rc = upload(ph.srcs, &pl->d_srcs)) || (rc = upload(ph.off, &pl->d_off)) ||
         (rc = upload(ph.beta, &pl->d_beta))) {
@@ -1345,6 +1379,9 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     (void)hipFree(pl->d_termsv);
     (void)hipFree(pl->d_recs);
     (void)hipFree(pl->d_hdr2);
+    (void)hipFree(pl->d_fgroups);
+    (void)hipFree(pl->d_fruns);
+    (void)hipFree(pl->d_frecs);
     delete pl;
 }
 
@@ -1483,6 +1520,8 @@ int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob,
     return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
+thread_local long long t_tile_base = 0, t_tile_count = -1;   // -1: all tiles
+
 template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA, bool B64>
 int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                      float* beam, int32_t* arg)
@@ -1493,13 +1532,19 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    dim3 grid((unsigned)(((N + 511) / 512 + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
-    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    // t_tile_*: the caller (interior / edge split of bpmf_bp_run_dev) may restrict the launch to a
+    // range of tiles and place the profile marks itself
+    const long long all_tiles = (long long)((N + 511) / 512);
+    const long long tile_base = t_tile_count >= 0 ? t_tile_base : 0;
+    const long long n_tiles = t_tile_count >= 0 ? t_tile_count : all_tiles;
+    if (n_tiles <= 0) return 0;
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
+    if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
                                                 (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,
-                                                pl->id_offset, beam, arg);
+                                                pl->id_offset, beam, arg, tile_base, n_tiles);
     BPMF_LAUNCH_CHECK();
-    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 
@@ -1610,6 +1655,30 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
                                                                (int)C, P, U);
     }
     BPMF_LAUNCH_CHECK();
+    if (pl->fast && reduce == BPMF_BP_REDUCE_MAX && pl->tpt == 2) {
+        // Tiles on which no source can leave the trace -- t0 + tmin_all >= 0 and t0 + 512 + tmax_all
+        // (+ the staging slack of 8 samples) <= N -- run the interior kernel of bp_fast.hip, which is
+        // the same for strict and flexible; the few tiles at the ends of the day run the general one.
+        const long long n_all = (long long)((N + 511) / 512);
+        long long lo = pl->tmin_all < 0 ? ((long long)(-pl->tmin_all) + 511) / 512 : 0;
+        long long hi = ((long long)N - pl->tmax_all - 8) / 512;
+        if ((long long)N - pl->tmax_all - 8 < 0) hi = 0;
+        lo = std::min(lo, n_all);
+        hi = std::max(lo, std::min(hi, n_all));
+        profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+        int rc = 0;
+        auto edge = [&](long long base, long long count) {
+            if (count <= 0 || rc) return;
+            t_tile_base = base; t_tile_count = count;
+            rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
+            t_tile_count = -1;
+        };
+        edge(0, lo);
+        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out);
+        edge(hi, n_all - hi);
+        profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+        return rc;
+    }
     switch (pl->tpt) {
         case 1: return dispatch_beam<1>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
         case 2: return dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);

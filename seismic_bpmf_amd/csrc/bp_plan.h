@@ -1,0 +1,73 @@
+// Shared between bp.hip (plan builder, generic beam kernels, C ABI) and bp_fast.hip (the
+// interior-tile production kernel): device-side plan records and the host-side plan object.
+#pragma once
+#include "common.h"
+#include "../../include/bpmf_hip.h"
+
+namespace bpmf {
+
+constexpr int BP_THREADS = 256;
+constexpr size_t BP_LDS_MAX = 160 * 1024;
+
+struct BpGroup {  // one LDS residency: a run of sources and the staging work they need
+    int first_src, n_src, first_chunk, n_chunk;
+};
+struct BpChunk {  // <= BP_THREADS consecutive floats of one prestacked (station, phase) row
+    int row;   // row of U (s * P + p)
+    int gofs;  // first sample, relative to the tile start t0 (window moveout origin + x0)
+    int dst;   // LDS float offset
+    int n;     // floats in this chunk
+};
+struct BpSource {
+    int id, tmin, tmax, nterm;  // global id, extreme used moveouts, terms padded to the chunk (0 = unused)
+};
+
+// ---- interior-tile fast path (bp_fast.hip) ----
+// A group's sources are listed once more, partitioned into RUNS of equal (even-padded) station
+// count, ascending id inside a run; one record of `rec_dw` dwords per source:
+//   uniform weights : [id, weight, addrP_0, addrS_0, addrP_1, addrS_1, ...]   LDS byte addresses
+//   per-station     : [id, 0, offs_0, w_0, offs_1, w_1, ...]   offs = float offsets P | S << 16
+// Padding stations address the zero slab (offset 0) with the source's weight (or weight 0).
+struct BpRun { int first_rec, n_src, nst, pad; };          // nst: stations of the run (even, 2..16)
+struct BpFastGroup { int first_run, n_run, first_chunk, n_chunk; };
+
+}  // namespace bpmf
+
+struct bpmf_bp_plan {
+    int device = 0;
+    size_t K = 0, S = 0, P = 0;
+    int tpt = 2;           // time samples per thread -> tile = BP_THREADS * tpt
+    int chunk = 4;         // terms gathered side by side
+    int NT = 4;            // padded number of (station, phase) terms per source
+    int n_groups = 0;
+    size_t lds_bytes = 0;  // largest group
+    bool dual = false;     // dual (shifted) windows: every term offset is even
+    int id_offset = 0;
+    double mean_group = 0; // diagnostics
+    bpmf::BpGroup* d_groups = nullptr;
+    bpmf::BpChunk* d_chunks = nullptr;
+    bpmf::BpSource* d_srcs = nullptr;
+    int* d_off = nullptr;
+    float* d_beta = nullptr;
+    int ntv = 0;                 // > 0: uniform-VGPR fast path with NTV padded terms
+    int wps = 1;                 // wave-per-source kernel (needs ntv > 0 and tile 512)
+    int nsv = 0;                 // > 0: packed per-station records (P == 2), NSV stations padded
+    int4* d_recs = nullptr;      // [K, nsv/2]
+    int4* d_hdr2 = nullptr;      // [K] headers with the station count in .w
+    void* d_termsv = nullptr;    // [K, ntv] BpTermV (bp.hip)
+    // interior-tile fast path (dual plans with <= 16 stations per source)
+    bool fast = false;
+    bool fast_uniform = false;   // every source's non-zero weights are equal
+    int fast_rec_dw = 0;         // dwords per record
+    int tmin_all = 0, tmax_all = 0;   // extreme used moveouts over all sources
+    bpmf::BpFastGroup* d_fgroups = nullptr;
+    bpmf::BpRun* d_fruns = nullptr;
+    int* d_frecs = nullptr;
+};
+
+namespace bpmf {
+// bp_fast.hip: running (max, arg-max) over all sources for the tiles [tile_lo, tile_hi), every
+// one of which lies inside [-tmin_all, N - tmax_all) (no bounds test per source).
+int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long tile_lo,
+                     long long tile_hi, hipStream_t stream, float* beam, int32_t* arg);
+}

@@ -283,6 +283,23 @@ def _suppress(ind, rank, mpd):
     return keep.astype(bool)
 
 
+def snap_and_merge_peaks(peaks, n, mpd, beam_slice):
+    """The regrouping lines of Beamformer.find_detections, BPMF/template_search.py:612-624: every
+    peak, in order, is moved to the largest sample within +-mpd/2 of its CURRENT position (first
+    occurrence on ties, np.argmax), together with every other peak that currently sits on the same
+    sample; duplicates are merged.  `beam_slice(i0, i1)` returns maxbeam[i0:i1] -- the only access
+    to the series, so the same code runs on a host array and on windows fetched from the device."""
+    peaks = np.array(peaks, copy=True)
+    for q in range(peaks.size):
+        lo = max(0, peaks[q] - mpd / 2)
+        hi = min(peaks[q] + mpd / 2, n)
+        win = np.arange(lo, hi).astype(np.int32)   # same float->int truncation as the reference
+        seg = np.asarray(beam_slice(int(win[0]), int(win[-1]) + 1))
+        snapped = np.argmax(seg[win - win[0]]) + win[0]
+        peaks[peaks == peaks[q]] = snapped
+    return np.unique(peaks)
+
+
 def find_beam_detections(maxbeam, maxbeam_sources, threshold, mpd):
     """Peak logic of Beamformer.find_detections (BP-6), BPMF/template_search.py:604-627.
 
@@ -294,14 +311,53 @@ def find_beam_detections(maxbeam, maxbeam_sources, threshold, mpd):
     threshold = np.broadcast_to(np.asarray(threshold), (n,))
     peaks = detect_peaks(maxbeam, mpd=mpd)
     peaks = peaks[maxbeam[peaks] > threshold[peaks]]
-    for q in range(peaks.size):
-        lo = max(0, peaks[q] - mpd / 2)
-        hi = min(peaks[q] + mpd / 2, n)
-        win = np.arange(lo, hi).astype(np.int32)   # same float->int truncation as the reference
-        snapped = np.argmax(maxbeam[win]) + win[0]
-        peaks[peaks == peaks[q]] = snapped
-    peaks = np.unique(peaks)
+    peaks = snap_and_merge_peaks(peaks, n, mpd, lambda i0, i1: maxbeam[i0:i1])
     return peaks, np.asarray(maxbeam_sources)[peaks]
+
+
+def find_beam_detections_from_candidates(index, height, threshold_at, mpd, n, beam_slice):
+    """find_beam_detections for a series that is not on the host: `index` (ascending) / `height`
+    list every rising-edge local maximum above a floor that no threshold value undercuts (the
+    device extraction, csrc/bp_detect.hip); `threshold_at(samples)` evaluates the threshold at a few
+    samples.  The tallest-first suppression of BPMF/utils.py:2334-2345 runs on this list: the peaks
+    it lacks are lower than every peak above the threshold, so they can neither remove one of those
+    nor tie with one, and the survivors above the threshold are the reference's.  (The order in
+    which exactly equal heights are visited is np.argsort's, as in the reference; it is only
+    defined up to the sort implementation, there as here.)"""
+    index = np.asarray(index, dtype=np.int64)
+    height = np.asarray(height).astype(np.float64)
+    if index.size and mpd > 1:
+        rank = np.argsort(height)[::-1]
+        keep = _suppress(index, rank, mpd)
+        index, height = index[keep], height[keep]
+    above = height > np.asarray(threshold_at(index), dtype=np.float64)
+    return snap_and_merge_peaks(index[above], n, mpd, beam_slice)
+
+
+def bp_threshold_nodes(n, window, overlap, median, mad, n_dev):
+    """Window centres and node values of template_search.time_dependent_threshold
+    (BPMF/template_search.py:1452-1487) from the per-window medians / MADs: `median`, `mad` are
+    float32 arrays of n_windows + 2 entries whose entries 1 .. n_windows are filled; the end fills
+    are applied here.  Returns (centre float32, threshold float32), both n_windows + 2 long; the
+    threshold at sample t is np.interp(t, centre, threshold) with the end values outside."""
+    shift = int((1.0 - overlap) * window)
+    n_windows = int((n - window) // shift) + 1
+    med = np.array(median, dtype=np.float32, copy=True)
+    dev = np.array(mad, dtype=np.float32, copy=True)
+    centre = np.zeros(n_windows + 2, dtype=np.float32)
+    for q in range(1, n_windows + 1):
+        i1 = q * shift
+        centre[q] = (i1 + min(n, i1 + window)) / 2.0
+    med[0], dev[0], centre[0] = med[1], dev[1], 0.0
+    med[-1], dev[-1], centre[-1] = med[-2], dev[-2], n
+    return centre, med + n_dev * dev
+
+
+def interp_threshold(samples, centre, nodes):
+    """The reference's interp1d(kind="slinear", bounds_error=False, fill_value=(first, last)) at
+    `samples` (float64, like bp_time_dependent_threshold)."""
+    return np.interp(np.asarray(samples, dtype=np.float64), centre.astype(np.float64),
+                     nodes.astype(np.float64), left=nodes[0], right=nodes[-1])
 
 
 def select_cc_indexes(cc_t, threshold, search_win, *, step, sr, data_duration_sec,
@@ -391,18 +447,11 @@ def bp_time_dependent_threshold(network_response, window, n_dev, overlap=0.75):
     n_windows = int((n - window) // shift) + 1
     med = np.zeros(n_windows + 2, dtype=np.float32)
     mad = np.zeros(n_windows + 2, dtype=np.float32)
-    centre = np.zeros(n_windows + 2, dtype=np.float32)
     for q in range(1, n_windows + 1):
         i1 = q * shift
-        i2 = min(n, i1 + window)
-        seg = x[i1:i2]
+        seg = x[i1:min(n, i1 + window)]
         m = np.median(seg)
         med[q] = m
         mad[q] = np.median(np.abs(seg - m))
-        centre[q] = (i1 + i2) / 2.0
-    med[0], mad[0], centre[0] = med[1], mad[1], 0.0
-    med[-1], mad[-1], centre[-1] = med[-2], mad[-2], n
-    thr = med + n_dev * mad
-    # scipy interp1d(kind="slinear", bounds_error=False, fill_value=(first, last))
-    return np.interp(np.arange(n, dtype=np.float64), centre.astype(np.float64), thr.astype(np.float64),
-                     left=thr[0], right=thr[-1])
+    centre, nodes = bp_threshold_nodes(n, window, overlap, med, mad, n_dev)
+    return interp_threshold(np.arange(n, dtype=np.float64), centre, nodes)

@@ -138,3 +138,67 @@ class ThresholdGPU:
             raise _lib.BpmfHipError(f"{n_found} candidates exceed the capacity {capacity}")
         out = rec[:n_found].cpu().numpy().view(candidate_dtype).reshape(-1)
         return out[np.lexsort((out["index"], out["row"]))]
+
+
+peak_dtype = np.dtype([("index", np.int32), ("beam", np.float32), ("source", np.int32),
+                       ("pad", np.int32)])
+
+
+class BeamDetectorGPU:
+    """Device side of ``Beamformer.find_detections`` (BPMF/template_search.py:574-627): the sliding
+    median/MAD statistics of its threshold (:1418-1487) and the extraction of the rising-edge local
+    maxima of the max-beam (BPMF/utils.py:2292-2301) above a floor, as compact records.  The (N,)
+    max-beam stays in HBM; see csrc/bp_detect.hip and workflow.backprojection_detections."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.BpmfHipError("BeamDetectorGPU needs a HIP device")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.lib = _lib.lib()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def window_stats(self, beam, window, overlap=0.75):
+        """(median, mad) float32 arrays of n_windows + 2 entries; entries 1 .. n_windows hold
+        np.median / MAD of the windows [q*shift, min(n, q*shift + window)), the two end entries
+        are left 0 (postprocess.bp_threshold_nodes fills them)."""
+        t = self.torch
+        x = beam.reshape(-1).contiguous()
+        n = x.numel()
+        window = int(window)
+        shift = int((1.0 - overlap) * window)
+        nw = self.lib.bpmf_bp_num_windows(n, window, shift)
+        if nw == 0:
+            raise ValueError("series shorter than the sliding window")
+        med = t.zeros(nw + 2, dtype=t.float32, device=self.device)
+        mad = t.zeros(nw + 2, dtype=t.float32, device=self.device)
+        with t.cuda.device(self.device):
+            rc = self.lib.bpmf_bp_window_stats_dev(x.data_ptr(), n, window, shift, self._stream(),
+                                                   med.data_ptr(), mad.data_ptr())
+        _lib.check(rc, "bpmf_bp_window_stats_dev")
+        return med.cpu().numpy(), mad.cpu().numpy()
+
+    def extract_peaks(self, beam, sources, floor, capacity=1 << 18):
+        """Records (index, beam, source) of every rising-edge local maximum above `floor`, sorted
+        by sample index.  The buffer grows and the extraction is repeated if it overflows."""
+        t = self.torch
+        x = beam.reshape(-1).contiguous()
+        src = sources.reshape(-1).contiguous() if sources is not None else None
+        n = x.numel()
+        while True:
+            count = t.zeros(1, dtype=t.int32, device=self.device)
+            rec = t.empty((capacity, 4), dtype=t.int32, device=self.device)
+            with t.cuda.device(self.device):
+                rc = self.lib.bpmf_bp_extract_peaks_dev(
+                    x.data_ptr(), src.data_ptr() if src is not None else None, n, float(floor),
+                    capacity, self._stream(), count.data_ptr(), rec.data_ptr())
+            _lib.check(rc, "bpmf_bp_extract_peaks_dev")
+            found = int(count.item())
+            if found <= capacity:
+                break
+            capacity = found
+        out = rec[:found].cpu().numpy().view(peak_dtype).reshape(-1)
+        return out[np.argsort(out["index"], kind="stable")]

@@ -125,20 +125,100 @@ def bp_time_dependent_threshold_device(beam, window, n_dev, overlap=0.75):
                      left=thr[0], right=thr[-1])
 
 
+def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev=15.0, overlap=0.75,
+                           device=None):
+    """``Beamformer.find_detections`` (BPMF/template_search.py:574-627) on a max-beam that lives
+    on the device: `beam` (N,) float32 and `arg` (N,) int32 device tensors (the output of
+    BeamformerGPU.run).  Nothing of length N is downloaded:
+
+      1. threshold: per-window median / MAD by radix select on the device (csrc/bp_detect.hip),
+         n_windows + 2 node values to the host (`threshold` None), or a scalar given by the caller;
+      2. the rising-edge local maxima above the smallest threshold node, compacted on the device;
+      3. on that list: tallest-first min-distance suppression, the float64 threshold test at the
+         survivors, the +-mpd/2 snap (on windows of the beam gathered in one small transfer) and
+         np.unique -- the reference's own index logic (postprocess.find_beam_detections_from_candidates).
+
+    Returns (peak samples int64, source indices int32, threshold nodes (centre, values) or None)."""
+    import torch
+    from .threshold import BeamDetectorGPU
+    det = BeamDetectorGPU(device=device if device is not None else beam.device.index)
+    n = beam.numel()
+    nodes = None
+    if threshold is None:
+        med, mad = det.window_stats(beam, window, overlap)
+        centre, thr = pp.bp_threshold_nodes(n, int(window), overlap, med, mad, n_dev)
+        nodes = (centre, thr)
+        floor = float(np.min(thr.astype(np.float64)))
+
+        def threshold_at(samples):
+            return pp.interp_threshold(samples, centre, thr)
+    elif np.ndim(threshold) == 0:
+        floor = float(threshold)
+
+        def threshold_at(samples):
+            return np.full(len(samples), float(threshold))
+    else:
+        thr_arr = np.asarray(threshold)
+        floor = float(thr_arr.min())
+
+        def threshold_at(samples):
+            return thr_arr[samples]
+    if not np.isfinite(floor):
+        raise ValueError("the detection threshold is not finite (NaN in the max-beam?)")
+    rec = det.extract_peaks(beam, arg, floor)
+    # beam windows around every candidate that can survive, in ONE gather + transfer: the snap
+    # looks +-mpd/2 around a peak, and a snapped peak can be looked at once more (+-mpd covers it)
+    half = int(mpd) + 1
+    idx_all = rec["index"].astype(np.int64)
+    cache = {}
+    if idx_all.size:
+        keep_rank = np.argsort(rec["beam"].astype(np.float64))[::-1]
+        keep = pp._suppress(idx_all, keep_rank, mpd) if mpd > 1 else np.ones(idx_all.size, bool)
+        cand = idx_all[keep]
+        cand = cand[rec["beam"][keep].astype(np.float64) > threshold_at(cand)]
+        if cand.size:
+            offs = torch.arange(-half, half + 1, device=beam.device)
+            pos = (torch.as_tensor(cand, device=beam.device)[:, None] + offs[None, :]).clamp_(0, n - 1)
+            wins = beam.reshape(-1)[pos].cpu().numpy()
+            for c, wrow in zip(cand, wins):
+                cache[int(c)] = wrow
+    flat = beam.reshape(-1)
+
+    def beam_slice(i0, i1):
+        for c, wrow in cache.items():            # a handful of entries: linear search is fine
+            lo = c - half
+            if i0 >= max(lo, 0) and i1 <= min(c + half + 1, n) and lo >= 0 and c + half < n:
+                return wrow[i0 - lo:i1 - lo]
+        return flat[i0:i1].cpu().numpy()         # rare: a window no candidate's gather covers
+
+    peaks = pp.find_beam_detections_from_candidates(idx_all, rec["beam"], threshold_at, mpd, n, beam_slice)
+    if peaks.size:
+        src = arg.reshape(-1)[torch.as_tensor(peaks, device=arg.device)].cpu().numpy()
+    else:
+        src = np.zeros(0, dtype=np.int32)
+    return peaks, src, nodes
+
+
 def backprojection_detections(features, moveouts, weights_phases, weights_sources, *, sr,
                               minimum_interevent_time, threshold_window_dur=None, n_dev=15.0,
-                              overlap=0.75, threshold=None, out_of_bounds="strict", device=None):
-    """Backprojection of one day: returns (peak samples, source indices, maxbeam, argmax)."""
+                              overlap=0.75, threshold=None, out_of_bounds="strict", device=None,
+                              return_device=False):
+    """Backprojection of one day: returns (peak samples, source indices, maxbeam, argmax).
+
+    The max-beam and its arg-max stay on the device through the whole detection stage
+    (beam_detections_device); they are downloaded at the end only because this function returns
+    them as arrays -- pass return_device=True to get the device tensors instead."""
     bf = BeamformerGPU(moveouts, weights_sources, device=device)
     beam, arg = bf.run(features, weights_phases, "max", out_of_bounds)
-    maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
-    if threshold is None:
-        window = int(pp.sec_to_samp(threshold_window_dur, sr))
-        threshold = bp_time_dependent_threshold_device(beam, window, n_dev, overlap=overlap)
-    bf.close()
     mpd = int(pp.sec_to_samp(minimum_interevent_time, sr))
-    peaks, peak_sources = pp.find_beam_detections(maxbeam, sources, threshold, mpd)
-    return peaks, peak_sources, maxbeam, sources
+    window = None if threshold is not None else int(pp.sec_to_samp(threshold_window_dur, sr))
+    peaks, peak_sources, _ = beam_detections_device(beam, arg, mpd=mpd, threshold=threshold,
+                                                   window=window, n_dev=n_dev, overlap=overlap,
+                                                   device=device)
+    bf.close()
+    if return_device:
+        return peaks, peak_sources, beam, arg
+    return peaks, peak_sources, beam.cpu().numpy(), arg.cpu().numpy()
 
 
 def numpy_order_sum(x):

@@ -79,3 +79,81 @@ def test_bp_threshold_on_device_equals_the_host_mirror():
         want = pp.bp_time_dependent_threshold(x, window, 15.0, overlap=overlap)
         got = bp_time_dependent_threshold_device(torch.as_tensor(x, device="cuda"), window, 15.0, overlap=overlap)
         assert np.array_equal(got, want), (n, window, overlap)
+
+
+# ------------------------------------------------------- BP detection stage on the device ---
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_bp_window_stats_radix_select_equals_np_median():
+    """Per-window median / MAD by radix select (csrc/bp_detect.hip) == np.median in float32, bit
+    for bit: the reference's golden series, even / odd window lengths, windows cut short by the end
+    of the trace, heavy ties (rounded values), negative values, zeros of both signs."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import BeamDetectorGPU
+    det = BeamDetectorGPU()
+    g = _golden("bp_threshold.npz")
+    cases = [(g["maxbeam"], int(g["window"]), float(g["overlap"]))]
+    rng = np.random.default_rng(8)
+    for n, window, overlap in [(50_001, 3001, 0.75), (40_000, 3000, 0.5), (12_345, 1000, 0.9),
+                               (9_000, 9_000, 0.75), (400_000, 90_000, 0.75), (2_100, 2_049, 0.98)]:
+        x = (np.abs(rng.standard_normal(n)) * (1 + 5 * (rng.random(n) > 0.999))).astype(np.float32)
+        cases.append((x, window, overlap))
+    x = np.round(rng.standard_normal(30_000), 1).astype(np.float32)           # ties, negatives, +-0
+    x[::7] = -0.0
+    cases.append((x, 4_000, 0.75))
+    for x, window, overlap in cases:
+        n = x.size
+        shift = int((1.0 - overlap) * window)
+        nw = int((n - window) // shift) + 1
+        med, mad = det.window_stats(torch.as_tensor(x, device="cuda"), window, overlap)
+        assert med.shape == (nw + 2,)
+        for q in range(1, nw + 1):
+            seg = x[q * shift:min(n, q * shift + window)]
+            m = np.median(seg)
+            assert med[q] == m and mad[q] == np.median(np.abs(seg - m)), (n, window, q)
+        # the node values and the interpolated threshold are then the host mirror's (pinned to the golden)
+        centre, thr = pp.bp_threshold_nodes(n, window, overlap, med, mad, 15.0)
+        assert np.array_equal(pp.interp_threshold(np.arange(n), centre, thr),
+                              pp.bp_time_dependent_threshold(x, window, 15.0, overlap))
+    xn = cases[1][0].copy()
+    xn[7_000] = np.nan                                                       # np.median: NaN in -> NaN out
+    med, mad = det.window_stats(torch.as_tensor(xn, device="cuda"), 3001, 0.75)
+    shift = int(0.25 * 3001)
+    for q in range(1, med.size - 1):
+        assert np.isnan(med[q]) == (q * shift <= 7_000 < q * shift + 3001)
+
+
+def test_bp_detections_on_device_equal_the_host_mirror():
+    """beam_detections_device (nothing of length N leaves the GPU) == postprocess.find_beam_detections
+    on the downloaded series: the reference's goldens (constant threshold), and series with a
+    time-dependent threshold, plateaus, peaks below the local threshold next to peaks above it."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.workflow import beam_detections_device
+    g = _golden("bp_find_detections.npz")
+    for j in range(int(g["n_cases"])):
+        mb, src, thr, mpd = g[f"maxbeam_{j}"], g[f"sources_{j}"], g[f"thr_{j}"], int(g[f"mpd_{j}"])
+        peaks, psrc, _ = beam_detections_device(torch.as_tensor(mb, device="cuda"),
+                                                torch.as_tensor(src, device="cuda"), mpd=mpd,
+                                                threshold=float(thr[0]))
+        assert np.array_equal(peaks, g[f"peaks_{j}"]) and np.array_equal(psrc, g[f"peak_sources_{j}"])
+    rng = np.random.default_rng(12)
+    for n, window, mpd, gain in [(200_000, 20_000, 250, 1.0), (120_000, 9_000, 40, 4.0), (60_000, 6_000, 1, 1.0),
+                                 (80_000, 8_000, 501, 2.5)]:
+        x = np.abs(rng.standard_normal(n)).astype(np.float32)
+        x[n // 2:] *= np.float32(gain)                                       # noisier second half: threshold steps up
+        for p in rng.integers(1000, n - 1000, 40):
+            x[p - 3:p + 4] += np.float32(rng.uniform(3, 30)) * np.array([.2, .6, .9, 1, .9, .6, .2], np.float32)
+        x = np.round(x, 2)                                                   # exact ties and plateaus
+        src = rng.integers(0, 50_000, n).astype(np.int32)
+        want_thr = pp.bp_time_dependent_threshold(x, window, 8.0, overlap=0.75)
+        want_peaks, want_src = pp.find_beam_detections(x, src, want_thr, mpd)
+        peaks, psrc, nodes = beam_detections_device(torch.as_tensor(x, device="cuda"),
+                                                    torch.as_tensor(src, device="cuda"), mpd=mpd,
+                                                    window=window, n_dev=8.0, overlap=0.75)
+        assert np.array_equal(peaks, want_peaks) and np.array_equal(psrc, want_src), (n, window, mpd)
+        assert want_peaks.size >= 5

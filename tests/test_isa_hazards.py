@@ -49,6 +49,45 @@ k2:
     assert len(bad) == 1 and bad[0][2] == [1]
 
 
+def test_checker_tracks_hand_issued_vector_loads():
+    """vmcnt: loads return in order; only inline-asm loads have their destinations tracked, the
+    compiler's own loads just take a slot of the queue; a loop entered with an empty queue keeps
+    the steady-state order."""
+    listing = """
+k3:
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v0, s[2:3] offset:8
+	;;#ASMEND
+	global_load_dword v9, v1, s[2:3]
+	;;#ASMSTART
+	global_load_dwordx2 v[10:11], v0, s[2:3] offset:0
+	;;#ASMEND
+	v_add_u32_e32 v12, v9, v9
+	s_waitcnt vmcnt(1)
+	v_add_u32_e32 v12, v4, v5
+	v_add_u32_e32 v12, v10, v4
+	s_waitcnt vmcnt(0)
+	v_add_u32_e32 v12, v10, v4
+.LBB2_1:
+	v_add_u32_e32 v13, v4, v4
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v0, s[2:3] offset:8
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dwordx4 v[20:23], v0, s[2:3] offset:24
+	;;#ASMEND
+	s_waitcnt vmcnt(1)
+	s_cbranch_scc1 .LBB2_1
+	s_waitcnt vmcnt(0)
+	s_endpgm
+"""
+    bad = check_inflight.check_kernel(check_inflight.split_kernels(listing)["k3"])
+    # (1) v10 read under vmcnt(1) while its load is the youngest; (2) in the loop the second load
+    # re-targets v[20:23] while the previous trip's load of the same registers is still in flight
+    assert [(b[1].split()[0], b[2]) for b in bad] == [("v_add_u32_e32", [10]),
+                                                      ("global_load_dwordx4", [20, 21, 22, 23])]
+
+
 @pytest.mark.timeout(900)
 def test_beam_kernels_touch_no_register_in_flight(tmp_path):
     from seismic_bpmf_amd.build import ARCH, CSRC, find_hipcc
@@ -62,4 +101,24 @@ def test_beam_kernels_touch_no_register_in_flight(tmp_path):
     assert len(names) >= 16
     for n in names:
         bad = check_inflight.check_kernel(kernels[n])
+        assert not bad, f"{n}: {bad[:4]}"
+
+
+@pytest.mark.timeout(900)
+def test_fast_beam_kernels_touch_no_register_in_flight(tmp_path):
+    """bp_fast.hip: the interior-tile kernels (uniform-weight and per-station records)."""
+    from seismic_bpmf_amd.build import ARCH, CSRC, find_hipcc
+    out = tmp_path / "bp_fast.s"
+    cmd = [find_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+           "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "bp_fast.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    kernels = check_inflight.split_kernels(out.read_text())
+    names = [n for n in kernels if "bp_beam_fast_kernel" in n]
+    assert len(names) == 2
+    for n in names:
+        body = kernels[n]
+        assert sum(t.startswith("ds_read_b64") for t in body) > 1000      # the unrolled gathers are there
+        assert not any("scratch_" in t for t in body)                      # no spills
+        bad = check_inflight.check_kernel(body)
         assert not bad, f"{n}: {bad[:4]}"

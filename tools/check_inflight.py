@@ -1,5 +1,5 @@
 """Static hazard check of a gfx950 ISA listing (hipcc -S output) for the kernels that issue LDS / SMEM
-loads from inline asm.
+loads -- and, since round 2, vector-memory loads -- from inline asm.
 
 The compiler does not know that the destination registers of an inline-asm `ds_read*` / `s_load*`
 are still in flight: it may copy them, or hand a dead part of them out as a temporary, before the
@@ -42,6 +42,8 @@ def split_kernels(text):
             continue
         t = line.split(';')[0].strip()
         if not t:
+            if '#ASMSTART' in line or '#ASMEND' in line:     # inline-asm brackets: kept as markers
+                body.append('#ASMSTART' if '#ASMSTART' in line else '#ASMEND')
             continue
         if t.startswith('.') and not t.endswith(':'):
             if t.startswith('.Lfunc_end'):
@@ -57,6 +59,9 @@ def split_kernels(text):
 def _blocks(lines):
     blocks, cur, label = [], [], '<entry>'
     for t in lines:
+        if t.startswith('#ASM'):
+            cur.append(t)
+            continue
         if t.endswith(':'):
             blocks.append((label, cur))
             label, cur = t[:-1], []
@@ -88,7 +93,13 @@ def _run_block(lines, state, report=None):
     left in flight in an unknown order (only lgkmcnt(0) retires those).  Returns the end state."""
     q = [(k, set(d)) for k, d in state[0]]
     v_un, s_un = set(state[1]), set(state[2])
+    vq = [set(d) for d in state[3]] if len(state) > 3 else []     # vector-memory ops, in order (vmcnt)
+    vm_un = set(state[4]) if len(state) > 4 else set()
+    in_asm = False
     for t in lines:
+        if t.startswith('#ASM'):
+            in_asm = t == '#ASMSTART'
+            continue
         op = t.split()[0]
         args = t[len(op):]
         if op == 's_waitcnt':
@@ -100,8 +111,16 @@ def _run_block(lines, state, report=None):
                 elif not any(k == 'smem' for k, _ in q) and not s_un and not v_un:
                     while len(q) > n:      # LDS only: in-order return
                         q.pop(0)
+            m = re.search(r'vmcnt\((\d+)\)', t)
+            if m:
+                n = int(m.group(1))
+                if n == 0:
+                    vq, vm_un = [], set()
+                elif not vm_un:
+                    while len(vq) > n:     # loads and stores return in order on gfx9
+                        vq.pop(0)
             continue
-        v_fl = set(v_un).union(*[d for k, d in q if k == 'lds'])
+        v_fl = set(v_un).union(*[d for k, d in q if k == 'lds']).union(vm_un, *vq)
         s_fl = set(s_un).union(*[d for k, d in q if k == 'smem'])
         v_t, s_t = _regs(_V, args), _regs(_S, args)
         hit = (v_t & v_fl, s_t & s_fl)
@@ -113,17 +132,40 @@ def _run_block(lines, state, report=None):
             q.append(('lds', set()))
         elif op.startswith('s_load') or op.startswith('s_buffer_load'):
             q.append(('smem', _regs(_S, args.split(',')[0])))
-    return (tuple((k, frozenset(d)) for k, d in q), frozenset(v_un), frozenset(s_un))
+        elif re.match(r'(global|flat|buffer|scratch)_load', op) and ' lds' not in t:
+            # destinations are tracked for hand-issued (inline-asm) loads only: the compiler counts
+            # its own loads itself; they still take a slot of the in-order queue
+            vq.append(_regs(_V, args.split(',')[0]) if in_asm else set())
+        elif re.match(r'(global|flat|buffer|scratch)_(store|atomic)', op) or (' lds' in t and 'load' in op):
+            vq.append(set())               # counts in vmcnt, has no destination registers
+    # normal form of the vector-memory queue: at most 64 entries (vmcnt is a 6-bit counter: an
+    # older operation has completed), and no leading entries without tracked registers (dropping
+    # them only makes later vmcnt(n) retire less)
+    vq = vq[-64:]
+    while vq and not vq[0]:
+        vq.pop(0)
+    return (tuple((k, frozenset(d)) for k, d in q), frozenset(v_un), frozenset(s_un),
+            tuple(frozenset(d) for d in vq), frozenset(vm_un))
 
 
 def _merge(a, b):
     if a is None:
         return b
+    # vector-memory queue: when one predecessor's queue is a suffix of the other's (e.g. a loop
+    # entered with nothing in flight and continued with a steady-state queue), the longer one is a
+    # safe model of both -- vmcnt(n) keeps the youngest n of it, a superset of what is really left.
+    la, lb = a[3], b[3]
+    if len(la) < len(lb):
+        la, lb = lb, la
+    if lb == la[len(la) - len(lb):]:
+        vq, vm = la, a[4] | b[4]
+    else:
+        vq, vm = (), frozenset(set(a[4] | b[4]).union(*a[3], *b[3]))
     if a[0] == b[0]:
-        return (a[0], a[1] | b[1], a[2] | b[2])
+        return (a[0], a[1] | b[1], a[2] | b[2], vq, vm)
     v = set(a[1] | b[1]).union(*[d for k, d in a[0] + b[0] if k == 'lds'])
     s = set(a[2] | b[2]).union(*[d for k, d in a[0] + b[0] if k == 'smem'])
-    return ((), frozenset(v), frozenset(s))
+    return ((), frozenset(v), frozenset(s), vq, vm)
 
 
 def check_kernel(lines):
@@ -131,7 +173,7 @@ def check_kernel(lines):
     blocks, succ = _blocks(lines)
     n = len(blocks)
     entry = [None] * n
-    entry[0] = ((), frozenset(), frozenset())
+    entry[0] = ((), frozenset(), frozenset(), (), frozenset())
     work = [0]
     while work:
         i = work.pop(0)
@@ -158,7 +200,7 @@ def main(argv):
     for name, lines in split_kernels(text).items():
         if pat and not pat.search(name):
             continue
-        if not any('ds_read' in t or 's_load' in t for t in lines):
+        if not any('ds_read' in t or 's_load' in t or 'global_load' in t for t in lines):
             continue
         bad = check_kernel(lines)
         total += len(bad)

@@ -1,0 +1,30 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import seismic_bpmf_amd as sb
+from seismic_bpmf_amd import synthetic as syn, _lib
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+cfg = syn.BP_CONFIGS[which]
+slab = (0, 64) if cfg["grid"] == (125, 125, 8) else None
+geo = syn.make_bp_geometry(cfg["grid"], cfg["S"], cfg["P"], cfg["sr"], depth_slab=slab)
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+feat = torch.randn((cfg["S"], cfg["C"], cfg["N"]), device="cuda", generator=g).abs_()
+wp = torch.as_tensor(syn.phase_weights(cfg["S"], cfg["C"], cfg["P"]), device="cuda")
+res = {}
+for fast in ("0", "1"):
+    os.environ["BPMF_BP_FAST"] = fast
+    bf = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"])
+    b, a = bf.run(feat, wp, "max", "strict")
+    torch.cuda.synchronize()
+    _lib.profile_enable(True)
+    for _ in range(3):
+        b, a = bf.run(feat, wp, "max", "strict")
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    ms = np.mean(_lib.profile_times_ms(_lib.KERNEL_BP_BEAM))
+    s_act = float((geo["weights_sources"] != 0).sum(axis=1).mean())
+    tbs = 4.0 * s_act * cfg["P"] * geo["moveouts"].shape[0] * cfg["N"] / (ms * 1e-3) / 1e12
+    print(f"{which} FAST={fast}: {ms:.2f} ms, {tbs:.1f} TB/s = {tbs/157.3*100:.1f}% ; plan {bf.plan_info()}", flush=True)
+    res[fast] = (b.clone(), a.clone())
+    bf.close()
+print("identical:", torch.equal(res["0"][0], res["1"][0]), torch.equal(res["0"][1], res["1"][1]))

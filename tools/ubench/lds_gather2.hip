@@ -11,6 +11,12 @@
 //   KIND 7: KIND 6 with the epilogue as 8 v_max_f32 + 8 v_cmp + 8 v_cndmask ... same count, less deps
 //   KIND 8: KIND 1 without the per-unit v_add (address VGPR fixed; offsets immediate): issue floor
 //   KIND 9: fma only (4 v_pk_fma_f32 + v_add per unit)
+//   KIND 10: batches of 2 units: 8 reads, ONE s_waitcnt lgkmcnt(8), 8 v_pk_fma_f32 (ring of 2 batches)
+//   KIND 11: KIND 10 + the epilogue of KIND 6 every 20 units
+//   KIND 12: KIND 6 with 2 units in flight ahead instead of 3 (lgkmcnt(8), ring of 3)
+//   KIND 13: KIND 6 with the max update of source k spread over the first 8 unit steps of source k+1
+//            (1 v_cmp + 2 v_cndmask per step instead of a burst of 24 VALU without any LDS issue)
+//   KIND 14: KIND 13 with the update spread over 4 steps (2 slots per step)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +77,96 @@ __global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int strid
             ISSUE4(2) WAIT(6); FMA4(3)
         }
         WAIT(0); FMA4(0) FMA4(1) FMA4(2)
+    } else if constexpr (KIND == 10 || KIND == 11) {
+        f32x2 X[4][4];
+#define ISSUEB(u) { so = (so + stride) & 0x3ffeu; const unsigned a_ = base + so * 4; \
+        RD64(X[u][0], a_, 0); RD64(X[u][1], a_, 512); RD64(X[u][2], a_, 1024); RD64(X[u][3], a_, 1536); }
+#define FMAB(u) { _Pragma("unroll") for (int j = 0; j < 4; ++j) PKFMA_S(ac[j], sp, X[u][j]); }
+        ISSUEB(0) ISSUEB(1)
+        int since = 0;
+        for (int i = 0; i < n_units; i += 4) {
+            ISSUEB(2) ISSUEB(3) WAIT(8); FMAB(0) FMAB(1)
+            ISSUEB(0) ISSUEB(1) WAIT(8); FMAB(2) FMAB(3)
+            if (KIND == 11) {
+                since += 4;
+                if (since == 20) {
+                    since = 0;
+                    const int sid = i;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float a = ac[j >> 1][j & 1];
+                        const bool take = a > best[j];
+                        best[j] = take ? a : best[j];
+                        arg[j] = take ? sid : arg[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ac[j] = (f32x2){0, 0};
+                }
+            }
+        }
+        WAIT(0); FMAB(0) FMAB(1)
+    } else if constexpr (KIND == 13 || KIND == 14) {
+        f32x2 X[4][4];
+        f32x2 acp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acp[j] = (f32x2){0, 0};
+#define ISSUED(u) { so = (so + stride) & 0x3ffeu; const unsigned a_ = base + so * 4; \
+        RD64(X[u][0], a_, 0); RD64(X[u][1], a_, 512); RD64(X[u][2], a_, 1024); RD64(X[u][3], a_, 1536); }
+        ISSUED(0) ISSUED(1) ISSUED(2)
+        for (int i = 0; i < n_units; i += 20) {
+            const int sid = i;
+#pragma unroll
+            for (int u = 0; u < 20; ++u) {
+                ISSUED((u + 3) & 3) WAIT(12);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) PKFMA_S(ac[j], sp, X[u & 3][j]);
+                constexpr int PER = KIND == 13 ? 1 : 2;
+                if (u < 8 / PER) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int j = u * PER + q;
+                        const float a = acp[j >> 1][j & 1];
+                        unsigned long long mk;
+                        asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(mk) : "v"(a), "v"(best[j]));
+                        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(best[j]) : "v"(a), "s"(mk));
+                        int sv = sid;
+                        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(arg[j]) : "v"(sv), "s"(mk));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acp[j] = ac[j]; ac[j] = (f32x2){0, 0}; }
+        }
+        WAIT(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ac[j][0] += acp[j][0]; ac[j][1] += acp[j][1]; }
+    } else if constexpr (KIND == 12) {
+        f32x2 X[3][4];
+#define ISSUEC(u) { so = (so + stride) & 0x3ffeu; const unsigned a_ = base + so * 4; \
+        RD64(X[u][0], a_, 0); RD64(X[u][1], a_, 512); RD64(X[u][2], a_, 1024); RD64(X[u][3], a_, 1536); }
+#define FMAC(u) { _Pragma("unroll") for (int j = 0; j < 4; ++j) PKFMA_S(ac[j], sp, X[u][j]); }
+        ISSUEC(0) ISSUEC(1)
+        int since = 0;
+        for (int i = 0; i < n_units; i += 3) {
+            ISSUEC(2) WAIT(8); FMAC(0)
+            ISSUEC(0) WAIT(8); FMAC(1)
+            ISSUEC(1) WAIT(8); FMAC(2)
+            since += 3;
+            if (since >= 21) {
+                since = 0;
+                const int sid = i;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = ac[j >> 1][j & 1];
+                    const bool take = a > best[j];
+                    best[j] = take ? a : best[j];
+                    arg[j] = take ? sid : arg[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ac[j] = (f32x2){0, 0};
+            }
+        }
+        WAIT(0); FMAC(0) FMAC(1)
     } else {
         f32x2 X[4][4];
 #define ISSUE(u) { so = (so + stride) & 0x3ffeu; unsigned a_ = base; if (KIND != 8) a_ = base + so * 4; else asm volatile("" : "+v"(a_)); \
@@ -144,14 +240,17 @@ void run(int stride)
     fflush(stdout);
     hipFree(d);
 }
-int main()
+int main(int argc, char** argv)
 {
     const int st = 338;
+    if (argc > 1) {   // round-2 follow-up set
+        run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
+        run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
+        return 0;
+    }
     run<0, 16>(st); run<1, 16>(st); run<2, 16>(st); run<3, 16>(st); run<4, 16>(st); run<5, 16>(st);
     run<6, 16>(st); run<7, 16>(st); run<8, 16>(st); run<9, 16>(st);
     run<0, 8>(st); run<1, 8>(st); run<4, 8>(st); run<5, 8>(st);
-    run<0, 20>(st); run<1, 20>(st); run<6, 20>(st);
-    run<0, 24>(st); run<1, 24>(st); run<6, 24>(st);
     run<1, 12>(st); run<4, 4>(st); run<4, 12>(st);
     return 0;
 }
