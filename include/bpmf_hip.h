@@ -163,6 +163,24 @@ int bpmf_bp_pack_max_dev(const float *d_beam, const int32_t *d_arg, size_t N, in
 int bpmf_bp_unpack_max_dev(const uint64_t *d_packed, size_t N, int as_signed,
                            bpmf_stream_t stream, float *d_beam, int32_t *d_arg);
 
+/* ------------------------------------------------------- inter-template CC, batched --- */
+/*
+ * The core of TemplateGroup.compute_intertemplate_cc (BPMF/dataset.py:4775-4841) for ALL template
+ * pairs in one pass (the reference makes one fast_matched_filter call per template, :4818-4827):
+ *   out[t, u] = sum_{s,c} base_weights[t, s, c] * max_{lag} CC(trimmed template u, waveform t at lag)
+ * for the pairs with pair_mask[t, u] != 0, else 0; trimmed = samples [max_lag, Lw - max_lag),
+ * lag = 0 .. 2 max_lag; CC = the matched filter's normalised cross-correlation (zero moveouts),
+ * 0 on channels of zero weight; the channel sum runs in NumPy's pairwise order, so the matrix
+ * equals the reference's per-template loop bit for bit.  The caller symmetrises ((out + out^T)/2,
+ * dataset.py:4833-4834).
+ *   d_waveforms (T,S,C,Lw) f32   d_base_weights (T,S,C) f32   d_pair_mask (T,T) u8   d_out (T,T) f32
+ */
+size_t bpmf_intertemplate_workspace_bytes(size_t T, size_t S, size_t C, size_t max_lag);
+int bpmf_intertemplate_cc_dev(const float *d_waveforms, const float *d_base_weights,
+                              const uint8_t *d_pair_mask, size_t T, size_t S, size_t C, size_t Lw,
+                              size_t max_lag, void *d_workspace, size_t workspace_bytes,
+                              bpmf_stream_t stream, float *d_out);
+
 /* ------------------------------------------ detection stage behind the beamformer --- */
 /*
  * Device version of the two full-length steps of Beamformer.find_detections

@@ -53,6 +53,8 @@ SIGNATURES = {
                               _f, _i]),
     "bpmf_bp_pack_max_dev": (C.c_int, [_vp, _vp, _sz, C.c_int, _vp, _vp]),
     "bpmf_bp_unpack_max_dev": (C.c_int, [_vp, _sz, C.c_int, _vp, _vp, _vp]),
+    "bpmf_intertemplate_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
+    "bpmf_intertemplate_cc_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp]),
     "bpmf_bp_num_windows": (_sz, [_sz, _sz, _sz]),
     "bpmf_bp_window_stats_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp, _vp]),
     "bpmf_bp_extract_peaks_dev": (C.c_int, [_vp, _vp, _sz, C.c_double, C.c_uint32, _vp, _vp, _vp]),

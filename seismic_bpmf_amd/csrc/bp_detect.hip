@@ -104,7 +104,7 @@ __device__ float window_median(const float* __restrict__ x, int len, float centr
     float m = key_f32(hi);
     if ((len & 1) == 0) {
         const unsigned lo = window_select<DEV>(x, len, centre, (unsigned)(len / 2 - 1), hist, sel);
-        m = __fdiv_rn(__fadd_rn(key_f32(lo), m), 2.0f);
+        m = (key_f32(lo) + m) / 2.0f;      // float32 mean of the two middle values (exact halving)
     }
     return m;
 }

@@ -35,6 +35,7 @@
 #include "bp_plan.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace bpmf {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const int4* __restrict__ chunks, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg)
+    int* __restrict__ out_arg, int dbg)
 {
     extern __shared__ float lds[];
     constexpr int TPW = 8, TILE = BPF_TILE, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
@@ -96,9 +97,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 
     for (int g = 0; g < n_groups; ++g) {
         const BpFastGroup grp = groups[g];
-        __syncthreads();  // previous group's gathers are done
+        if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done
         // ---- staging: one chunk per wave, 16 bytes per lane, 8 chunks in flight per wave
-        {
+        // (dbg: timing ablations of tools/probe_bp_fast.py -- 1 skips the staging, 2 the barriers;
+        // results are wrong with either)
+        if (!(dbg & 1)) {
             constexpr int STG_R = 8;
             typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
             typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     if (4 * lane < dsc[r].w) *(f32x4v*)(lds + dsc[r].z + 4 * lane) = v[r];
             }
         }
-        __syncthreads();
+        if (!(dbg & 2)) __syncthreads();
 
         for (int rr = 0; rr < grp.n_run; ++rr) {
             const BpRun run = runs[grp.first_run + rr];
@@ -296,6 +299,8 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
     const long long n_tiles = tile_hi - tile_lo;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * BPF_WPB * BPF_TILE * sizeof(float));
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
+    const char* de = getenv("BPMF_BP_FAST_DBG");
+    const int dbg = de ? atoi(de) : 0;
 #define BPF_LAUNCH(UNI)                                                                            \
     do {                                                                                           \
         auto kern = bp_beam_fast_kernel<UNI>;                                                      \
@@ -304,7 +309,7 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, (const int4*)pl->d_chunks,  \
-            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg);             \
+            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, dbg);        \
     } while (0)
     if (pl->fast_uniform) BPF_LAUNCH(true); else BPF_LAUNCH(false);
 #undef BPF_LAUNCH

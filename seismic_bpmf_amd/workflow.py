@@ -247,7 +247,68 @@ def numpy_order_sum(x):
     return numpy_order_sum(x[..., :n2]) + numpy_order_sum(x[..., n2:])
 
 
-def intertemplate_cc(waveforms_arr, weights, max_lag=10, device=None):
+def factorise_pair_weights(weights):
+    """(T, T, S, C) weights -> (base (T, S, C), mask (T, T) bool) if, for every t, all non-zero rows
+    weights[t, u] are one and the same (S, C) pattern -- how the reference builds them
+    (dataset.py:4789-4816: template t's normalised station weights, zeroed for the templates beyond
+    the distance threshold); None otherwise."""
+    w = np.asarray(weights, dtype=np.float32)
+    T = w.shape[0]
+    mask = (w != 0).reshape(T, T, -1).any(axis=2)
+    base = np.zeros((T,) + w.shape[2:], dtype=np.float32)
+    for t in range(T):
+        rows = np.flatnonzero(mask[t])
+        if rows.size == 0:
+            continue
+        base[t] = w[t, rows[0]]
+        if not np.array_equal(w[t, rows], np.broadcast_to(base[t], (rows.size,) + base[t].shape)):
+            return None
+    return base, mask
+
+
+def intertemplate_cc(waveforms_arr, weights, max_lag=10, device=None, pair_mask=None):
+    """Pair-wise template similarity: intertp[t, u] = sum_{s,c} w[t][u,s,c] * max_lag CC, symmetrised.
+
+    waveforms_arr (T,S,C,L).  weights: (T, S, C) with pair_mask (T, T) -- row t's channel weights and
+    the pairs within the distance threshold, the factors the reference multiplies together
+    (dataset.py:4789-4816) -- or the full (T, T, S, C) array / a callable t -> (T, S, C).  Factorised
+    weights (given, or recognised in a full array) run as ONE batched launch
+    (bpmf_intertemplate_cc_dev); anything else takes the per-template loop of the reference
+    (intertemplate_cc_loop).  Both give the same bits."""
+    import torch
+    if not callable(weights):
+        w = np.asarray(weights, dtype=np.float32)
+        fact = None
+        if w.ndim == 3:
+            T = w.shape[0]
+            fact = (w, np.ones((T, T), bool) if pair_mask is None else np.asarray(pair_mask, dtype=bool))
+        elif w.ndim == 4 and pair_mask is None:
+            fact = factorise_pair_weights(w)
+        if fact is not None:
+            base, mask = fact
+            mf = MatchedFilterGPU(device=device)
+            wf = mf._dev(np.ascontiguousarray(waveforms_arr, dtype=np.float32), torch.float32)
+            T, S, Cc, Lw = wf.shape
+            base_d = mf._dev(np.ascontiguousarray(base, dtype=np.float32), torch.float32)
+            mask_d = torch.as_tensor(np.ascontiguousarray(mask, dtype=np.uint8), device=wf.device)
+            lib = mf.lib
+            ws = torch.empty(lib.bpmf_intertemplate_workspace_bytes(T, S, Cc, max_lag), dtype=torch.uint8,
+                             device=wf.device)
+            out = torch.empty((T, T), dtype=torch.float32, device=wf.device)
+            import ctypes as C
+            from . import _lib
+            with torch.cuda.device(wf.device):
+                rc = lib.bpmf_intertemplate_cc_dev(wf.data_ptr(), base_d.data_ptr(), mask_d.data_ptr(), T, S, Cc,
+                                                   Lw, int(max_lag), ws.data_ptr(), ws.numel(),
+                                                   C.c_void_p(torch.cuda.current_stream(wf.device).cuda_stream),
+                                                   out.data_ptr())
+            _lib.check(rc, "bpmf_intertemplate_cc_dev")
+            o = out.cpu().numpy()
+            return (o + o.T) / 2.0
+    return intertemplate_cc_loop(waveforms_arr, weights, max_lag=max_lag, device=device)
+
+
+def intertemplate_cc_loop(waveforms_arr, weights, max_lag=10, device=None):
     """Pair-wise template similarity: intertp[t, u] = sum_{s,c} w[t][u,s,c] * max_lag CC.
 
     waveforms_arr (T,S,C,L); weights (T, T, S, C), or a callable t -> (T, S, C) -- row t holds the

@@ -108,9 +108,20 @@ def _run_block(lines, state, report=None):
                 n = int(m.group(1))
                 if n == 0:
                     q, v_un, s_un = [], set(), set()
-                elif not any(k == 'smem' for k, _ in q) and not s_un and not v_un:
-                    while len(q) > n:      # LDS only: in-order return
-                        q.pop(0)
+                elif not v_un:
+                    # at most n operations are outstanding in total.  LDS operations return in
+                    # order among themselves, scalar loads in any order: whatever the scalar loads
+                    # do, at most the n youngest LDS operations can still be in flight; every
+                    # scalar load may be (only lgkmcnt(0) proves one complete)
+                    n_lds = sum(1 for k, _ in q if k == 'lds')
+                    drop = max(0, n_lds - n)
+                    kept = []
+                    for k, d in q:
+                        if k == 'lds' and drop > 0:
+                            drop -= 1
+                            continue
+                        kept.append((k, d))
+                    q = kept
             m = re.search(r'vmcnt\((\d+)\)', t)
             if m:
                 n = int(m.group(1))
@@ -144,25 +155,38 @@ def _run_block(lines, state, report=None):
     vq = vq[-64:]
     while vq and not vq[0]:
         vq.pop(0)
+    q = q[-16:]                    # lgkmcnt is a 4-bit counter
     return (tuple((k, frozenset(d)) for k, d in q), frozenset(v_un), frozenset(s_un),
             tuple(frozenset(d) for d in vq), frozenset(vm_un))
+
+
+def _merge_queue(qa, qb, kinded):
+    """Element-wise merge of two in-order queues, aligned at their YOUNG end: slot i from the end
+    retires at the same counter value in both predecessors, so the union of the two destination
+    sets is a sound model of it; older entries that only one predecessor has are kept (they can
+    only make a later wait retire less).  Returns None if the kinds (LDS / SMEM) disagree."""
+    if len(qa) < len(qb):
+        qa, qb = qb, qa
+    out = list(qa)
+    off = len(qa) - len(qb)
+    for i, e in enumerate(qb):
+        if kinded:
+            if out[off + i][0] != e[0]:
+                return None
+            out[off + i] = (e[0], out[off + i][1] | e[1])
+        else:
+            out[off + i] = out[off + i] | e
+    return tuple(out)
 
 
 def _merge(a, b):
     if a is None:
         return b
-    # vector-memory queue: when one predecessor's queue is a suffix of the other's (e.g. a loop
-    # entered with nothing in flight and continued with a steady-state queue), the longer one is a
-    # safe model of both -- vmcnt(n) keeps the youngest n of it, a superset of what is really left.
-    la, lb = a[3], b[3]
-    if len(la) < len(lb):
-        la, lb = lb, la
-    if lb == la[len(la) - len(lb):]:
-        vq, vm = la, a[4] | b[4]
-    else:
-        vq, vm = (), frozenset(set(a[4] | b[4]).union(*a[3], *b[3]))
-    if a[0] == b[0]:
-        return (a[0], a[1] | b[1], a[2] | b[2], vq, vm)
+    vq = _merge_queue(a[3], b[3], False)
+    vm = a[4] | b[4]
+    q = _merge_queue(a[0], b[0], True)
+    if q is not None:
+        return (q, a[1] | b[1], a[2] | b[2], vq, vm)
     v = set(a[1] | b[1]).union(*[d for k, d in a[0] + b[0] if k == 'lds'])
     s = set(a[2] | b[2]).union(*[d for k, d in a[0] + b[0] if k == 'smem'])
     return ((), frozenset(v), frozenset(s), vq, vm)

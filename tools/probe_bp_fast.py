@@ -7,12 +7,20 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 cfg = syn.BP_CONFIGS[which]
 slab = (0, 64) if cfg["grid"] == (125, 125, 8) else None
 geo = syn.make_bp_geometry(cfg["grid"], cfg["S"], cfg["P"], cfg["sr"], depth_slab=slab)
+if len(sys.argv) > 2 and sys.argv[2] == "exact10":   # exactly 10 stations per source (no ties at the cut-off): one run per group
+    first = geo["moveouts"][:, :, 0].astype(np.int64) * 64 + np.arange(cfg["S"])[None, :]
+    order = np.argsort(first, axis=1)
+    w = np.zeros_like(geo["weights_sources"])
+    np.put_along_axis(w, order[:, :10], 0.1, axis=1)
+    geo["weights_sources"] = w.astype(np.float32)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 feat = torch.randn((cfg["S"], cfg["C"], cfg["N"]), device="cuda", generator=g).abs_()
 wp = torch.as_tensor(syn.phase_weights(cfg["S"], cfg["C"], cfg["P"]), device="cuda")
 res = {}
-for fast in ("0", "1"):
+variants = [("0", "0"), ("1", "0")] + ([("1", "1"), ("1", "3")] if "ablate" in sys.argv else [])
+for fast, dbg in variants:
     os.environ["BPMF_BP_FAST"] = fast
+    os.environ["BPMF_BP_FAST_DBG"] = dbg
     bf = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"])
     b, a = bf.run(feat, wp, "max", "strict")
     torch.cuda.synchronize()
@@ -24,7 +32,8 @@ for fast in ("0", "1"):
     ms = np.mean(_lib.profile_times_ms(_lib.KERNEL_BP_BEAM))
     s_act = float((geo["weights_sources"] != 0).sum(axis=1).mean())
     tbs = 4.0 * s_act * cfg["P"] * geo["moveouts"].shape[0] * cfg["N"] / (ms * 1e-3) / 1e12
-    print(f"{which} FAST={fast}: {ms:.2f} ms, {tbs:.1f} TB/s = {tbs/157.3*100:.1f}% ; plan {bf.plan_info()}", flush=True)
-    res[fast] = (b.clone(), a.clone())
+    print(f"{which} FAST={fast} DBG={dbg}: {ms:.2f} ms, {tbs:.1f} TB/s = {tbs/157.3*100:.1f}% ; plan {bf.plan_info()}", flush=True)
+    if dbg == "0":
+        res[fast] = (b.clone(), a.clone())
     bf.close()
 print("identical:", torch.equal(res["0"][0], res["1"][0]), torch.equal(res["0"][1], res["1"][1]))

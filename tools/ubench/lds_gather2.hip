@@ -221,11 +221,12 @@ __global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int strid
     out[blockIdx.x * 64 * WPB + threadIdx.x] = r;
 }
 
+static int g_units = 200000;   // per wave; 200000 = ~13 ms, 3000000 = ~200 ms (sustained clocks)
 template <int KIND, int WPB>
 void run(int stride)
 {
     float* d; hipMalloc(&d, 256 * 2048 * sizeof(float));
-    const int n = 200000;
+    const int n = g_units;
     hipFuncSetAttribute((const void*)k<KIND, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, 1000, stride);
@@ -243,6 +244,7 @@ void run(int stride)
 int main(int argc, char** argv)
 {
     const int st = 338;
+    if (argc > 2) g_units = atoi(argv[2]);
     if (argc > 1) {   // round-2 follow-up set
         run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
         run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
