@@ -71,8 +71,16 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const int4* __restrict__ chunks, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int dbg)
+    int* __restrict__ out_arg)
 {
+    // timing ablations (build with -DBPF_DBG=<bits>, see tools/probe_bp_fast.py): 1 skips the staging,
+    // 2 the barriers, 8 the record refills (every source re-uses the first record), 16 the max
+    // update -- results are WRONG with any of them; 4 = the register-staged copy of round 1
+    // (results identical).  Measured at cfg3 (profiles/r02_bp_ablation.txt).
+#ifndef BPF_DBG
+#define BPF_DBG 0
+#endif
+    constexpr int dbg = BPF_DBG;
     extern __shared__ float lds[];
     constexpr int TPW = 8, TILE = BPF_TILE, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     const int tid = threadIdx.x;
@@ -99,9 +107,43 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         const BpFastGroup grp = groups[g];
         if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done
         // ---- staging: one chunk per wave, 16 bytes per lane, 8 chunks in flight per wave
-        // (dbg: timing ablations of tools/probe_bp_fast.py -- 1 skips the staging, 2 the barriers;
-        // results are wrong with either)
-        if (!(dbg & 1)) {
+        if (!(dbg & 1) && !(dbg & 4)) {
+            // LDS-DMA: a chunk (<= 256 consecutive floats of one prestacked row) goes global -> LDS
+            // in ONE instruction per wave (16 bytes per lane, destination = wave-uniform base +
+            // 16 * lane), without staging registers and without ds_write_b128 (13 cycles each): a
+            // wave fetches the descriptors of all its chunks of the group (one round trip), then
+            // issues all its copies back to back (one more).  The register-staged version below
+            // paid two dependent round trips per 8 chunks per wave: 5.5 % of the kernel at cfg3.
+            // The copies count in vmcnt; __syncthreads() waits for them (vmcnt(0)) before the barrier.
+            constexpr int STG_R = 16;
+            const int nck = grp.n_chunk;
+            const i32x4* chunks4 = (const i32x4*)chunks;
+            for (int c0 = wv; c0 < nck; c0 += WPB * STG_R) {
+                i32x4 dsc[STG_R];    // {row, first sample relative to t0, LDS float offset, floats}
+#pragma unroll
+                for (int r = 0; r < STG_R; ++r) {
+                    const int c = c0 + r * WPB;
+                    dsc[r] = chunks4[grp.first_chunk + min(c, nck - 1) + vzero];
+                    if (c >= nck) dsc[r][3] = 0;
+                }
+                // every descriptor has landed before the first copy is issued: beside a copy in
+                // flight hipcc waits vmcnt(0) at each use of an ordinary load's result, which would
+                // serialise the copies
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(dsc[0]), "+v"(dsc[1]), "+v"(dsc[2]), "+v"(dsc[3]), "+v"(dsc[4]), "+v"(dsc[5]),
+                               "+v"(dsc[6]), "+v"(dsc[7]), "+v"(dsc[8]), "+v"(dsc[9]), "+v"(dsc[10]), "+v"(dsc[11]),
+                               "+v"(dsc[12]), "+v"(dsc[13]), "+v"(dsc[14]), "+v"(dsc[15]));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < STG_R; ++r) {
+                    const float* src = U + (size_t)dsc[r][0] * (size_t)N + (t0 + dsc[r][1]) + 4 * lane;
+                    float* dst = lds + __builtin_amdgcn_readfirstlane(dsc[r][2]);
+                    if (4 * lane < dsc[r][3])
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        } else if (!(dbg & 1)) {
             constexpr int STG_R = 8;
             typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
             typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -190,7 +232,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     i32x2 sp_u;
                     // the header of the next source (the table is padded by one round of records: no clamp)
                     p = (const int*)((const char*)p + rec_stride);
-                    BPF_LOADX2(h_next, vzero, p, 0);
+                    if (!(dbg & 8)) BPF_LOADX2(h_next, vzero, p, 0);
+                    else h_next = h_cur;
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
                         // ---- keep three units in flight ahead of unit u: the unit issued now belongs to
@@ -219,7 +262,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             else BPF_PKFMA(ac[jj], sp, X[u & 3][jj]);
                         }
                         // ---- quad u / 4 is consumed (addresses issued, weights multiplied): refill it
-                        if (u % 4 == 3) {
+                        if (u % 4 == 3 && !(dbg & 8)) {
                             switch (u >> 2) {
                                 case 0: BPF_LOADQ(0); break; case 1: BPF_LOADQ(1); break;
                                 case 2: BPF_LOADQ(2); break; case 3: BPF_LOADQ(3); break;
@@ -230,7 +273,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     }
                     // ---- max / arg-max update, strict >: 8 compares, then 16 selects; the next source's
                     // first three units are in flight meanwhile
-                    {
+                    if (!(dbg & 16)) {
                         unsigned long long mk[TPW];
 #pragma unroll
                         for (int j = 0; j < TPW; ++j)
@@ -299,8 +342,6 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
     const long long n_tiles = tile_hi - tile_lo;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * BPF_WPB * BPF_TILE * sizeof(float));
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
-    const char* de = getenv("BPMF_BP_FAST_DBG");
-    const int dbg = de ? atoi(de) : 0;
 #define BPF_LAUNCH(UNI)                                                                            \
     do {                                                                                           \
         auto kern = bp_beam_fast_kernel<UNI>;                                                      \
@@ -309,7 +350,7 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, (const int4*)pl->d_chunks,  \
-            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, dbg);        \
+            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg);             \
     } while (0)
     if (pl->fast_uniform) BPF_LAUNCH(true); else BPF_LAUNCH(false);
 #undef BPF_LAUNCH

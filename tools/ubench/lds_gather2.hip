@@ -31,10 +31,16 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 template <int KIND, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int stride)
+__global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int stride, int random_data)
 {
     extern __shared__ float lds[];
-    for (int i = threadIdx.x; i < 35840; i += 64 * WPB) lds[i] = (float)(i & 15);
+    // g_random (argv[3]): pseudo-random LDS contents instead of a 16-value pattern -- data toggling
+    // costs power, and the sustained clock (hence the rate) depends on it
+    for (int i = threadIdx.x; i < 35840; i += 64 * WPB) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        lds[i] = random_data ? (float)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f : (float)(i & 15);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,6 +227,7 @@ __global__ __launch_bounds__(64 * WPB) void k(float* out, int n_units, int strid
     out[blockIdx.x * 64 * WPB + threadIdx.x] = r;
 }
 
+static int g_random = 0;
 static int g_units = 200000;   // per wave; 200000 = ~13 ms, 3000000 = ~200 ms (sustained clocks)
 template <int KIND, int WPB>
 void run(int stride)
@@ -229,14 +236,14 @@ void run(int stride)
     const int n = g_units;
     hipFuncSetAttribute((const void*)k<KIND, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, 1000, stride);
+    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, 1000, stride, g_random);
     hipEventRecord(e0);
-    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, n, stride);
+    k<KIND, WPB><<<256, 64 * WPB, 140 * 1024>>>(d, n, stride, g_random);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double per_unit = (KIND == 5 ? 8 : 4) * 512.0;   // bytes gathered per unit and wave
     const double bytes = 256.0 * WPB * (double)n * per_unit;
-    printf("kind %d, %2d waves/CU, stride %4d: %.1f TB/s gathered (%.1f%% of 157.3), %.1f ms\n", KIND, WPB, stride,
+    printf("kind %d, %2d waves/CU, random %d, stride %4d: %.1f TB/s gathered (%.1f%% of 157.3), %.1f ms\n", KIND, WPB, g_random, stride,
            bytes / ms / 1e9, bytes / ms / 1e9 / 157.3 * 100, ms);
     fflush(stdout);
     hipFree(d);
@@ -245,6 +252,7 @@ int main(int argc, char** argv)
 {
     const int st = 338;
     if (argc > 2) g_units = atoi(argv[2]);
+    if (argc > 3) g_random = atoi(argv[3]);
     if (argc > 1) {   // round-2 follow-up set
         run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
         run<1, 16>(st); run<6, 16>(st); run<13, 16>(st); run<14, 16>(st);
