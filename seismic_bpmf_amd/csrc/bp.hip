@@ -1349,6 +1349,11 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             bpmf_bp_plan_destroy(pl);
             return rc;
         }
+        if (any) {
+            BPMF_HIP_CHECK(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
+            BPMF_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+            BPMF_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+        }
         pl->fast = any;
         pl->fast_uniform = uniform;
         pl->fast_rec_dw = rec_dw;
@@ -1379,6 +1384,9 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     (void)hipFree(pl->d_termsv);
     (void)hipFree(pl->d_recs);
     (void)hipFree(pl->d_hdr2);
+    if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
+    if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+    if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     (void)hipFree(pl->d_fgroups);
     (void)hipFree(pl->d_fruns);
     (void)hipFree(pl->d_frecs);
@@ -1667,15 +1675,24 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         hi = std::max(lo, std::min(hi, n_all));
         profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
         int rc = 0;
+        const bool have_edge = lo > 0 || hi < n_all;
+        hipStream_t es = stream;          // edge tiles: on the side stream, beside the interior kernel
+        if (have_edge && pl->side_stream) {
+            BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
+            BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
+            es = pl->side_stream;
+        }
         auto edge = [&](long long base, long long count) {
             if (count <= 0 || rc) return;
             t_tile_base = base; t_tile_count = count;
-            rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
+            rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, es, d_beam_out, d_arg_out);
             t_tile_count = -1;
         };
         edge(0, lo);
-        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out);
         edge(hi, n_all - hi);
+        if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
+        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out);
+        if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
         profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
         return rc;
     }

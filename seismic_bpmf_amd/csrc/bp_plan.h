@@ -60,6 +60,11 @@ struct bpmf_bp_plan {
     bool fast_uniform = false;   // every source's non-zero weights are equal
     int fast_rec_dw = 0;         // dwords per record
     int tmin_all = 0, tmax_all = 0;   // extreme used moveouts over all sources
+    // the few edge tiles of a day run the general kernel on a side stream, beside the interior
+    // kernel (fork / join through the two events): a serial launch of 3-6 workgroups would add the
+    // full duration of one tile (5 ms at cfg3) to every call.  A plan serves one call at a time.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bpmf::BpFastGroup* d_fgroups = nullptr;
     bpmf::BpRun* d_fruns = nullptr;
     int* d_frecs = nullptr;

@@ -151,3 +151,70 @@ def test_bp_cfg5_share_full_day(oracle_lib):
         assert maxbeam[peaks[hit[0]]] >= maxbeam[t0] >= 8.0
     for b in (full, r0, r1):
         b.close()
+
+
+def test_mf_cfg2_all_500_templates_full_day():
+    """BASELINE configs[1] at its full size, all 500 templates: every planted event (5 per template)
+    is found by the device detection stage at EXACTLY its planted CC index (a handful may share a
+    merge window with a stronger one), template blocks concatenate to the single pass bit for bit,
+    re-running is bit-identical, |CC| <= 1."""
+    import torch
+    from seismic_bpmf_amd import MatchedFilterGPU, synthetic as syn
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    cfg = syn.MF_CONFIGS["cfg2"]
+    T, S, C, L, N = cfg["T"], cfg["S"], cfg["C"], cfg["L"], cfg["N"]
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    data = torch.randn((S, C, N), device=dev, generator=g)
+    raw = torch.randn((T, S, C, L + 4), device=dev, generator=g)
+    tmpl = sum(raw[..., k:k + L] for k in range(5))
+    tmpl = tmpl - tmpl.mean(dim=-1, keepdim=True)
+    tmpl = (tmpl / tmpl.std(dim=-1, keepdim=True)).contiguous()
+    mv_p = torch.randint(0, 1501, (T, S), device=dev, generator=g)
+    mv_s = mv_p + torch.randint(0, 1501, (T, S), device=dev, generator=g)
+    mv = torch.empty((T, S, C), dtype=torch.int32, device=dev)
+    mv[:, :, 0] = mv_p
+    mv[:, :, 1:] = mv_s[:, :, None]
+    w = torch.full((T, S, C), 1.0 / (S * C), device=dev)
+    n_ev = 5
+    slots = torch.randint(0, (N - L - 3002) // (4 * L), (T, n_ev), device=dev, generator=g)
+    amps = 1.5 + 2.5 * torch.rand((T, n_ev), device=dev, generator=g)
+    ar = torch.arange(L, device=dev)
+    for t in range(T):
+        for e in range(n_ev):
+            j = (slots[t, e] * 4 * L + mv[t].long())[..., None] + ar
+            data.scatter_add_(2, j, amps[t, e] * tmpl[t])
+    data /= data.std(dim=-1, keepdim=True)
+    planted = (slots * 4 * L).cpu().numpy()
+    mf = MatchedFilterGPU()
+    mf.set_data(data)
+    cc = mf.run(tmpl, mv, w, 1)
+    assert cc.shape == (T, N - L + 1) and float(cc.abs().max()) <= 1.0 + 1e-5
+    again = mf.run(tmpl, mv, w, 1)
+    assert torch.equal(cc, again)
+    del again
+    k = 187
+    part = mf.run(tmpl[:k], mv[:k], w[:k], 1)
+    assert torch.equal(cc[:k], part)
+    del part
+    part = mf.run(tmpl[k:], mv[k:], w[k:], 1)
+    assert torch.equal(cc[k:], part)
+    del part
+    th = ThresholdGPU()
+    wn = np.random.default_rng(5).standard_normal(500).astype(np.float32)
+    thr_win, _ = th.time_dependent_threshold(cc, 180_000, 8.0, overlap=0.25, white_noise=wn)
+    cand = th.extract_candidates(cc, thr_win, 180_000, overlap=0.25)
+    exact = 0
+    for t in range(T):
+        mine = cand[cand["row"] == t]
+        idx, val = list(mine["index"]), list(mine["cc"])
+        q = 1
+        while q < len(idx):                       # pair-wise merge, similarity_search.py:240-251
+            if idx[q] - idx[q - 1] < 512:
+                drop = q - 1 if val[q] > val[q - 1] else q
+                del idx[drop], val[drop]
+            else:
+                q += 1
+        exact += len(set(idx) & set(planted[t].tolist()))
+    assert exact >= T * n_ev - 5, exact

@@ -12,8 +12,9 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for p in glob.glob("$R/gpurun_out/bptraffic_$TAG/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(p)):
-        if "bp_beam" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in agg.items():
-    print("$TAG", k, "KiB mean per launch", sum(v) / len(v), "launches", len(v))
+        for kern in ("bp_beam_fast", "bp_beam_wps2"):     # interior kernel / the few edge tiles of a day
+            if kern in r["Kernel_Name"]:
+                agg[(kern, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (kern, k), v in sorted(agg.items()):
+    print("$TAG", kern, k, "KiB mean per launch", sum(v) / len(v), "launches", len(v))
 PY

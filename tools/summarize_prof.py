@@ -36,4 +36,4 @@ if __name__ == "__main__":
             if d_ not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d_]):
                 newest[d_] = f
         pm = list(newest.values())
-        print(json.dumps(pmc(pm, ["mf_mfma", "bp_beam", "mf_csum_local", "bp_prestack", "tdt_window"], f"profiles/{tag}_pmc.json"), indent=1))
+        print(json.dumps(pmc(pm, ["mf_mfma", "bp_beam_fast", "bp_beam_wps2", "mf_csum_local", "bp_prestack", "tdt_window", "bp_window_stats", "bp_extract_peaks", "intertp_cc"], f"profiles/{tag}_pmc.json"), indent=1))
