@@ -255,3 +255,35 @@ def test_host_apis_split_work_over_a_device_list(oracle_lib):
             assert ma.dtype == np.int32 and np.array_equal(ma, oa), (dev, oob)
     full = oracle_lib.beamform(f, tau, wp, ws, "strict", "none")
     _assert_same(beamform(f, tau, wp, ws, device="gpu", reduce="none", device_id=[0, 0, 0]), full, "BP none split")
+
+
+@pytest.mark.gpu
+def test_host_apis_on_several_real_devices_and_device_restore(oracle_lib):
+    """(a) Every host entry point restores the caller's current device and binds its own thread
+    to the device it is given -- also on a plan-cache hit, where round 1 skipped the hipSetDevice
+    (ADVICE r1): beamform() twice with the same tables must give the same, correct result the
+    second time (the plan comes from the library's cache).  (b) With more than one GPU visible
+    the default device list really spans them; run twice to hit every per-device cache slot."""
+    import torch
+    from seismic_bpmf_amd import beamform, matched_filter
+    from seismic_bpmf_amd import _lib
+    rng = np.random.default_rng(31)
+    f, tau, wp, ws = _bp_case(rng, 257, 6, 3, 2, 5000, 150)
+    ob, oa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    n_dev = _lib.device_count()
+    before = torch.cuda.current_device()
+    for dev in ([0], None, list(range(n_dev)), [n_dev - 1]):
+        for _ in range(2):                            # second call: plan-cache hit on every device
+            mb, ma = beamform(f, tau, wp, ws, device="gpu", reduce="max", device_id=dev)
+            assert np.array_equal(mb, ob) and np.array_equal(ma, oa), dev
+            assert torch.cuda.current_device() == before
+    tp = rng.standard_normal((5, 3, 2, 40)).astype(np.float32)
+    data = rng.standard_normal((3, 2, 5000)).astype(np.float32)
+    mv = rng.integers(0, 60, (5, 3, 2)).astype(np.int32)
+    w = rng.random((5, 3, 2)).astype(np.float32)
+    want = oracle_lib.matched_filter(tp, mv, w, data, 1)
+    for dev in (None, [n_dev - 1]):
+        assert np.array_equal(matched_filter(tp, mv, w, data, 1, arch="gpu", device=dev, check_zeros=False), want)
+        assert torch.cuda.current_device() == before
+    with pytest.raises(_lib.BpmfHipError, match="out of range"):
+        beamform(f, tau, wp, ws, device="gpu", device_id=[n_dev])
