@@ -1057,7 +1057,10 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     // spread per row (dense station weights), use the whole LDS (one workgroup per CU) instead of
     // degenerating to one source per group.  (Measured on cfg3 geometry, 10 / 15 / 20 used
     // stations: 0.35 / 0.64 / 0.91 s.)
-    const size_t base_need = (size_t)tile + max_terms * row_cost(0);
+    // dual plans (bp_fast.hip) keep 4 KB behind the zero slab for the next group's window descriptors
+    // (16 bytes per window; a group has at most 2 S P windows)
+    const size_t slab_extra = dual ? (size_t)4 * std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64) : 0;
+    const size_t base_need = (size_t)tile + slab_extra + max_terms * row_cost(0);
     // More than 16 stations (P = 2: 32 terms): the packed kernel runs one 16-wave workgroup per CU.
     if (base_need + max_terms * (row_cost(16) - row_cost(0)) > soft_floats || (P == 2 && max_terms > 32))
         soft_floats = hard_floats;
@@ -1072,7 +1075,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     size_t first = 0;
     while (first < K) {
         std::fill(used.begin(), used.end(), 0);
-        size_t need = (size_t)tile, q = first;  // the zero slab
+        size_t need = (size_t)tile + slab_extra, q = first;  // the zero slab (+ the descriptor slab)
         for (; q < K && (int)(q - first) < max_group; ++q) {
             const size_t k = (size_t)order[q];
             size_t need2 = need;
@@ -1107,7 +1110,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
         }
         // close group [first, q): lay the windows out after the zero slab, cut them in chunks
         BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
-        size_t o = (size_t)tile;
+        size_t o = (size_t)tile + slab_extra;
         for (size_t r = 0; r < SP; ++r) {
             base[r] = -1;
             if (!used[r]) continue;
@@ -1309,10 +1312,23 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         const int rec_dw = (2 + 2 * std::max(pl->nsv, 4) + 3) / 4 * 4;
         std::vector<BpFastGroup> fg;
         std::vector<BpRun> fr;
+        std::vector<BpWindow> fw;
         std::vector<int> rec;
         std::vector<int> order;
+        bool wins_ok = true;
         for (const BpGroup& g : ph.groups) {
-            BpFastGroup f{(int)fr.size(), 0, g.first_chunk, g.n_chunk};
+            // the group's staging chunks (pieces of <= 256 floats), merged back into whole windows
+            BpFastGroup f{(int)fr.size(), 0, (int)fw.size(), 0};
+            for (int c = g.first_chunk; c < g.first_chunk + g.n_chunk; ++c) {
+                const BpChunk& ck = ph.chunks[c];
+                if (!fw.empty() && (int)fw.size() > f.first_win && fw.back().row == ck.row &&
+                    fw.back().gofs + fw.back().len == ck.gofs && fw.back().dst + fw.back().len == ck.dst)
+                    fw.back().len += ck.n;
+                else
+                    fw.push_back(BpWindow{ck.row, ck.gofs, ck.dst, ck.n});
+            }
+            f.n_win = (int)fw.size() - f.first_win;
+            wins_ok = wins_ok && f.n_win <= BPF_DESC_MAX;
             for (int nst = 4; nst <= 16; nst += 2) {        // a group's sources are listed by ascending id
                 order.clear();                              // (1-2 stations: padded to 4 with zero-slab terms)
                 for (int q = g.first_src; q < g.first_src + g.n_src; ++q)
@@ -1344,8 +1360,10 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             fg.push_back(f);
         }
         rec.resize(rec.size() + (size_t)16 * rec_dw, 0);   // one round of records: the prefetch past the last source
+        fw.resize(fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});   // the descriptor prefetch past the last group
+        any = any && wins_ok;                              // > 256 windows in a group: general kernel
         if (any && ((rc = upload(fg, &pl->d_fgroups)) || (rc = upload(fr, &pl->d_fruns)) ||
-                    (rc = upload(rec, &pl->d_frecs)))) {
+                    (rc = upload(fw, &pl->d_fwins)) || (rc = upload(rec, &pl->d_frecs)))) {
             bpmf_bp_plan_destroy(pl);
             return rc;
         }
@@ -1389,6 +1407,7 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     (void)hipFree(pl->d_fgroups);
     (void)hipFree(pl->d_fruns);
+    (void)hipFree(pl->d_fwins);
     (void)hipFree(pl->d_frecs);
     delete pl;
 }

@@ -69,14 +69,13 @@ constexpr int BPF_THREADS = 64 * BPF_WPB;
 template <bool UNI>
 __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
-    const BpRun* __restrict__ runs, const int4* __restrict__ chunks, const int* __restrict__ recs,
+    const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg)
+    int* __restrict__ out_arg, int desc_waves)
 {
-    // timing ablations (build with -DBPF_DBG=<bits>, see tools/probe_bp_fast.py): 1 skips the staging,
+    // timing ablations (build with -DBPF_DBG=<bits>, see tools/ablate_bp_fast.sh): 1 skips the staging,
     // 2 the barriers, 8 the record refills (every source re-uses the first record), 16 the max
-    // update -- results are WRONG with any of them; 4 = the register-staged copy of round 1
-    // (results identical).  Measured at cfg3 (profiles/r02_bp_ablation.txt).
+    // update -- results are WRONG with any of them.  Measured at cfg3 (profiles/r02_bp_ablation.txt).
 #ifndef BPF_DBG
 #define BPF_DBG 0
 #endif
@@ -103,73 +102,48 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
     const long long rec_stride = (long long)rec_dw * 4 * WPB;   // bytes between a wave's sources
 
+    // Window descriptors of a group travel through a 4 KB slab of LDS: waves 0-3 copy the NEXT
+    // group's descriptors there (LDS-DMA, 16 bytes per lane) right after the staging barrier of the
+    // current group, so that at the next group boundary they are read from LDS instead of paying a
+    // memory round trip in front of the window copies.
+    auto prefetch_descriptors = [&](int first_win) {
+        if (wv < desc_waves) {
+            const BpWindow* src = wins + first_win + 64 * wv + lane;     // the table is padded by BPF_DESC_MAX
+            float* dst = lds + BPF_DESC_OFS + 256 * wv;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    if (n_groups > 0) prefetch_descriptors(groups[0].first_win);
+
     for (int g = 0; g < n_groups; ++g) {
         const BpFastGroup grp = groups[g];
-        if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done
-        // ---- staging: one chunk per wave, 16 bytes per lane, 8 chunks in flight per wave
-        if (!(dbg & 1) && !(dbg & 4)) {
-            // LDS-DMA: a chunk (<= 256 consecutive floats of one prestacked row) goes global -> LDS
-            // in ONE instruction per wave (16 bytes per lane, destination = wave-uniform base +
-            // 16 * lane), without staging registers and without ds_write_b128 (13 cycles each): a
-            // wave fetches the descriptors of all its chunks of the group (one round trip), then
-            // issues all its copies back to back (one more).  The register-staged version below
-            // paid two dependent round trips per 8 chunks per wave: 5.5 % of the kernel at cfg3.
-            // The copies count in vmcnt; __syncthreads() waits for them (vmcnt(0)) before the barrier.
-            constexpr int STG_R = 16;
-            const int nck = grp.n_chunk;
-            const i32x4* chunks4 = (const i32x4*)chunks;
-            for (int c0 = wv; c0 < nck; c0 += WPB * STG_R) {
-                i32x4 dsc[STG_R];    // {row, first sample relative to t0, LDS float offset, floats}
-#pragma unroll
-                for (int r = 0; r < STG_R; ++r) {
-                    const int c = c0 + r * WPB;
-                    dsc[r] = chunks4[grp.first_chunk + min(c, nck - 1) + vzero];
-                    if (c >= nck) dsc[r][3] = 0;
+        if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done, this group's descriptors are in LDS
+        // ---- staging by LDS-DMA: a window (tile + moveout spread floats of one prestacked row) goes
+        // global -> LDS in pieces of 256 floats, ONE instruction per piece and wave (16 bytes per
+        // lane, destination = wave-uniform base + 16 * lane; an unaligned global source is fine),
+        // without staging registers and without ds_write_b128 (13 cycles each).  Wave w takes the
+        // windows w, w + 16, ...; all its copies are in flight together.  The register-staged
+        // version of round 1 paid two dependent round trips per 8 chunks per wave: 5.5 % of the
+        // kernel at cfg3, this one 2 %.  The copies count in vmcnt; __syncthreads() waits for them
+        // (vmcnt(0)) before the barrier.
+        if (!(dbg & 1)) {
+            const i32x4* dsc = (const i32x4*)(lds + BPF_DESC_OFS);
+            for (int wi = wv; wi < grp.n_win; wi += WPB) {
+                const i32x4 d = dsc[wi];                       // {row, first sample relative to t0, LDS float offset, floats}
+                const int row = __builtin_amdgcn_readfirstlane(d[0]), gofs = __builtin_amdgcn_readfirstlane(d[1]);
+                const int dst0 = __builtin_amdgcn_readfirstlane(d[2]), len = __builtin_amdgcn_readfirstlane(d[3]);
+                // interior tile: every sample of every window lies inside [0, N)
+                const float* src = U + (size_t)row * (size_t)N + (t0 + gofs) + 4 * lane;
+                for (int x0 = 0; x0 < len; x0 += 256) {
+                    if (x0 + 4 * lane < len)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + x0),
+                                                         (__attribute__((address_space(3))) void*)(lds + dst0 + x0), 16, 0, 0);
                 }
-                // every descriptor has landed before the first copy is issued: beside a copy in
-                // flight hipcc waits vmcnt(0) at each use of an ordinary load's result, which would
-                // serialise the copies
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(dsc[0]), "+v"(dsc[1]), "+v"(dsc[2]), "+v"(dsc[3]), "+v"(dsc[4]), "+v"(dsc[5]),
-                               "+v"(dsc[6]), "+v"(dsc[7]), "+v"(dsc[8]), "+v"(dsc[9]), "+v"(dsc[10]), "+v"(dsc[11]),
-                               "+v"(dsc[12]), "+v"(dsc[13]), "+v"(dsc[14]), "+v"(dsc[15]));
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int r = 0; r < STG_R; ++r) {
-                    const float* src = U + (size_t)dsc[r][0] * (size_t)N + (t0 + dsc[r][1]) + 4 * lane;
-                    float* dst = lds + __builtin_amdgcn_readfirstlane(dsc[r][2]);
-                    if (4 * lane < dsc[r][3])
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
-            }
-        } else if (!(dbg & 1)) {
-            constexpr int STG_R = 8;
-            typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
-            typedef float f32x4v __attribute__((ext_vector_type(4)));
-            const int nck = grp.n_chunk;
-            for (int c0 = wv; c0 < nck; c0 += WPB * STG_R) {
-                int4 dsc[STG_R];
-                f32x4v v[STG_R];
-#pragma unroll
-                for (int r = 0; r < STG_R; ++r) {
-                    const int c = c0 + r * WPB;
-                    dsc[r] = chunks[grp.first_chunk + min(c, nck - 1) + vzero];
-                    if (c >= nck) dsc[r].w = 0;
-                }
-#pragma unroll
-                for (int r = 0; r < STG_R; ++r) {
-                    // interior tile: every chunk of every window lies inside [0, N)
-                    const float* src = U + (size_t)dsc[r].x * (size_t)N + (t0 + dsc[r].y);
-                    v[r] = (f32x4v){0.0f, 0.0f, 0.0f, 0.0f};
-                    if (4 * lane < dsc[r].w) v[r] = *(const f32x4u4*)(src + 4 * lane);
-                }
-#pragma unroll
-                for (int r = 0; r < STG_R; ++r)
-                    if (4 * lane < dsc[r].w) *(f32x4v*)(lds + dsc[r].z + 4 * lane) = v[r];
             }
         }
         if (!(dbg & 2)) __syncthreads();
+        if (g + 1 < n_groups) prefetch_descriptors(groups[g + 1].first_win);
 
         for (int rr = 0; rr < grp.n_run; ++rr) {
             const BpRun run = runs[grp.first_run + rr];
@@ -342,6 +316,8 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
     const long long n_tiles = tile_hi - tile_lo;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * BPF_WPB * BPF_TILE * sizeof(float));
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
+    // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
+    const int desc_waves = (int)std::min<size_t>(BPF_DESC_MAX, (2 * pl->S * pl->P + 63) / 64 * 64) / 64;
 #define BPF_LAUNCH(UNI)                                                                            \
     do {                                                                                           \
         auto kern = bp_beam_fast_kernel<UNI>;                                                      \
@@ -349,8 +325,8 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
                                            hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
-            U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, (const int4*)pl->d_chunks,  \
-            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg);             \
+            U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, pl->d_fwins,                \
+            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, desc_waves); \
     } while (0)
     if (pl->fast_uniform) BPF_LAUNCH(true); else BPF_LAUNCH(false);
 #undef BPF_LAUNCH

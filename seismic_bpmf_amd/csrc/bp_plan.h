@@ -29,7 +29,14 @@ struct BpSource {
 //   per-station     : [id, 0, offs_0, w_0, offs_1, w_1, ...]   offs = float offsets P | S << 16
 // Padding stations address the zero slab (offset 0) with the source's weight (or weight 0).
 struct BpRun { int first_rec, n_src, nst, pad; };          // nst: stations of the run (even, 2..16)
-struct BpFastGroup { int first_run, n_run, first_chunk, n_chunk; };
+struct BpFastGroup { int first_run, n_run, first_win, n_win; };
+// one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
+// offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
+struct BpWindow { int row, gofs, dst, len; };
+// LDS floats [BPF_DESC_OFS, BPF_DESC_OFS + 4 * BPF_DESC_MAX) hold the NEXT group's window
+// descriptors (copied there while the current group is computed); plans with dual windows leave
+// this slab free behind the zero slab
+constexpr int BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
 
 }  // namespace bpmf
 
@@ -67,6 +74,7 @@ struct bpmf_bp_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bpmf::BpFastGroup* d_fgroups = nullptr;
     bpmf::BpRun* d_fruns = nullptr;
+    bpmf::BpWindow* d_fwins = nullptr;
     int* d_frecs = nullptr;
 };
 
