@@ -536,6 +536,12 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     int t;
     long long lag_block;
     if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
+    // experiment (BPMF_MF_ABLATE bits 8..): stagger the waves of a SIMD by (hardware wave slot & 3)
+    // x (ablate >> 8) x 64 cycles, so that their per-channel store / epilogue phases do not coincide
+    if (ablate >> 8) {
+        const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.wave_id
+        for (int i = 0; i < slot * (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rgi = range[t];
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
