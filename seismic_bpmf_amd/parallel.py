@@ -33,6 +33,26 @@ def shard_bounds(n, world):
     return out
 
 
+def shard_bounds_weighted(costs, world):
+    """Contiguous partition of range(len(costs)) into `world` blocks with balanced total cost: block
+    r ends where the running cost first reaches (r + 1) / world of the total.  For the matched
+    filter the cost of a template is its number of channels with non-zero weight (zero-weight
+    channels are skipped by the kernel), SURVEY.md section 8e."""
+    import numpy as np
+    c = np.asarray(costs, dtype=np.float64)
+    n = c.size
+    cum = np.concatenate(([0.0], np.cumsum(c)))
+    total = cum[-1]
+    if total <= 0:
+        return shard_bounds(n, world)
+    cuts = [0]
+    for r in range(1, world):
+        k = int(np.searchsorted(cum, total * r / world, side="left"))
+        cuts.append(min(max(k, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def pack_max_keys(beam, arg):
     """(float32 beam, int32 source id) -> int64 keys, ordered by (beam asc, id desc)."""
     bits = beam.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
@@ -119,12 +139,19 @@ class ShardedMatchedFilter:
     def set_data(self, data):
         self.local.set_data(data)
 
-    def template_range(self, n_templates):
+    def template_range(self, n_templates, weights=None):
+        """This rank's block of templates: equal counts, or -- given the (T, S, C) weights -- equal
+        numbers of weighted channels (the kernel skips zero-weight channels)."""
+        if weights is not None:
+            import numpy as np
+            w = weights.detach().cpu().numpy() if hasattr(weights, "detach") else np.asarray(weights)
+            costs = (w.reshape(w.shape[0], -1) != 0).sum(axis=1)
+            return shard_bounds_weighted(costs, self.world)[self.rank]
         return shard_bounds(n_templates, self.world)[self.rank]
 
-    def run(self, templates, moveouts, weights, step=1, network_sum=True):
+    def run(self, templates, moveouts, weights, step=1, network_sum=True, balance=True):
         """CC of this rank's block of templates; returns (t0, t1, cc_local)."""
-        t0, t1 = self.template_range(templates.shape[0])
+        t0, t1 = self.template_range(templates.shape[0], weights if balance else None)
         if t1 == t0:
             return t0, t1, None
         cc = self.local.run(templates[t0:t1], moveouts[t0:t1], weights[t0:t1], step, network_sum)

@@ -107,3 +107,20 @@ def test_two_rank_merge_equals_single_pass(oracle_lib):
         assert np.array_equal(arg, oa), f"rank {rank}: {(arg != oa).sum()} arg-max differ"
         assert [len(p) for p in parts] == [2, 3]
         assert parts[1][0, 0] == 100.0 and parts[0][1, 2] == 5.0
+
+
+def test_weighted_template_sharding_balances_active_channels():
+    """shard_bounds_weighted: contiguous blocks, every template in exactly one block, loads within
+    one template's cost of the ideal share; falls back to equal counts when every cost is zero."""
+    sys.path.insert(0, ROOT)
+    from seismic_bpmf_amd import parallel
+    rng = np.random.default_rng(3)
+    for n, world in [(5000, 8), (17, 4), (3, 8), (100, 1)]:
+        costs = rng.integers(0, 121, n)
+        costs[rng.random(n) < 0.2] = 0
+        b = parallel.shard_bounds_weighted(costs, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+        assert all(b[r][1] == b[r + 1][0] for r in range(world - 1))
+        loads = [costs[lo:hi].sum() for lo, hi in b]
+        assert max(loads) <= costs.sum() / world + costs.max() + 1e-9
+    assert parallel.shard_bounds_weighted(np.zeros(10), 3) == parallel.shard_bounds(10, 3)
