@@ -188,3 +188,57 @@ def test_bad_arguments_raise_with_a_message():
     with pytest.raises(_lib.BpmfHipError, match="station-phase"):
         sb.beamform(np.zeros((150, 1, 100), np.float32), np.zeros((2, 150, 2), np.int32),
                     np.ones((150, 1, 2), np.float32), np.ones((2, 150), np.float32))
+
+
+# ------------------------------------------------------------ interior-tile fast path ---
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_used,uniform", [(1, True), (3, True), (4, False), (7, True), (10, False),
+                                            (13, True), (16, True), (16, False)])
+@pytest.mark.parametrize("oob", ["strict", "flexible"])
+def test_bp_fast_path_station_counts_and_weight_kinds(oracle_lib, n_used, uniform, oob, monkeypatch):
+    """bp_beam_fast_kernel (csrc/bp_fast.hip): every station-count class 4..16 (1-3 stations are
+    padded to 4 with zero-slab terms), uniform weights (ready-made address records) and per-station
+    weights (packed records), mixed counts inside a group (several runs), a source without any
+    station, negative moveouts (edge tiles at the START of the trace as well), exact ties; against
+    the oracle and against the general kernel (BPMF_BP_FAST=0), bit for bit."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(100 * n_used + int(uniform))
+    K, S, C, P, N = 700, 18, 3, 2, 9000
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4   # ties
+    tau = rng.integers(-150, 600, (K, S, P)).astype(np.int32)
+    tau[100:140] = tau[300:340]                                   # identical sources -> lowest id must win
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        n = n_used if k % 5 else max(1, n_used - (k // 5) % 3)     # mixed counts -> several runs per group
+        sel = rng.choice(S, n, replace=False)
+        ws[k, sel] = 0.25 if uniform else rng.uniform(0.1, 1.0, n).astype(np.float32)
+    ws[100:140] = ws[300:340]
+    ws[77] = 0.0
+    ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+    got = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("BPMF_BP_FAST", fast)
+        bf = BeamformerGPU(tau, ws)
+        b, a = bf.run(f, wp, "max", oob)
+        got[fast] = (b.cpu().numpy(), a.cpu().numpy())
+        bf.close()
+    for fast in ("1", "0"):
+        assert np.array_equal(got[fast][0], ob) and np.array_equal(got[fast][1], oa), (fast, n_used, uniform, oob)
+
+
+@pytest.mark.gpu
+def test_bp_fast_path_short_traces_have_no_interior_tiles(oracle_lib):
+    """N smaller than tile + largest moveout: every tile is an edge tile, the interior kernel gets
+    an empty range; N of a few tiles: both kernels write disjoint parts of the same arrays."""
+    from seismic_bpmf_amd import beamform
+    rng = np.random.default_rng(5)
+    for N in (300, 700, 1100, 2049, 4096):
+        K, S = 120, 9
+        f = np.abs(rng.standard_normal((S, 3, N))).astype(np.float32)
+        tau = rng.integers(0, 260, (K, S, 2)).astype(np.int32)
+        wp = rng.random((S, 3, 2)).astype(np.float32)
+        ws = (rng.random((K, S)) < 0.5).astype(np.float32)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+        mb, ma = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds="strict")
+        assert np.array_equal(mb, ob) and np.array_equal(ma, oa), N
