@@ -192,3 +192,36 @@ def test_intertemplate_cc_batched_equals_the_per_template_loop(oracle_lib):
     w = rng.random((T, T, S, C)).astype(np.float32)
     assert workflow.factorise_pair_weights(w) is None
     assert np.array_equal(workflow.intertemplate_cc(wf, w, max_lag=7), workflow.intertemplate_cc_loop(wf, w, max_lag=7))
+
+
+def test_bp_detections_on_device_edge_cases():
+    """No peak above the threshold, a threshold given as an array, a record buffer that overflows
+    and grows, NaNs in the series, a window longer than the series."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import BeamDetectorGPU
+    from seismic_bpmf_amd.workflow import beam_detections_device
+    rng = np.random.default_rng(2)
+    n = 30_000
+    x = np.abs(rng.standard_normal(n)).astype(np.float32)
+    src = rng.integers(0, 100, n).astype(np.int32)
+    xd, sd = torch.as_tensor(x, device="cuda"), torch.as_tensor(src, device="cuda")
+    peaks, psrc, _ = beam_detections_device(xd, sd, mpd=50, threshold=100.0)
+    assert peaks.size == 0 and psrc.size == 0 and peaks.dtype.kind == "i"
+    thr = (2.5 + np.sin(np.arange(n) / 3000.0)).astype(np.float32)
+    want_p, want_s = pp.find_beam_detections(x, src, thr, 50)
+    peaks, psrc, _ = beam_detections_device(xd, sd, mpd=50, threshold=thr)
+    assert np.array_equal(peaks, want_p) and np.array_equal(psrc, want_s) and want_p.size > 10
+    det = BeamDetectorGPU()
+    few = det.extract_peaks(xd, sd, 1.0, capacity=4)            # overflows, grows, repeats
+    many = det.extract_peaks(xd, sd, 1.0)
+    assert few.size > 4 and np.array_equal(few, many) and np.all(np.diff(many["index"]) > 0)
+    loc = np.flatnonzero((x[1:-1] > x[:-2]) & (x[2:] <= x[1:-1]) & (x[1:-1] > 1.0)) + 1
+    assert np.array_equal(many["index"], loc) and np.array_equal(many["source"], src[loc])
+    xn = x.copy()
+    xn[[500, 501, 9000]] = np.nan                                # peaks next to a NaN are dropped
+    want_p, _ = pp.find_beam_detections(xn, src, 2.0, 25)
+    peaks, _, _ = beam_detections_device(torch.as_tensor(xn, device="cuda"), sd, mpd=25, threshold=2.0)
+    assert np.array_equal(peaks, want_p)
+    with pytest.raises(ValueError):
+        det.window_stats(xd, n + 1, 0.75)
