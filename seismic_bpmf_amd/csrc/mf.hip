@@ -519,7 +519,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate, int n_lag_blocks)
+    float* __restrict__ out, int ablate, int n_lag_blocks, int nsub)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -535,15 +535,24 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 
     int t;
     long long lag_block;
-    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
+    // A workgroup walks `nsub` consecutive lag blocks of its template (BPMF_MF_NSUB, default 1): an
+    // experiment on the L2-miss traffic -- the template's rows (65 KB at cfg2) would come from L2 for
+    // the blocks after the first.  Measured at cfg2 (profiles/r02_mf_nsub.txt): FETCH_SIZE 88.4 / 82.0 /
+    // 81.3 / 92.2 M KiB and 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for nsub = 1 / 2 / 4 / 8: the
+    // template rows are not what the L2 misses are made of.
+    long long super_block;
+    if (!mf_tile_of_block(blockIdx.x, T, (n_lag_blocks + nsub - 1) / nsub, ablate & 16 ? 0 : 1, t, super_block)) return;
     // experiment (BPMF_MF_ABLATE bits 8..): stagger the waves of a SIMD by (hardware wave slot & 3)
     // x (ablate >> 8) x 64 cycles, so that their per-channel store / epilogue phases do not coincide
     if (ablate >> 8) {
         const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.wave_id
         for (int i = 0; i < slot * (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(1);
     }
-    const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rgi = range[t];
+    for (int sub = 0; sub < nsub; ++sub) {
+    lag_block = super_block * nsub + sub;
+    if (lag_block >= n_lag_blocks) break;
+    const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
 
@@ -746,6 +755,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
         }
     }
+    }   // sub
 }
 
 // ------------------------------------------------------ generic (any step) kernel ---
@@ -959,11 +969,17 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         const bool wave_kernel = (wke ? atoi(wke) != 0 : true) && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
+            const char* nse = getenv("BPMF_MF_NSUB");          // lag blocks per workgroup
+            int nsub = nse ? atoi(nse) : 1;                     // measured: 2-4 blocks save 7-8 % of the L2-miss
+                                                                // traffic and cost 0.2-0.6 % of the time
+            if (nsub < 1) nsub = 1;
+            const size_t n_super = (n_lag_blocks + nsub - 1) / nsub;
+            dim3 grid_w((unsigned)(T * 8 * ((n_super + 7) / 8)));
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                           \
-    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid, dim3(MF_THREADS), wl, stream>>>(                  \
+    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid_w, dim3(MF_THREADS), wl, stream>>>(                \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks)
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks, nsub)
             if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
             else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);
