@@ -223,3 +223,45 @@ def test_input_conditioning_matches_reference():
     assert np.array_equal(pp.normalize_data(g["sd_data"]), g["sd_data_arr"])
     for method in ("rms", "max"):
         assert np.array_equal(pp.normalize_templates(g["mf_waveforms"], method), g[f"tg_norm_{method}"])
+
+
+def test_candidate_based_beam_detections_equal_the_full_series_logic():
+    """Host half of the device detection stage (workflow.beam_detections_device): given only the
+    rising-edge local maxima above a floor that no threshold value undercuts -- what
+    csrc/bp_detect.hip compacts -- and window medians / MADs, the detections equal the ones of
+    find_beam_detections on the whole series: the reference's goldens and time-dependent thresholds,
+    plateaus, exact ties."""
+    def local_maxima_above(x, floor):
+        idx = np.flatnonzero((x[1:-1] > x[:-2]) & (x[2:] <= x[1:-1]) & (x[1:-1].astype(np.float64) > floor)) + 1
+        return idx, x[idx]
+
+    g = load("bp_find_detections.npz")
+    for j in range(int(g["n_cases"])):
+        mb, src, thr, mpd = g[f"maxbeam_{j}"], g[f"sources_{j}"], g[f"thr_{j}"], int(g[f"mpd_{j}"])
+        idx, h = local_maxima_above(mb, float(thr[0]))
+        peaks = pp.find_beam_detections_from_candidates(idx, h, lambda s: np.full(len(s), float(thr[0])), mpd,
+                                                        mb.size, lambda i0, i1: mb[i0:i1])
+        assert np.array_equal(peaks, g[f"peaks_{j}"]) and np.array_equal(src[peaks], g[f"peak_sources_{j}"])
+    rng = np.random.default_rng(12)
+    for n, window, mpd, gain in [(120_000, 9_000, 40, 4.0), (60_000, 6_000, 1, 1.0), (80_000, 8_000, 501, 2.5)]:
+        x = np.abs(rng.standard_normal(n)).astype(np.float32)
+        x[n // 2:] *= np.float32(gain)
+        for p in rng.integers(1000, n - 1000, 40):
+            x[p - 3:p + 4] += np.float32(rng.uniform(3, 30)) * np.array([.2, .6, .9, 1, .9, .6, .2], np.float32)
+        x = np.round(x, 2)
+        overlap, n_dev = 0.75, 8.0
+        shift = int((1.0 - overlap) * window)
+        nw = int((n - window) // shift) + 1
+        med, mad = np.zeros(nw + 2, np.float32), np.zeros(nw + 2, np.float32)
+        for q in range(1, nw + 1):
+            seg = x[q * shift:min(n, q * shift + window)]
+            med[q] = np.median(seg)
+            mad[q] = np.median(np.abs(seg - med[q]))
+        centre, nodes = pp.bp_threshold_nodes(n, window, overlap, med, mad, n_dev)
+        full_thr = pp.bp_time_dependent_threshold(x, window, n_dev, overlap)
+        assert np.array_equal(pp.interp_threshold(np.arange(n), centre, nodes), full_thr)
+        want, _ = pp.find_beam_detections(x, np.zeros(n, np.int32), full_thr, mpd)
+        idx, h = local_maxima_above(x, float(nodes.astype(np.float64).min()))
+        got = pp.find_beam_detections_from_candidates(idx, h, lambda s: pp.interp_threshold(s, centre, nodes), mpd, n,
+                                                      lambda i0, i1: x[i0:i1])
+        assert np.array_equal(got, want) and want.size >= 5 and idx.size < n // 4
