@@ -684,6 +684,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
     __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
+            // experiment (BPMF_MF_ABLATE bit 32): raise this wave's issue priority for the K loop, so
+            // that MFMA-issuing waves win the arbitration against waves in their store / epilogue phase
+            if (ablate & 32) __builtin_amdgcn_s_setprio(2);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 bp += 72;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ablate & 32) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
 #undef MF_LDS_READ
 #undef MF_MFMA
