@@ -1368,9 +1368,15 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             return rc;
         }
         if (any) {
-            BPMF_HIP_CHECK(hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking));
-            BPMF_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
-            BPMF_HIP_CHECK(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+            hipError_t e1 = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
+            hipError_t e2 = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+            hipError_t e3 = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+                set_error("bpmf_bp_plan_create: side stream / events: %s",
+                          hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+                bpmf_bp_plan_destroy(pl);
+                return -2;
+            }
         }
         pl->fast = any;
         pl->fast_uniform = uniform;
