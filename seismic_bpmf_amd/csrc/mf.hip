@@ -38,6 +38,19 @@ __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t
     e_t[i] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
 }
 
+// Toeplitz band image of every (template, channel) row as the wave kernel keeps it in LDS:
+// band[15 + l] = tmpl[l], zeros around, band_len floats -- the source of the LDS-DMA staging
+// (a DMA copy has no per-dword bounds check to produce the zeros).
+__global__ void mf_band_image_kernel(const float* __restrict__ tmpl, size_t n_rows, int L, int band_len,
+                                     float* __restrict__ band)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * (size_t)band_len) return;
+    const size_t row = i / (size_t)band_len;
+    const int l = (int)(i % (size_t)band_len) - 15;
+    band[i] = (l >= 0 && l < L) ? tmpl[row * (size_t)L + l] : 0.0f;
+}
+
 // Valid lag range [first, last] of each template (first > last = empty).
 // Also writes the template's compact list of used channels, one int4 {channel, moveout,
 // weight bits, r_t bits} per channel with w != 0, in channel order, closed by two {-1,..}
@@ -514,12 +527,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // execute in order): single-buffered, 6.6 KB per wave instead of 9.9 KB.  The price is the
 // 256-float overlap between neighbouring waves' windows (25 % more staging traffic from L2).
 // Used for L <= 257 (window 1280 floats = 20 staging registers per lane).
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
-__global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
+// DMA: the LDS-DMA staging variant (see below); it computes only the waves whose windows lie
+// inside the trace for every channel, the register-staged variant (DMA = false) launched with
+// `band_img` set computes exactly the others.
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, bool DMA = false>
+__global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate, int n_lag_blocks, int nsub)
+    float* __restrict__ out, int ablate, int n_lag_blocks, const float* __restrict__ band_img)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -535,13 +551,12 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 
     int t;
     long long lag_block;
-    // A workgroup walks `nsub` consecutive lag blocks of its template (BPMF_MF_NSUB, default 1): an
-    // experiment on the L2-miss traffic -- the template's rows (65 KB at cfg2) would come from L2 for
-    // the blocks after the first.  Measured at cfg2 (profiles/r02_mf_nsub.txt): FETCH_SIZE 88.4 / 82.0 /
-    // 81.3 / 92.2 M KiB and 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for nsub = 1 / 2 / 4 / 8: the
-    // template rows are not what the L2 misses are made of.
-    long long super_block;
-    if (!mf_tile_of_block(blockIdx.x, T, (n_lag_blocks + nsub - 1) / nsub, ablate & 16 ? 0 : 1, t, super_block)) return;
+    // (Letting a workgroup walk several consecutive lag blocks of its template, so that the template
+    // rows come from L2 after the first block, was measured in round 2 -- BPMF_MF_NSUB in commit
+    // "MF: lag blocks per workgroup experiment": FETCH_SIZE 88.4 / 82.0 / 81.3 / 92.2 M KiB and
+    // 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for 1 / 2 / 4 / 8 blocks, profiles/r02_mf_nsub.txt;
+    // the loop also cost 7 spilled registers.  One block per workgroup.)
+    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
     // experiment (BPMF_MF_ABLATE bits 8..): stagger the waves of a SIMD by (hardware wave slot & 3)
     // x (ablate >> 8) x 64 cycles, so that their per-channel store / epilogue phases do not coincide
     if (ablate >> 8) {
@@ -549,9 +564,6 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         for (int i = 0; i < slot * (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(1);
     }
     const int2 rgi = range[t];
-    for (int sub = 0; sub < nsub; ++sub) {
-    lag_block = super_block * nsub + sub;
-    if (lag_block >= n_lag_blocks) break;
     const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
@@ -571,8 +583,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         const int b_base = 18 * a + kq;  // window padded 2 floats per 16: conflict-free B reads
         const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
 
-        float rd[MAXR], rt[MAXT];
+        float rd[DMA ? 1 : MAXR], rt[DMA ? 1 : MAXT];
         auto issue_stage = [&](int ch, int mvc) {
+            if constexpr (DMA) return;
             const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
             const int o_d = (int)((lag0 + mvc + lane) * 4);
@@ -589,6 +602,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         };
         const bool full_window = Ww == 64 * MAXR;  // L = 241..257: every staging register is used
         auto write_stage = [&]() {
+            if constexpr (DMA) return;
             if (full_window) {
 #pragma unroll
                 for (int r = 0; r < MAXR; ++r) {
@@ -609,13 +623,48 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
         };
 
+        // ---- LDS-DMA staging (band_img != nullptr, waves whose windows lie inside the trace for
+        // every channel): the next channel's window and band go global -> LDS with 6 + 2
+        // global_load_lds_dwordx4 (16 bytes per lane, lane-linear destination) issued after the
+        // epilogue, instead of 25 loads into registers during the K loop and 25 + 5 ds_write_b32
+        // after it.  The window keeps its padded layout (2 floats per 16): LDS slot j (floats
+        // 4j .. 4j+3) of group g = 4j / 18, position r = 4j % 18 is ONE contiguous 16-byte read at
+        // data[g0 + 16 g + min(r, 14)] -- the pad positions of a slot receive neighbouring samples
+        // that no operand read ever addresses.  The wave waits for its copies (vmcnt(0)) at the top
+        // of the next channel; the other waves of the SIMD keep the matrix pipe busy meanwhile.
+        const int n_slots = (Ww + 2 * (Ww >> 4) + 3) >> 2;
+        const bool wave_dma = band_img != nullptr && wave_inside && n_slots <= 6 * 64 &&
+                              lag0 + MF_LAGS_PER_WAVE - 1 + 24 <= rg.y;
+        if (wave_dma != DMA) return;       // the other variant's launch computes this wave
+        auto dma_stage = [&](int ch, int mvc) {
+            if constexpr (!DMA) return;
+            const float* src = data + (size_t)ch * (size_t)N + (lag0 + mvc);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                // source sample of this lane's slot in piece q (floats, relative to the window start)
+                const int p4 = 4 * (64 * q + lane);
+                const int g = p4 / 18, r = p4 - 18 * g;
+                const int xo = 16 * g + (r < 14 ? r : 14);
+                if (64 * q + lane < n_slots)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xo),
+                                                     (__attribute__((address_space(3))) void*)(dw + 256 * q), 16, 0, 0);
+            }
+            const float* bsrc = band_img + ((size_t)t * n_ch + ch) * (size_t)tp_len + 4 * lane;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (4 * (64 * q + lane) < tp_len)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 256 * q),
+                                                     (__attribute__((address_space(3))) void*)(tp + 256 * q), 16, 0, 0);
+        };
+
         int4 rec = recs[0];
         int4 rec1 = recs[1];
         int ri = 0;
-        if (rec.x >= 0) issue_stage(rec.x, rec.y);
+        if (rec.x >= 0) { if (wave_dma) dma_stage(rec.x, rec.y); else issue_stage(rec.x, rec.y); }
         while (rec.x >= 0) {
             const int ch = rec.x;
-            write_stage();  // in place: this wave finished reading the previous channel
+            if (wave_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this channel's copies have landed
+            else write_stage();  // in place: this wave finished reading the previous channel
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
@@ -637,7 +686,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                     ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
-            if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
+            if (!wave_dma && rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
 
             f32x4 acc[4];
 #pragma unroll
@@ -737,6 +786,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 }
             }
             }
+            // LDS-DMA staging: the K loop is done with the buffers (lgkmcnt(0) above), the next
+            // channel's window and band can land in place
+            if (wave_dma && rec1.x >= 0) dma_stage(rec1.x, rec1.y);
             rec = rec1;
             rec1 = rec2;
             ++ri;
@@ -759,7 +811,6 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
         }
     }
-    }   // sub
 }
 
 // ------------------------------------------------------ generic (any step) kernel ---
@@ -809,6 +860,7 @@ struct MfWorkspace {
     float* e_t;     // [T, n_ch]
     int2* range;    // [T]
     int4* chan_rec; // [T, n_ch + 2] compact used-channel records
+    float* band;    // [T, n_ch, band_len] Toeplitz band images (LDS-DMA staging of the wave kernel)
     size_t bytes;
 };
 
@@ -827,6 +879,7 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
     ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
+    ws.band = (float*)(p + o);   o += align_up(T * n_ch * (size_t)mf_band_len((int)L) * sizeof(float) + 64, 256);
     ws.bytes = o;
     return ws;
 }
@@ -924,6 +977,12 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         mf_template_energy_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
             d_templates, n, (int)L, ws.e_t);
         BPMF_LAUNCH_CHECK();
+        if (getenv("BPMF_MF_DMA") && atoi(getenv("BPMF_MF_DMA")) && mf_kpad((int)L) <= 272) {   // LDS-DMA staging (experiment)
+            const size_t nb = n * (size_t)mf_band_len((int)L);
+            mf_band_image_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream>>>(
+                d_templates, n, (int)L, mf_band_len((int)L), ws.band);
+            BPMF_LAUNCH_CHECK();
+        }
         mf_range_kernel<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, stream>>>(
             d_moveouts, d_weights, ws.e_t, (int)T, (int)n_ch, (long long)step, (long long)L,
             (long long)N, (long long)n_corr, ws.range, ws.chan_rec);
@@ -973,17 +1032,23 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         const bool wave_kernel = (wke ? atoi(wke) != 0 : true) && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
-            const char* nse = getenv("BPMF_MF_NSUB");          // lag blocks per workgroup
-            int nsub = nse ? atoi(nse) : 1;                     // measured: 2-4 blocks save 7-8 % of the L2-miss
-                                                                // traffic and cost 0.2-0.6 % of the time
-            if (nsub < 1) nsub = 1;
-            const size_t n_super = (n_lag_blocks + nsub - 1) / nsub;
-            dim3 grid_w((unsigned)(T * 8 * ((n_super + 7) / 8)));
+            dim3 grid_w = grid;
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
+            const char* dme = getenv("BPMF_MF_DMA");
+            const bool use_dma = dme && atoi(dme) != 0;
+            const float* band_arg = use_dma ? ws.band : nullptr;
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                           \
-    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid_w, dim3(MF_THREADS), wl, stream>>>(                \
-        d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks, nsub)
+    do {                                                                                         \
+        mf_mfma_wave_kernel<NS, 20, 5, S1, false><<<grid_w, dim3(MF_THREADS), wl, stream>>>(     \
+            d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,    \
+            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks,        \
+            band_arg);                                                                           \
+        if (use_dma)                                                                             \
+            mf_mfma_wave_kernel<NS, 20, 5, S1, true><<<grid_w, dim3(MF_THREADS), wl, stream>>>(  \
+                d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T, \
+                (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks,    \
+                band_arg);                                                                 \
+    } while (0)
             if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
             else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);

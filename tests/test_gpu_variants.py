@@ -50,6 +50,27 @@ def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, monkeypatch):
               oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"wave_kernel={wave_kernel} ns={ns}")
 
 
+@pytest.mark.parametrize("L", [48, 130, 256, 257])
+@pytest.mark.parametrize("step", [1, 3])
+def test_mf_lds_dma_staging_variant(oracle_lib, L, step, monkeypatch):
+    """BPMF_MF_DMA=1: interior waves stage window and band by LDS-DMA (padded-slot source mapping,
+    band image from the workspace), the waves at the ends of a template's valid lag range run the
+    register-staged variant in a second launch; together bit-identical to the oracle, negative
+    moveouts, zero-weight channels and both output layouts included."""
+    from seismic_bpmf_amd import matched_filter
+    monkeypatch.setenv("BPMF_MF_DMA", "1")
+    rng = np.random.default_rng(1000 + L + step)
+    T, S, C, N = 3, 4, 3, 41_000
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-300, 2500, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[1, 2] = 0.0
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for ns in (True, False):
+        _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
+              oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"DMA staging L={L} step={step} ns={ns}")
+
+
 @pytest.mark.parametrize("step", [2, 3, 7, 16, 17, 50])
 @pytest.mark.parametrize("L", [64, 400])
 def test_mf_step_greater_than_one(oracle_lib, step, L):
