@@ -262,6 +262,48 @@ __device__ __forceinline__ bool mf_tile_of_block(unsigned bid, int T, int n_lag_
     return lag_block < n_lag_blocks;
 }
 
+// Zero-padded staging loads.  A raw buffer load returns 0 for a lane whose byte offset lies outside
+// [0, num_records) -- which is how the windows get their zeros before the start and past the end of a
+// trace -- but on gfx950 that check is per lane only while the instruction carries NO immediate
+// offset: with one, an aligned group of 4 lanes whose (voffset + immediate) values straddle the
+// 32-bit wrap (some lanes before sample 0, some at samples 0..2) comes back as zeros for all 4 lanes
+// (tools/ubench/buffer_neg.hip, profiles/r02_buffer_wrap.txt).  Rounds 1 and early 2 lost the first
+// 1-3 samples of a trace that way, at the first valid lags of a template whose most negative
+// moveout is not a multiple of 4.  So: immediates only when every voffset is non-negative (`first`,
+// the window's first sample, is uniform over the wave / workgroup), otherwise one register offset
+// per load.
+template <int NR, int STRIDE>
+__device__ __forceinline__ void mf_stage_rows(float (&rd)[NR], __amdgpu_buffer_rsrc_t rs,
+                                              long long first, int idx)
+{
+    const int o = (int)((first + idx) * 4);
+    if (first >= 0) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o + STRIDE * 4 * r, 0, 0));
+    } else {
+        int oo = o;                                // wraps like the hardware's u32 offset
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            asm volatile("" : "+v"(oo));           // keep the constant out of the immediate field
+            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oo, 0, 0));
+            oo += STRIDE * 4;
+        }
+    }
+}
+// band row r holds template samples idx + STRIDE r - 15: negative only in row 0
+template <int NR, int STRIDE>
+__device__ __forceinline__ void mf_stage_band(float (&rt)[NR], __amdgpu_buffer_rsrc_t rs, int idx)
+{
+    int o0 = (idx - 15) * 4;
+    asm volatile("" : "+v"(o0));
+    rt[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));
+#pragma unroll
+    for (int r = 1; r < NR; ++r)
+        rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                              rs, idx * 4 + (STRIDE * r - 15) * 4, 0, 0));
+}
+
 template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
@@ -323,21 +365,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
         // Staging loads go through buffer descriptors: an offset outside [0, bytes) -- a
         // window sample before the start / past the end of the trace, or a band row outside
         // the template -- returns 0 from the hardware bounds check, so the zero padding costs
-        // no address clamping or select.
+        // no address clamping or select (see mf_stage_rows for the one trap in that).
         auto issue_stage = [&](int ch, int mvc) {
             const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
-            const int o_d = (int)((lag0 + mvc + tid) * 4);  // wraps like the hardware's u32 offset
-#pragma unroll
-            for (int r = 0; r < MAXR; ++r)
-                rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_d, o_d + MF_THREADS * 4 * r, 0, 0));
+            mf_stage_rows<MAXR, MF_THREADS>(rd, rs_d, lag0 + mvc, tid);
             const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < MAXT; ++r)
-                rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_t, (tid + MF_THREADS * r - 15) * 4, 0, 0));
+            mf_stage_band<MAXT, MF_THREADS>(rt, rs_t, tid);
         };
         auto write_stage = [&](float* tp, float* dw) {
 #pragma unroll
@@ -545,7 +580,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: lag0 etc. live in SGPRs
     const int a = lane & 15;
     const int kq = lane >> 4;
 
@@ -588,17 +623,10 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
             if constexpr (DMA) return;
             const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
-            const int o_d = (int)((lag0 + mvc + lane) * 4);
-#pragma unroll
-            for (int r = 0; r < MAXR; ++r)
-                rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_d, o_d + 64 * 4 * r, 0, 0));
+            mf_stage_rows<DMA ? 1 : MAXR, 64>(rd, rs_d, lag0 + mvc, lane);
             const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < MAXT; ++r)
-                rt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_t, (lane + 64 * r - 15) * 4, 0, 0));
+            mf_stage_band<DMA ? 1 : MAXT, 64>(rt, rs_t, lane);
         };
         const bool full_window = Ww == 64 * MAXR;  // L = 241..257: every staging register is used
         auto write_stage = [&]() {
@@ -663,7 +691,10 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
         if (rec.x >= 0) { if (wave_dma) dma_stage(rec.x, rec.y); else issue_stage(rec.x, rec.y); }
         while (rec.x >= 0) {
             const int ch = rec.x;
-            if (wave_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this channel's copies have landed
+            if (wave_dma) {
+                // each wave stages its own buffers: its copies are in LDS once vmcnt retires them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             else write_stage();  // in place: this wave finished reading the previous channel
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;

@@ -71,6 +71,32 @@ def test_mf_lds_dma_staging_variant(oracle_lib, L, step, monkeypatch):
               oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"DMA staging L={L} step={step} ns={ns}")
 
 
+@pytest.mark.parametrize("L", [48, 64, 300, 1100])
+@pytest.mark.parametrize("first", [-1, -2, -3, -74, -253, -271, -1023, -1025])
+def test_mf_first_samples_of_the_trace_with_negative_moveouts(oracle_lib, L, first, monkeypatch):
+    """A template whose most negative moveout is not a multiple of 4 has its first valid lags read
+    samples 0..2 of the trace through staging loads whose neighbours lie before the trace: on gfx950 a
+    raw buffer load WITH an immediate offset zeroes the whole 4-lane group there
+    (tools/ubench/buffer_neg.hip), which rounds 1 and early 2 got wrong by up to 3 CCs per template.
+    Every MFMA kernel family (per-wave, per-workgroup), both output layouts."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(abs(first) * 7 + L)
+    T, S, C, N = 2, 3, 3, 12_000
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(0, 900, (T, S, C)).astype(np.int32)
+    mv[0, 1, 1] = first
+    mv[1, 2, 0] = first + 1 if first < -1 else first
+    w = (rng.random((T, S, C)) + 0.1).astype(np.float32)
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for wave in ("1", "0"):
+        monkeypatch.setenv("BPMF_MF_WAVE_KERNEL", wave)
+        for step in (1, 2):
+            for ns in (True, False):
+                _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
+                      oracle_lib.matched_filter(tp, mv, w, d, step, ns),
+                      f"first={first} L={L} wave={wave} step={step} ns={ns}")
+
+
 @pytest.mark.parametrize("step", [2, 3, 7, 16, 17, 50])
 @pytest.mark.parametrize("L", [64, 400])
 def test_mf_step_greater_than_one(oracle_lib, step, L):
