@@ -351,7 +351,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    const bool wg_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WG - 1 < rg.x);
+    // (an empty range is stored as first > last: without the first test a workgroup that straddles
+    // both ends of it would count as valid and its norm loads -- "lag + 3 >= first && lag <= last"
+    // holds for lags last-3..last -- would run at lag + moveout far outside the table)
+    const bool wg_valid = rg.x <= rg.y && !(lag0 > rg.y || lag0 + MF_LAGS_PER_WG - 1 < rg.x);
     const bool wg_inside = lag0 >= rg.x && lag0 + MF_LAGS_PER_WG - 1 <= rg.y;  // no range tests needed
     // result (tile u, register r) of this lane is lag  lag_w + 256 u + r
     const long long lag_w = lag0 + (long long)wv * MF_LAGS_PER_WAVE + 16 * a + 4 * kq;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    const bool wave_valid = !(lag0 > rg.y || lag0 + MF_LAGS_PER_WAVE - 1 < rg.x);
+    const bool wave_valid = rg.x <= rg.y && !(lag0 > rg.y || lag0 + MF_LAGS_PER_WAVE - 1 < rg.x);   // empty range: first > last
     const bool wave_inside = lag0 >= rg.x && lag0 + MF_LAGS_PER_WAVE - 1 <= rg.y;
     const long long lag_w = lag0 + 16 * a + 4 * kq;
 

@@ -68,3 +68,87 @@ def test_mf_random_shapes(oracle_lib, seed):
         want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=network_sum)
         _same(got, want, f"seed {seed} network_sum={network_sum} (T={T} S={S} C={C} L={L} N={N} step={step} mv<={mv_max})")
         assert np.isfinite(got).all()
+
+
+def _fuzz_seeds(default):
+    """BPMF_FUZZ_SEEDS=a:b widens the sweep for a long session on the GPU box
+    (tools/fuzz_long.sh); the default stays small enough for the driver's run."""
+    import os
+    spec = os.environ.get("BPMF_FUZZ_SEEDS")
+    if not spec:
+        return range(default)
+    a, b = spec.split(":")
+    return range(int(a), int(b))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(40))
+def test_mf_random_shapes_signed_moveouts(oracle_lib, seed):
+    """Moveouts of both signs (the reference's are relative to the origin time and can be negative
+    for a template cut before it), every kernel family (L up to 2100 -> per-wave, per-workgroup
+    17/2, 20/5, 24/9, generic), steps on both sides of the MFMA limit, first valid lags that are not
+    multiples of 4 (the buffer-load trap of DESIGN.md)."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(7000 + seed)
+    T = int(rng.integers(1, 7))
+    S = int(rng.integers(1, 5))
+    C = int(rng.integers(1, 4))
+    L = int(rng.choice([1, 3, 16, 31, 48, 64, 100, 128, 200, 256, 257, 258, 273, 274, 400, 1041, 1042, 1500, 2065, 2066, 2100]))
+    N = int(L + rng.choice([0, 1, 2, 3, 5, 255, 1000, 4095, 4096, 4097, 9000, 20000]))
+    step = int(rng.choice([1, 1, 1, 1, 2, 3, 4, 7, 16, 17, 64, 65]))
+    lo = -int(rng.choice([0, 1, 2, 3, 5, 7, 50, 255, 257, 1023, 1026, max(1, N // 2), N + 3]))
+    hi = int(rng.choice([0, 1, 2, 3, 100, 1025, max(1, N // 2), N + 3]))
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    data = rng.standard_normal((S, C, N)).astype(np.float32)
+    if seed % 5 == 0:
+        a = int(rng.integers(0, max(1, N - 1)))
+        data[:, :, a:a + L + int(rng.integers(0, 2 * L + 2))] = 0.0   # a gap: zero-energy windows
+    if seed % 9 == 0:
+        tp[0, 0] = 0.0
+    mv = rng.integers(lo, hi + 1, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[rng.random((T, S, C)) < 0.2] = 0.0
+    for network_sum in (True, False):
+        got = matched_filter(tp, mv, w, data, step, arch="gpu", network_sum=network_sum, check_zeros=False)
+        want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=network_sum)
+        _same(got, want, f"seed {seed} network_sum={network_sum} (T={T} S={S} C={C} L={L} N={N} step={step} mv in [{lo},{hi}])")
+        assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(40))
+def test_bp_random_shapes_signed_moveouts(oracle_lib, seed):
+    """Moveouts of both signs, series spanning several 512-sample tiles (interior tiles run
+    bp_beam_fast_kernel, the ends round 1's kernel on the side stream), 1..20 weighted stations,
+    uniform and per-station weights."""
+    from seismic_bpmf_amd import beamform
+    rng = np.random.default_rng(8000 + seed)
+    K = int(rng.integers(1, 600))
+    S = int(rng.integers(1, 22))
+    P = int(rng.choice([1, 2, 2, 2, 2, 3]))
+    C = int(rng.integers(1, 4))
+    N = int(rng.choice([1, 2, 511, 512, 513, 1024, 3000, 6000, 12000, 20011]))
+    lo = -int(rng.choice([0, 0, 1, 3, 40, 300, 700]))
+    hi = int(rng.choice([0, 1, 9, 200, 600, 1500, N + 5]))
+    f = np.abs(rng.standard_normal((S, C, N))).astype(np.float32)
+    if seed % 3 == 0:
+        f = np.round(f * 2)
+    tau = rng.integers(lo, hi + 1, (K, S, P)).astype(np.int32)
+    wp = rng.random((S, C, P)).astype(np.float32)
+    if seed % 2 == 0:
+        # n closest stations with equal weights, as set_weights_sources builds them
+        n_close = int(rng.integers(1, S + 1))
+        order = np.argsort(tau[:, :, 0], axis=1)
+        ws = np.zeros((K, S), np.float32)
+        np.put_along_axis(ws, order[:, :n_close], 1.0, axis=1)
+        if seed % 4 == 0:
+            ws /= ws.sum(axis=1, keepdims=True)
+    else:
+        ws = rng.random((K, S)).astype(np.float32)
+        ws[rng.random((K, S)) < rng.random()] = 0.0
+    for oob in ("strict", "flexible"):
+        mb, ma = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds=oob)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        _same(mb, ob, f"seed {seed} {oob} maxbeam (K={K} S={S} P={P} N={N} tau in [{lo},{hi}])")
+        _same(ma, oa, f"seed {seed} {oob} argmax")
+    if K * N <= 400_000:
+        _same(beamform(f, tau, wp, ws, device="gpu", reduce="none"),
+              oracle_lib.beamform(f, tau, wp, ws, "strict", "none"), f"seed {seed} full beam")

@@ -97,6 +97,28 @@ def test_mf_first_samples_of_the_trace_with_negative_moveouts(oracle_lib, L, fir
                       f"first={first} L={L} wave={wave} step={step} ns={ns}")
 
 
+@pytest.mark.parametrize("L,N,step,lo", [(1, 2, 2, -1026), (3, 5, 1, -1023), (1, 1, 1, -1026), (1, 3, 1, -1023),
+                                         (64, 70, 1, -5000), (300, 305, 1, -5000), (300, 9000, 3, -20000),
+                                         (1100, 1101, 1, -70000)])
+def test_mf_no_valid_lag_at_all(oracle_lib, L, N, step, lo):
+    """Every template window lies before the trace: the valid range is empty (stored first > last)
+    and the result all zeros.  The MFMA kernels used to take a workgroup that straddles both ends of
+    the inverted range for a valid one and load norms at lag + moveout, far outside the table -- a
+    GPU memory fault found by the long fuzz session (tools/fuzz_long.sh, seeds 59, 266, 1106, 1277)."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(L * 31 + N)
+    T, S, C = 3, 4, 2
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(lo, lo // 2, (T, S, C)).astype(np.int32)
+    w = (rng.random((T, S, C)) + 0.1).astype(np.float32)
+    w[0, 0, 0] = 0.0
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns)
+        _same(got, oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"L={L} N={N} step={step} ns={ns}")
+        assert not got.any()
+
+
 @pytest.mark.parametrize("step", [2, 3, 7, 16, 17, 50])
 @pytest.mark.parametrize("L", [64, 400])
 def test_mf_step_greater_than_one(oracle_lib, step, L):
