@@ -121,6 +121,10 @@ __global__ __launch_bounds__(SEL_THREADS) void bp_window_stats_kernel(
     const long long i1 = q * shift;
     const long long i2 = i1 + window < n ? i1 + window : n;
     const int len = (int)(i2 - i1);
+    if (len <= 0) {                       // empty window: np.median([]) = NaN
+        if (threadIdx.x == 0) { med[q] = __uint_as_float(0x7fc00000u); mad[q] = __uint_as_float(0x7fc00000u); }
+        return;
+    }
     const float* x = beam + i1;
     if (threadIdx.x == 0) has_nan = 0;
     __syncthreads();
@@ -188,14 +192,10 @@ extern "C" int bpmf_bp_window_stats_dev(const float* d_beam, size_t n, size_t wi
         set_error("bpmf_bp_window_stats_dev: window too long");
         return -1;
     }
-    // windows q = 1 .. nw; the last ones may be cut short by the end of the series, and a window
-    // that would start at or past n (possible only for q = nw when shift does not divide) is empty
-    size_t last = nw;
-    while (last >= 1 && last * shift >= n) --last;
-    if (last < nw) {
-        set_error("bpmf_bp_window_stats_dev: window %zu starts past the end of the series", nw);
-        return -1;
-    }
+    // windows q = 1 .. nw; the last ones may be cut short by the end of the series, and the last one
+    // is EMPTY when nw * shift == n (overlap 0 and a series of a whole number of windows): the
+    // reference takes np.median of an empty slice there, NaN (template_search.py:1459-1466) -- so
+    // does the kernel (len <= 0)
     bp_window_stats_kernel<<<dim3((unsigned)nw), dim3(SEL_THREADS), 0, stream>>>(
         d_beam, (long long)n, (long long)window, (long long)shift, d_median, d_mad);
     BPMF_LAUNCH_CHECK();

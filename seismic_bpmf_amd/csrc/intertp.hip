@@ -42,23 +42,22 @@ __global__ void intertp_norms_kernel(const float* __restrict__ wf, int n_rows, i
     r_t[row] = 1.0f / sqrtf(e);   // correctly rounded sqrt and divide (hipcc default), as mf.hip
     // prefix sums of the squares, hierarchical exactly like the matched filter's: restart inside
     // every chunk of CSUM_CHUNK samples, chunk totals accumulated sequentially
-    double off = 0.0, local = 0.0;
-    int n = 0;                       // csum(n) = off + local is known for this n
+    double off = 0.0, local = 0.0;   // csum(n) = off + local
     double lo[64];                   // csum(lag), lag = 0 .. n_lag - 1  (n_lag <= 64)
-    for (int lag = 0; lag < n_lag; ++lag) {
-        for (; n < lag; ++n) {
-            if (n % CSUM_CHUNK == 0 && n) { off += local; local = 0.0; }
-            local += (double)x[n] * (double)x[n];
+    // one pass over the samples; csum(lag) is stored when n reaches lag, window `lag` is closed when n
+    // reaches lag + L (L >= 1, so its csum(lag) is already there -- also when L < 2 max_lag, where the
+    // starts of the late windows come AFTER the ends of the early ones)
+    int lag_lo = 0, lag_hi = 0;
+    for (int n = 0; ; ++n) {
+        const double cs = off + local;
+        if (lag_lo < n_lag && lag_lo == n) lo[lag_lo++] = cs;
+        if (lag_hi < n_lag && lag_hi + L == n) {
+            r_d[(size_t)row * n_lag + lag_hi] = 1.0f / sqrtf((float)(cs - lo[lag_hi]));
+            ++lag_hi;
         }
-        lo[lag] = off + local;
-    }
-    for (int lag = 0; lag < n_lag; ++lag) {
-        for (; n < lag + L; ++n) {
-            if (n % CSUM_CHUNK == 0 && n) { off += local; local = 0.0; }
-            local += (double)x[n] * (double)x[n];
-        }
-        const double hi = off + local;
-        r_d[(size_t)row * n_lag + lag] = 1.0f / sqrtf((float)(hi - lo[lag]));
+        if (n == Lw) break;
+        if (n % CSUM_CHUNK == 0 && n) { off += local; local = 0.0; }
+        local += (double)x[n] * (double)x[n];
     }
 }
 

@@ -260,9 +260,31 @@ def detect_peaks(x, mpd=1):
     if ind.size and ind[-1] == x.size - 1:
         ind = ind[:-1]
     if ind.size and mpd > 1:
-        rank = np.argsort(x[ind])[::-1]           # tallest first (ties: same order as argsort)
+        rank = _tallest_first(x[ind])
         ind = ind[_suppress(ind, rank, mpd)]
     return ind
+
+
+def _tallest_first(height):
+    """Visiting order of the suppression, the reference's own expression
+    `np.argsort(x[ind])[::-1]` (BPMF/utils.py:2335).  NumPy's default sort is not stable (for
+    float64 a SIMD sort): the order of EXACTLY equal heights depends on the whole array, so it
+    can only be reproduced by sorting the same full list of local maxima -- which is what
+    detect_peaks does, and what the device path falls back to when two equal peaks closer than mpd
+    exist among its candidates (has_close_ties)."""
+    return np.argsort(np.asarray(height))[::-1]
+
+
+def has_close_ties(index, height, mpd):
+    """True if two peaks of exactly equal height lie within mpd samples of each other -- the only
+    case in which the visiting order of equal heights changes which peaks survive."""
+    index = np.asarray(index, dtype=np.int64)
+    height = np.asarray(height)
+    if index.size < 2:
+        return False
+    order = np.lexsort((index, height))
+    h, i = height[order], index[order]
+    return bool(np.any((h[1:] == h[:-1]) & (i[1:] - i[:-1] <= mpd)))
 
 
 def _suppress(ind, rank, mpd):
@@ -321,13 +343,13 @@ def find_beam_detections_from_candidates(index, height, threshold_at, mpd, n, be
     device extraction, csrc/bp_detect.hip); `threshold_at(samples)` evaluates the threshold at a few
     samples.  The tallest-first suppression of BPMF/utils.py:2334-2345 runs on this list: the peaks
     it lacks are lower than every peak above the threshold, so they can neither remove one of those
-    nor tie with one, and the survivors above the threshold are the reference's.  (The order in
-    which exactly equal heights are visited is np.argsort's, as in the reference; it is only
-    defined up to the sort implementation, there as here.)"""
+    nor tie with one, and the survivors above the threshold are the reference's.  Exactly equal
+    heights closer than mpd are the one exception (has_close_ties): the caller then passes the list
+    of ALL local maxima, on which the order is the reference's (_tallest_first)."""
     index = np.asarray(index, dtype=np.int64)
     height = np.asarray(height).astype(np.float64)
     if index.size and mpd > 1:
-        rank = np.argsort(height)[::-1]
+        rank = _tallest_first(height)
         keep = _suppress(index, rank, mpd)
         index, height = index[keep], height[keep]
     above = height > np.asarray(threshold_at(index), dtype=np.float64)

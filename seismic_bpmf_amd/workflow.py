@@ -148,7 +148,12 @@ def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev
         med, mad = det.window_stats(beam, window, overlap)
         centre, thr = pp.bp_threshold_nodes(n, int(window), overlap, med, mad, n_dev)
         nodes = (centre, thr)
-        floor = float(np.min(thr.astype(np.float64)))
+        # a NaN node (a window that holds a NaN, or the reference's empty last window when the
+        # series is a whole number of non-overlapping windows) makes the interpolated threshold
+        # NaN around it, where the reference then keeps no peak (`>` is false); the floor is the
+        # smallest finite node
+        finite = thr[np.isfinite(thr)]
+        floor = float(finite.astype(np.float64).min()) if finite.size else float("nan")
 
         def threshold_at(samples):
             return pp.interp_threshold(samples, centre, thr)
@@ -159,20 +164,25 @@ def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev
             return np.full(len(samples), float(threshold))
     else:
         thr_arr = np.asarray(threshold)
-        floor = float(thr_arr.min())
+        floor = float(np.nanmin(thr_arr)) if np.isfinite(thr_arr).any() else float("nan")
 
         def threshold_at(samples):
             return thr_arr[samples]
-    if not np.isfinite(floor):
-        raise ValueError("the detection threshold is not finite (NaN in the max-beam?)")
+    if not np.isfinite(floor):               # no finite threshold anywhere: nothing can exceed it
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int32), nodes
     rec = det.extract_peaks(beam, arg, floor)
+    if mpd > 1 and pp.has_close_ties(rec["index"], rec["beam"], mpd):
+        # two exactly equal peaks closer than mpd: which one survives depends on where NumPy's
+        # unstable sort puts them in the list of ALL local maxima (pp._tallest_first) -- fetch that
+        # list (12 bytes per local maximum; rare on real beams, common on rounded test series)
+        rec = det.extract_peaks(beam, arg, -np.inf)
     # beam windows around every candidate that can survive, in ONE gather + transfer: the snap
     # looks +-mpd/2 around a peak, and a snapped peak can be looked at once more (+-mpd covers it)
     half = int(mpd) + 1
     idx_all = rec["index"].astype(np.int64)
     cache = {}
     if idx_all.size:
-        keep_rank = np.argsort(rec["beam"].astype(np.float64))[::-1]
+        keep_rank = pp._tallest_first(rec["beam"].astype(np.float64))
         keep = pp._suppress(idx_all, keep_rank, mpd) if mpd > 1 else np.ones(idx_all.size, bool)
         cand = idx_all[keep]
         cand = cand[rec["beam"][keep].astype(np.float64) > threshold_at(cand)]
@@ -276,7 +286,9 @@ def intertemplate_cc(waveforms_arr, weights, max_lag=10, device=None, pair_mask=
     (bpmf_intertemplate_cc_dev); anything else takes the per-template loop of the reference
     (intertemplate_cc_loop).  Both give the same bits."""
     import torch
-    if not callable(weights):
+    if np.shape(waveforms_arr)[-1] <= 2 * int(max_lag) or max_lag < 0:
+        raise ValueError("intertemplate_cc: the waveforms must be longer than 2 * max_lag samples")
+    if not callable(weights) and max_lag <= 31:      # the batched kernel keeps 2 * max_lag + 1 <= 63 lags per pair
         w = np.asarray(weights, dtype=np.float32)
         fact = None
         if w.ndim == 3:
@@ -305,6 +317,11 @@ def intertemplate_cc(waveforms_arr, weights, max_lag=10, device=None, pair_mask=
             _lib.check(rc, "bpmf_intertemplate_cc_dev")
             o = out.cpu().numpy()
             return (o + o.T) / 2.0
+    if not callable(weights) and np.ndim(weights) == 3:     # factorised weights, too many lags for the batched kernel
+        w = np.asarray(weights, dtype=np.float32)
+        T = w.shape[0]
+        mask = np.ones((T, T), bool) if pair_mask is None else np.asarray(pair_mask, dtype=bool)
+        weights = lambda t: w[t][None, :, :] * mask[t][:, None, None]
     return intertemplate_cc_loop(waveforms_arr, weights, max_lag=max_lag, device=device)
 
 
@@ -320,6 +337,8 @@ def intertemplate_cc_loop(waveforms_arr, weights, max_lag=10, device=None):
     (T, T) matrix comes back."""
     import torch
     wf = np.ascontiguousarray(waveforms_arr, dtype=np.float32)
+    if wf.shape[-1] <= 2 * int(max_lag) or max_lag < 0:
+        raise ValueError("intertemplate_cc: the waveforms must be longer than 2 * max_lag samples")
     T, S, Cc = wf.shape[:3]
     mf = MatchedFilterGPU(device=device)
     wf_dev = mf._dev(wf, torch.float32)

@@ -7,12 +7,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def _fuzz_seeds(default):
+    """BPMF_FUZZ_SEEDS=a:b widens the sweep for a long session on the GPU box
+    (tools/fuzz_long.sh); the default stays small enough for the driver's run."""
+    import os
+    spec = os.environ.get("BPMF_FUZZ_SEEDS")
+    if not spec:
+        return range(default)
+    a, b = spec.split(":")
+    return range(int(a), int(b))
+
+
 def _same(a, b, what):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     assert np.array_equal(a, b), f"{what}: {(a != b).sum()} of {a.size} values differ"
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _fuzz_seeds(24))
 def test_bp_random_shapes(oracle_lib, seed):
     from seismic_bpmf_amd import beamform
     rng = np.random.default_rng(1000 + seed)
@@ -41,7 +52,7 @@ def test_bp_random_shapes(oracle_lib, seed):
               oracle_lib.beamform(f, tau, wp, ws, "strict", "none"), f"seed {seed} full beam")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _fuzz_seeds(24))
 def test_mf_random_shapes(oracle_lib, seed):
     from seismic_bpmf_amd import matched_filter
     rng = np.random.default_rng(2000 + seed)
@@ -68,17 +79,6 @@ def test_mf_random_shapes(oracle_lib, seed):
         want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=network_sum)
         _same(got, want, f"seed {seed} network_sum={network_sum} (T={T} S={S} C={C} L={L} N={N} step={step} mv<={mv_max})")
         assert np.isfinite(got).all()
-
-
-def _fuzz_seeds(default):
-    """BPMF_FUZZ_SEEDS=a:b widens the sweep for a long session on the GPU box
-    (tools/fuzz_long.sh); the default stays small enough for the driver's run."""
-    import os
-    spec = os.environ.get("BPMF_FUZZ_SEEDS")
-    if not spec:
-        return range(default)
-    a, b = spec.split(":")
-    return range(int(a), int(b))
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds(40))

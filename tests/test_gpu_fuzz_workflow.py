@@ -1,0 +1,114 @@
+"""GPU: seeded random sweeps of the device stages around the two hot paths -- BP detection
+(window statistics, peak extraction, suppression), the RMS threshold + candidate extraction behind
+the matched filter, the batched inter-template CC -- against their host mirrors / the oracle, which
+tests/test_postprocess.py and tests/test_oracle_pinned.py pin to the reference's goldens.  Bit-exact.
+BPMF_FUZZ_SEEDS=a:b widens the sweep (tools/fuzz_long.sh A B secs fuzz_workflow)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fuzz_seeds(default):
+    spec = os.environ.get("BPMF_FUZZ_SEEDS")
+    if not spec:
+        return range(default)
+    a, b = spec.split(":")
+    return range(int(a), int(b))
+
+
+@pytest.mark.filterwarnings("ignore:Mean of empty slice", "ignore:invalid value encountered")
+@pytest.mark.parametrize("seed", _fuzz_seeds(16))
+def test_fuzz_workflow_bp_detections(seed):
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.workflow import beam_detections_device
+    rng = np.random.default_rng(31_000 + seed)
+    n = int(rng.choice([3, 50, 999, 5_000, 20_001, 65_536, 150_000]))
+    window = int(rng.choice([w for w in (2, 7, 64, 500, 2_049, 4_096, 30_000) if w <= n] or [n]))
+    overlap = float(rng.choice([0.0, 0.5, 0.75, 0.9]))
+    if int((1.0 - overlap) * window) < 1:
+        overlap = 0.0
+    mpd = int(rng.choice([1, 2, 5, 40, 333, 5_000]))
+    n_dev = float(rng.choice([0.0, 3.0, 8.0, 15.0]))
+    x = np.abs(rng.standard_normal(n)).astype(np.float32)
+    kind = seed % 4
+    if kind == 0:
+        x = np.round(x, 1)                                   # plateaus and exact ties
+    elif kind == 1:
+        x[n // 3:] *= np.float32(5.0)                        # the threshold steps up
+    elif kind == 2:
+        x = (x - np.float32(1.0)).astype(np.float32)         # negative values
+    for p in rng.integers(0, n, max(1, n // 700)):
+        x[p] += np.float32(rng.uniform(3, 40))
+    src = rng.integers(0, 1_000_000, n).astype(np.int32)
+    xd, sd = torch.as_tensor(x, device="cuda"), torch.as_tensor(src, device="cuda")
+    what = f"seed {seed} n={n} window={window} overlap={overlap} mpd={mpd} n_dev={n_dev}"
+    want_thr = pp.bp_time_dependent_threshold(x, window, n_dev, overlap=overlap)
+    want_p, want_s = pp.find_beam_detections(x, src, want_thr, mpd)
+    peaks, psrc, _ = beam_detections_device(xd, sd, mpd=mpd, window=window, n_dev=n_dev, overlap=overlap)
+    assert np.array_equal(peaks, want_p) and np.array_equal(psrc, want_s), what
+    c = float(np.quantile(x, 0.98))
+    want_p, want_s = pp.find_beam_detections(x, src, c, mpd)
+    peaks, psrc, _ = beam_detections_device(xd, sd, mpd=mpd, threshold=c)
+    assert np.array_equal(peaks, want_p) and np.array_equal(psrc, want_s), what + " constant threshold"
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(12))
+def test_fuzz_workflow_rms_threshold_and_candidates(oracle_lib, seed):
+    import torch
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    rng = np.random.default_rng(32_000 + seed)
+    rows = int(rng.integers(1, 6))
+    n = int(rng.choice([600, 5_000, 20_011, 70_000]))
+    window = int(rng.choice([w for w in (100, 512, 3_000, 10_000) if 2 * w <= n]))
+    overlap = float(rng.choice([0.0, 0.25]))
+    num_dev = float(rng.choice([3.0, 8.0]))
+    x = (0.05 * rng.standard_normal((rows, n))).astype(np.float32)
+    if seed % 3 == 0:
+        a = int(rng.integers(0, n // 2))
+        x[0, a:a + int(rng.integers(1, n // 3))] = 0.0       # exact zeros: replaced by scaled white noise
+    for r in range(rows):
+        for p in rng.integers(0, n, 6):
+            x[r, p] += np.float32(rng.uniform(0.3, 0.9))
+    wn = rng.standard_normal(500).astype(np.float32)
+    th = ThresholdGPU()
+    xd = torch.as_tensor(x, device="cuda")
+    thr_win, full = th.time_dependent_threshold(xd, window, num_dev, overlap=overlap, white_noise=wn, expand=True)
+    full = full.cpu().numpy()
+    for r in range(rows):
+        want = oracle_lib.time_dependent_threshold(x[r], window, num_dev, overlap, wn)
+        assert np.array_equal(full[r], want), f"seed {seed} row {r} n={n} window={window} overlap={overlap}"
+    cand = th.extract_candidates(xd, thr_win, window, overlap=overlap)
+    rr, ii = np.nonzero(x > full)
+    assert np.array_equal(cand["row"], rr) and np.array_equal(cand["index"], ii), f"seed {seed}"
+    assert np.array_equal(cand["cc"], x[rr, ii])
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(12))
+def test_fuzz_workflow_intertemplate_cc(oracle_lib, seed):
+    from seismic_bpmf_amd import workflow
+    rng = np.random.default_rng(33_000 + seed)
+    T = int(rng.integers(1, 40))
+    S = int(rng.integers(1, 9))
+    C = int(rng.integers(1, 4))
+    L = int(rng.choice([1, 2, 9, 40, 100, 257, 1025, 1300]))
+    max_lag = int(rng.choice([0, 1, 5, 10, 33]))         # 33: more lags than the batched kernel holds -> the loop
+    if L <= 2 * max_lag:
+        with pytest.raises(ValueError):
+            workflow.intertemplate_cc(np.zeros((2, 1, 1, L), np.float32), np.ones((2, 1, 1), np.float32), max_lag=max_lag)
+        max_lag = (L - 1) // 2
+    wf = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    if T > 2:
+        wf[2, 0, 0] = 0.0
+    base = (rng.random((T, S, C)) > 0.3).astype(np.float32) * rng.random((T, S, C)).astype(np.float32)
+    if seed % 3 == 0:
+        base = (base > 0).astype(np.float32)
+        base /= np.maximum(base.sum(axis=(1, 2), keepdims=True), 1.0)
+    mask = rng.random((T, T)) > rng.random()
+    got = workflow.intertemplate_cc(wf, base, max_lag=max_lag, pair_mask=mask)
+    full = base[:, None, :, :] * mask[:, :, None, None]
+    want = workflow.intertemplate_cc_loop(wf, full, max_lag=max_lag)
+    assert np.array_equal(got, want), f"seed {seed} T={T} S={S} C={C} L={L} max_lag={max_lag}"

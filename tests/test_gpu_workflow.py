@@ -225,3 +225,13 @@ def test_bp_detections_on_device_edge_cases():
     assert np.array_equal(peaks, want_p)
     with pytest.raises(ValueError):
         det.window_stats(xd, n + 1, 0.75)
+    # overlap 0 and a series of a whole number of windows: the reference's last window is empty, its
+    # node NaN (np.median of an empty slice), and no peak is kept where the interpolated threshold is NaN
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_thr = pp.bp_time_dependent_threshold(x, 3_000, 3.0, overlap=0.0)
+        want_p, want_s = pp.find_beam_detections(x, src, want_thr, 50)
+    assert np.isnan(want_thr[-1]) and want_p.size > 3
+    peaks, psrc, nodes = beam_detections_device(xd, sd, mpd=50, window=3_000, n_dev=3.0, overlap=0.0)
+    assert np.array_equal(peaks, want_p) and np.array_equal(psrc, want_s) and np.isnan(nodes[1][-2])

@@ -265,3 +265,15 @@ def test_candidate_based_beam_detections_equal_the_full_series_logic():
         got = pp.find_beam_detections_from_candidates(idx, h, lambda s: pp.interp_threshold(s, centre, nodes), mpd, n,
                                                       lambda i0, i1: x[i0:i1])
         assert np.array_equal(got, want) and want.size >= 5 and idx.size < n // 4
+
+
+def test_has_close_ties():
+    """Equal heights matter only within mpd of each other (postprocess.has_close_ties decides
+    whether the device path needs the full list of local maxima)."""
+    idx = np.array([10, 50, 400, 900])
+    assert not pp.has_close_ties(idx, np.array([1.0, 2.0, 3.0, 4.0]), 100)
+    assert pp.has_close_ties(idx, np.array([2.0, 2.0, 3.0, 4.0]), 40)
+    assert not pp.has_close_ties(idx, np.array([2.0, 2.0, 3.0, 4.0]), 39)
+    assert not pp.has_close_ties(idx, np.array([2.0, 5.0, 2.0, 2.0]), 300)      # equal, but far apart
+    assert pp.has_close_ties(idx, np.array([2.0, 5.0, 2.0, 2.0]), 500)
+    assert not pp.has_close_ties(idx[:1], np.array([2.0]), 500)

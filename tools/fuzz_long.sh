@@ -4,7 +4,7 @@
 # with the process -- a GPU memory fault aborts it -- is reported and replaced).
 # Usage: tools/fuzz_long.sh 40 1500 [seconds] [-k expr]
 set -u
-A=${1:-40}; B=${2:-1000}; K=${4:-signed}
+A=${1:-40}; B=${2:-1000}; K=${4:-random_shapes}
 mkdir -p gpurun_out
 BPMF_FUZZ_SEEDS=$A:$B timeout ${3:-1500} python -m pytest tests/test_gpu_fuzz.py -q -m gpu -k "$K" -n 8 \
     > gpurun_out/fuzz_long_${A}_${B}.log 2>&1
