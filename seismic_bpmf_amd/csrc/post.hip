@@ -351,7 +351,8 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
 // BPMF/libc.c:11-53 (kurtosis; wrapper BPMF/clib.py:86-102), conventions of
 // oracle/adjacent_oracle.c:kurtosis_cpu: kurto[n] (n >= W) from the W samples before n, mean as a
 // sequential float sum, 2nd and 4th moments as float accumulators of double squares, written only
-// where the variance exceeds 1e-6 (other samples keep the caller's zeros).  One thread per output
+// where the variance exceeds 1e-6 (other samples keep the caller's zeros; W = 2 and 3 divide by
+// (W - 2)(W - 3) = 0 and give +-inf / NaN exactly as the reference does, W = 1 never writes).  One thread per output
 // sample; a workgroup stages its 256 + W input samples in LDS once.
 namespace bpmf {
 __global__ __launch_bounds__(256) void kurtosis_kernel(const float* __restrict__ x, int W,
@@ -393,7 +394,7 @@ extern "C" int bpmf_kurtosis_dev(const float* d_signal, int W, size_t n_channels
                                  bpmf_stream_t stream_, float* d_kurto)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!d_signal || !d_kurto || W < 4 || n_channels == 0 || n_channels > 65535 ||
+    if (!d_signal || !d_kurto || W < 1 || n_channels == 0 || n_channels > 65535 ||
         (size_t)W > 32768) {
         bpmf::set_error("bpmf_kurtosis_dev: bad argument (W=%d, channels=%zu)", W, n_channels);
         return -1;
