@@ -23,6 +23,9 @@ for c in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_INSTS_VALU SQ
   done
 done
 cd $R && python tools/summarize_prof.py gpurun_out/prof_$TAG $TAG > /dev/null
+# profiles/ on the box is not merged back by gpurun, gpurun_out/ is: leave a copy there
+mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_bench.json $R/profiles/${TAG}_bench_under_rocprof.json \
+    $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_kernel_stats_by_grid.csv $R/profiles/${TAG}_pmc.json $R/gpurun_out/profiles_$TAG/ 2>/dev/null
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 ls -la $R/profiles
