@@ -691,14 +691,22 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
         int4 rec = recs[0];
         int4 rec1 = recs[1];
         int ri = 0;
+        // experiment (-DMF_EARLY_STAGE=1): the next channel's LDS stores (or LDS-DMA copies) go right
+        // behind the K loop, BEFORE the epilogue of the current channel, so that their latency runs
+        // under the epilogue's VALU work instead of in front of the next K loop
+#ifndef MF_EARLY_STAGE
+#define MF_EARLY_STAGE 0
+#endif
+        constexpr bool EARLY = MF_EARLY_STAGE != 0;
         if (rec.x >= 0) { if (wave_dma) dma_stage(rec.x, rec.y); else issue_stage(rec.x, rec.y); }
+        if (EARLY && !wave_dma && rec.x >= 0) write_stage();
         while (rec.x >= 0) {
             const int ch = rec.x;
             if (wave_dma) {
                 // each wave stages its own buffers: its copies are in LDS once vmcnt retires them
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            else write_stage();  // in place: this wave finished reading the previous channel
+            else if (!EARLY) write_stage();  // in place: this wave finished reading the previous channel
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
@@ -787,6 +795,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
 #undef MF_MFMA
 #undef MF_REQ
 #undef MF_STEP
+            if (EARLY && rec1.x >= 0) { if (wave_dma) dma_stage(rec1.x, rec1.y); else write_stage(); }
 
             if (NETWORK_SUM && STEP1 && wave_inside && !(ablate & 1)) {
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
             }
             // LDS-DMA staging: the K loop is done with the buffers (lgkmcnt(0) above), the next
             // channel's window and band can land in place
-            if (wave_dma && rec1.x >= 0) dma_stage(rec1.x, rec1.y);
+            if (!EARLY && wave_dma && rec1.x >= 0) dma_stage(rec1.x, rec1.y);
             rec = rec1;
             rec1 = rec2;
             ++ri;
