@@ -112,3 +112,41 @@ def test_fuzz_workflow_intertemplate_cc(oracle_lib, seed):
     full = base[:, None, :, :] * mask[:, :, None, None]
     want = workflow.intertemplate_cc_loop(wf, full, max_lag=max_lag)
     assert np.array_equal(got, want), f"seed {seed} T={T} S={S} C={C} L={L} max_lag={max_lag}"
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(8))
+def test_fuzz_workflow_matched_filter_detections(oracle_lib, seed):
+    """workflow.matched_filter_detections (CC, RMS threshold, candidate compaction on the device, merge
+    on the host) == the same chain from CPU pieces: oracle CC, oracle threshold (pinned to the
+    reference's libc.c), postprocess.select_cc_indexes (pinned to the reference's Python)."""
+    from seismic_bpmf_amd import postprocess as pp, synthetic as syn, workflow
+    rng = np.random.default_rng(34_000 + seed)
+    T, S, C = int(rng.integers(1, 5)), int(rng.integers(2, 6)), int(rng.integers(1, 4))
+    L = int(rng.choice([32, 64, 200]))
+    N = int(rng.choice([40_000, 90_001]))
+    step = int(rng.choice([1, 1, 2]))
+    sr = 100.0
+    m = syn.make_mf_inputs(T=T, S=S, C=C, L=L, N=N, seed=int(rng.integers(1 << 30)),
+                           max_moveout=int(rng.choice([50, 400])), n_events=int(rng.integers(1, 6)), step=step)
+    window_dur = float(rng.choice([20.0, 75.0]))
+    min_iet = float(rng.choice([0.5, 3.0]))
+    overlap = float(rng.choice([0.0, 0.25]))
+    n_dev = float(rng.choice([6.0, 8.0]))
+    wn = rng.standard_normal(500).astype(np.float32)
+    got, cc = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], m["data"], step=step,
+                                                 sr=sr, threshold_window_dur=window_dur,
+                                                 minimum_interevent_time=min_iet, n_dev=n_dev, overlap=overlap,
+                                                 white_noise=wn, remove_edges=False)
+    cc_ref = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], step)
+    assert np.array_equal(cc.cpu().numpy(), cc_ref)
+    window = int(pp.sec_to_samp(window_dur, sr))
+    w = np.asarray(m["weights"], np.float32)
+    mv = np.asarray(m["moveouts"])
+    for t in range(T):
+        thr = oracle_lib.time_dependent_threshold(cc_ref[t], window, n_dev, overlap, wn)
+        thr = np.minimum(thr, np.float32((0.80 * w.reshape(T, -1).sum(axis=1))[t]))
+        win = workflow.search_window(mv[t].reshape(mv.shape[1], -1), int(pp.sec_to_samp(min_iet, sr)), step)
+        want = pp.select_cc_indexes(cc_ref[t], thr, win, step=step, sr=sr, data_duration_sec=1e9,
+                                    n_dev_threshold=n_dev, min_freq_hz=2.0, data_buffer_sec=0.0,
+                                    remove_edges=False, anomalous_cdf_at_mean_plus_1sig=0.0)
+        assert np.array_equal(got[t], want), f"seed {seed} template {t}: T={T} S={S} C={C} L={L} N={N} step={step}"
