@@ -6,6 +6,9 @@ size-independent properties of the domain:
     neighbourhood's peak at EXACTLY its planted lag; |CC| <= 1; template blocks computed separately
     (the multi-GPU sharding) concatenate to the single-pass result bit for bit; re-running is
     bit-identical; a random sample of lags equals the oracle evaluated on just those windows.
+  * MF, whole day against the oracle: 4 templates with moveouts of both signs, all 34.6 M CCs bit-exact
+    (the oracle needs ~10 s on the GPU box's 128 host threads); BP: a 2 500-source slab of the cfg3 grid
+    over the whole day, max-beam and arg-max bit-exact (~25 s).
   * BP (cfg3: 50 000 sources, 1 day @ 50 Hz): the grid split in two "ranks" with global ids and
     merged with the packed-key max equals the single-pass result bit for bit (what the RCCL
     all-reduce does at N = 2); planted events come out within the bump width of their sample with a beam >= the
@@ -60,6 +63,38 @@ def test_mf_full_day_properties(oracle_lib):
         assert np.array_equal(cch[1, i0:i0 + 3000], want)
 
 
+def test_mf_full_day_signed_moveouts_whole_day_against_the_oracle(oracle_lib):
+    """cfg2's day (20 x 3 channels, L = 256, 8.64 M samples) with moveouts of both signs, 4 templates:
+    ALL 34.6 M network CCs equal the oracle bit for bit -- the first and last lags, where the valid
+    range starts and ends inside a workgroup and the staging loads are zero-filled by the buffer
+    bounds check (the two MFMA-kernel defects of round 2 lived there), the zeros outside the valid
+    range, and every lag block in between.  (~10 s of oracle time on the GPU box's host cores; a
+    segment-wise oracle would not do: the window energies are differences of double prefix sums from
+    the start of the trace, and a segment's own origin rounds them differently.)"""
+    import torch
+    from seismic_bpmf_amd import MatchedFilterGPU
+    S, C, L, N, T = 20, 3, 256, 8_640_000, 4
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    data = torch.randn((S, C, N), device="cuda", generator=g)
+    rng = np.random.default_rng(33)
+    tmpl = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-1500, 3001, (T, S, C)).astype(np.int32)
+    mv[0, 3, 1], mv[1, 0, 0], mv[2, 5, 2] = -1499, -1022, -3          # first valid lags of every residue mod 4
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[3, :, 1] = 0.0
+    mf = MatchedFilterGPU()
+    mf.set_data(data)
+    cc = mf.run(tmpl, mv, w, 1).cpu().numpy()
+    assert cc.shape == (T, N - L + 1)
+    want = oracle_lib.matched_filter(tmpl, mv, w, data.cpu().numpy(), 1)
+    assert np.array_equal(cc, want), f"{(cc != want).sum()} of {cc.size} CCs differ"
+    for t in range(T):
+        used = w[t] != 0
+        lo, hi = int(-mv[t][used].min()), int(N - L - mv[t][used].max())
+        assert not cc[t, :lo].any() and not cc[t, hi + 1:].any() and cc[t, lo] != 0 and cc[t, hi] != 0
+
+
 def test_bp_full_day_shard_merge_and_planted_events():
     import torch
     from seismic_bpmf_amd import BeamformerGPU, parallel, postprocess as pp, synthetic as syn
@@ -109,6 +144,36 @@ def test_bp_full_day_shard_merge_and_planted_events():
         assert maxbeam[peaks[hit[0]]] >= maxbeam[t0] >= 8.0      # 20 terms x 0.1 x (8 + noise)
     for b in (full, r0, r1):
         b.close()
+
+
+def test_bp_full_day_slab_of_the_grid_against_the_oracle(oracle_lib):
+    """cfg3's day (20 stations x 3 components, 4.32 M samples) and a slab of 2 500 sources of its grid
+    (50 x 50 x 1: one depth level, 10 closest stations): every one of the 8 438 tiles of the day --
+    bp_beam_fast_kernel on the interior ones, round 1's kernel on the ends -- max-beam and arg-max
+    equal the oracle bit for bit, strict and flexible.  (~20 s of oracle time per mode on the GPU
+    box's host cores.)"""
+    import torch
+    from seismic_bpmf_amd import BeamformerGPU, synthetic as syn
+    cfg = syn.BP_CONFIGS["cfg3"]
+    geo = syn.make_bp_geometry((50, 50, 1), cfg["S"], cfg["P"], cfg["sr"], n_closest=10)
+    tau, ws = geo["moveouts"], geo["weights_sources"]
+    N = cfg["N"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    feat = torch.randn((cfg["S"], cfg["C"], N), device="cuda", generator=g).abs_()
+    wp = syn.phase_weights(cfg["S"], cfg["C"], cfg["P"])
+    f_host = feat.cpu().numpy()
+    bf = BeamformerGPU(tau, ws)
+    try:
+        info = bf.plan_info()
+        for oob in ("strict", "flexible"):
+            beam, arg = bf.run(feat, wp, "max", oob)
+            ob, oa = oracle_lib.beamform(f_host, tau, wp, ws, oob, "max")
+            b, a = beam.cpu().numpy(), arg.cpu().numpy()
+            assert np.array_equal(b, ob), f"{oob}: {(b != ob).sum()} of {N} beams differ ({info})"
+            assert np.array_equal(a, oa), f"{oob}: {(a != oa).sum()} of {N} arg-max differ"
+    finally:
+        bf.close()
 
 
 def test_mf_baseline_config0_whole_against_oracle_and_float64(oracle_lib):
