@@ -48,8 +48,9 @@ def test_bp_random_shapes(oracle_lib, seed):
         _same(mb, ob, f"seed {seed} {oob} maxbeam (K={K} S={S} P={P} N={N} tau<={tau_max})")
         _same(ma, oa, f"seed {seed} {oob} argmax")
     if K * N <= 400_000:
-        _same(beamform(f, tau, wp, ws, device="gpu", reduce="none"),
-              oracle_lib.beamform(f, tau, wp, ws, "strict", "none"), f"seed {seed} full beam")
+        for oob in ("strict", "flexible"):
+            _same(beamform(f, tau, wp, ws, device="gpu", reduce="none", out_of_bounds=oob),
+                  oracle_lib.beamform(f, tau, wp, ws, oob, "none"), f"seed {seed} full beam {oob}")
 
 
 @pytest.mark.parametrize("seed", _fuzz_seeds(24))
@@ -150,5 +151,6 @@ def test_bp_random_shapes_signed_moveouts(oracle_lib, seed):
         _same(mb, ob, f"seed {seed} {oob} maxbeam (K={K} S={S} P={P} N={N} tau in [{lo},{hi}])")
         _same(ma, oa, f"seed {seed} {oob} argmax")
     if K * N <= 400_000:
-        _same(beamform(f, tau, wp, ws, device="gpu", reduce="none"),
-              oracle_lib.beamform(f, tau, wp, ws, "strict", "none"), f"seed {seed} full beam")
+        for oob in ("strict", "flexible"):
+            _same(beamform(f, tau, wp, ws, device="gpu", reduce="none", out_of_bounds=oob),
+                  oracle_lib.beamform(f, tau, wp, ws, oob, "none"), f"seed {seed} full beam {oob}")
