@@ -276,18 +276,18 @@ template <int NR, int STRIDE>
 __device__ __forceinline__ void mf_stage_rows(float (&rd)[NR], __amdgpu_buffer_rsrc_t rs,
                                               long long first, int idx)
 {
-    const int o = (int)((first + idx) * 4);
+    const unsigned o = (unsigned)((first + idx) * 4);   // 32-bit byte offset, wraps like the hardware's
     if (first >= 0) {
 #pragma unroll
         for (int r = 0; r < NR; ++r)
-            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o + STRIDE * 4 * r, 0, 0));
+            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + STRIDE * 4u * r), 0, 0));
     } else {
-        int oo = o;                                // wraps like the hardware's u32 offset
+        unsigned oo = o;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             asm volatile("" : "+v"(oo));           // keep the constant out of the immediate field
-            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oo, 0, 0));
-            oo += STRIDE * 4;
+            rd[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)oo, 0, 0));
+            oo += STRIDE * 4u;
         }
     }
 }
