@@ -631,12 +631,23 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ recs, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, long long tile_base, long long n_tiles)
+    int* __restrict__ out_arg, long long tile_base, long long n_tiles, long long split_stride)
 {
     extern __shared__ float lds[];
     constexpr int TPW = 8;
     constexpr int TILE = 64 * TPW;
     constexpr int NTHREADS = 64 * WPB;
+    // Short series (an event relocation: 3-6 tiles) leave most of the 256 CUs without a tile: the
+    // launch then carries gridDim.y > 1 and workgroup (tile, y) walks only the groups
+    // [n_groups y / Y, n_groups (y + 1) / Y).  reduce="none": every source still belongs to exactly
+    // one workgroup of a tile; reduce="max": partial maxima go to out + y * split_stride and
+    // bp_merge_splits_kernel folds them (value, then lowest id -- the rule of the 16-wave merge below).
+    const int g_lo = (int)((long long)n_groups * blockIdx.y / gridDim.y);
+    const int g_hi = (int)((long long)n_groups * (blockIdx.y + 1) / gridDim.y);
+    if (REDUCE == BPMF_BP_REDUCE_MAX) {
+        out_beam += (size_t)blockIdx.y * (size_t)split_stride;
+        out_arg += (size_t)blockIdx.y * (size_t)split_stride;
+    }
 #ifndef BP_DBG
 #define BP_DBG 0
 #endif
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
     for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
 
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
         const BpGroup grp = groups[g];
         const int k_last = grp.first_src + grp.n_src - 1;
         const int k_first = grp.first_src + wv;
@@ -944,6 +955,25 @@ __device__ __forceinline__ unsigned f32_to_ordered(float f)
 __device__ __forceinline__ float ordered_to_f32(unsigned k)
 {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// reduce="max" of a short series computed in `n_split` group ranges per tile: fold the partial
+// (beam, arg) rows -- larger beam wins, lowest source id on equal beams, the rule of every other merge
+__global__ void bp_merge_splits_kernel(const float* __restrict__ pbeam, const int* __restrict__ parg,
+                                       int n_split, size_t N, float* __restrict__ beam,
+                                       int* __restrict__ arg)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float b = pbeam[i];
+    int a = parg[i];
+    for (int y = 1; y < n_split; ++y) {
+        const float bw = pbeam[(size_t)y * N + i];
+        const int aw = parg[(size_t)y * N + i];
+        if (bw > b || (bw == b && aw < a)) { b = bw; a = aw; }
+    }
+    beam[i] = b;
+    arg[i] = a;
 }
 
 __global__ void bp_pack_kernel(const float* __restrict__ beam, const int* __restrict__ arg, size_t N,
@@ -1434,11 +1464,32 @@ extern "C" int bpmf_bp_plan_info(const bpmf_bp_plan* pl, bpmf_bp_plan_stats* out
     return 0;
 }
 
+namespace {
+// Group ranges per tile (gridDim.y of the beam kernels).  A workgroup owns a 512-sample tile and one
+// workgroup fills a CU, so a series of fewer than ~128 tiles -- the reference's event relocation
+// beamforms 1 500-3 000 samples over the whole grid (BPMF/dataset.py:2174-2216) -- leaves most of the
+// 256 CUs idle: the groups of the plan are then dealt to 256 / tiles workgroups per tile.
+// BPMF_BP_SPLIT: 0/1 = off, n = force n ranges (tests).  Only the P = 2 packed kernels take it.
+int bp_split_count(const bpmf_bp_plan* pl, size_t N)
+{
+    if (!pl || pl->tpt != 2 || !pl->wps || pl->n_groups < 2) return 1;
+    if (pl->nsv != 4 && pl->nsv != 8 && pl->nsv != 12 && pl->nsv != 16 && pl->nsv != 32) return 1;   // dispatch_beam<2>'s packed kernels
+    const long long n_tiles = (long long)((N + 511) / 512);
+    long long want = n_tiles * 2 > 256 ? 1 : 256 / n_tiles;
+    const int forced = env_int("BPMF_BP_SPLIT", -1);   // read per call: the tests switch it
+    if (forced >= 0) want = forced < 1 ? 1 : forced;
+    return (int)std::max<long long>(1, std::min<long long>(want, pl->n_groups));
+}
+}  // namespace
+
 extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size_t C)
 {
     (void)C;
     if (!pl) return 0;
-    return align_up(pl->S * pl->P * N * sizeof(float), 256);
+    // the prestacked traces + (short series) the partial maxima of the group ranges
+    const size_t n_split = (size_t)bp_split_count(pl, N);
+    return align_up(pl->S * pl->P * N * sizeof(float), 256) +
+           (n_split > 1 ? align_up(n_split * N * (sizeof(float) + sizeof(int32_t)), 256) : 0);
 }
 
 namespace {
@@ -1554,6 +1605,8 @@ int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob,
 }
 
 thread_local long long t_tile_base = 0, t_tile_count = -1;   // -1: all tiles
+thread_local int t_n_split = 1;                  // group ranges per tile (short series, see bp_split_count)
+thread_local long long t_split_stride = 0;       // elements between the partial outputs of reduce="max"
 
 template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA, bool B64>
 int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
@@ -1571,11 +1624,12 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
     const long long tile_base = t_tile_count >= 0 ? t_tile_base : 0;
     const long long n_tiles = t_tile_count >= 0 ? t_tile_count : all_tiles;
     if (n_tiles <= 0) return 0;
-    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)t_n_split);  // x: multiple of 8 (XCD-aware tile order)
     if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
                                                 (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,
-                                                pl->id_offset, beam, arg, tile_base, n_tiles);
+                                                pl->id_offset, beam, arg, tile_base, n_tiles,
+                                                t_split_stride);
     BPMF_LAUNCH_CHECK();
     if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
@@ -1688,6 +1742,28 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
                                                                (int)C, P, U);
     }
     BPMF_LAUNCH_CHECK();
+    // short series: several group ranges per tile (bp_split_count); reduce="max" goes through partial
+    // rows behind the prestack in the workspace and one merge launch
+    const int n_split = bp_split_count(pl, N);
+    float* const beam_final = d_beam_out;
+    int32_t* const arg_final = d_arg_out;
+    struct SplitScope {          // the launchers read the thread-local pair; always reset on the way out
+        SplitScope(int n, long long stride) { t_n_split = n; t_split_stride = stride; }
+        ~SplitScope() { t_n_split = 1; t_split_stride = 0; }
+    } split_scope(n_split, n_split > 1 && reduce == BPMF_BP_REDUCE_MAX ? (long long)N : 0);
+    if (n_split > 1 && reduce == BPMF_BP_REDUCE_MAX) {
+        char* part = (char*)d_workspace + align_up((size_t)S * P * N * sizeof(float), 256);
+        d_beam_out = (float*)part;
+        d_arg_out = (int32_t*)(part + (size_t)n_split * N * sizeof(float));
+    }
+    auto merge_splits = [&]() -> int {
+        if (n_split > 1 && reduce == BPMF_BP_REDUCE_MAX) {
+            bp_merge_splits_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
+                d_beam_out, d_arg_out, n_split, N, beam_final, arg_final);
+            BPMF_LAUNCH_CHECK();
+        }
+        return 0;
+    };
     if (pl->fast && reduce == BPMF_BP_REDUCE_MAX && pl->tpt == 2) {
         // Tiles on which no source can leave the trace -- t0 + tmin_all >= 0 and t0 + 512 + tmax_all
         // (+ the staging slack of 8 samples) <= N -- run the interior kernel of bp_fast.hip, which is
@@ -1716,16 +1792,21 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         edge(0, lo);
         edge(hi, n_all - hi);
         if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
-        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out);
+        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out, n_split,
+                                       n_split > 1 ? (long long)N : 0);
         if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
+        if (!rc) rc = merge_splits();
         profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
         return rc;
     }
+    int rc;
     switch (pl->tpt) {
-        case 1: return dispatch_beam<1>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
-        case 2: return dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
-        default: return dispatch_beam<4>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out);
+        case 1: rc = dispatch_beam<1>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out); break;
+        case 2: rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out); break;
+        default: rc = dispatch_beam<4>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out); break;
     }
+    if (!rc) rc = merge_splits();
+    return rc;
 }
 
 namespace {

@@ -71,8 +71,14 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride)
 {
+    // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
+    // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel)
+    const int g_lo = (int)((long long)n_groups * blockIdx.y / gridDim.y);
+    const int g_hi = (int)((long long)n_groups * (blockIdx.y + 1) / gridDim.y);
+    out_beam += (size_t)blockIdx.y * (size_t)split_stride;
+    out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     // timing ablations (build with -DBPF_DBG=<bits>, see tools/ablate_bp_fast.sh): 1 skips the staging,
     // 2 the barriers, 8 the record refills (every source re-uses the first record), 16 the max
     // update -- results are WRONG with any of them.  Measured at cfg3 (profiles/r02_bp_ablation.txt).
@@ -129,15 +135,15 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    if (n_groups > 0) prefetch_descriptors(groups[0].first_win);
+    if (g_hi > g_lo) prefetch_descriptors(groups[g_lo].first_win);
 
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
         const BpFastGroup grp = groups[g];
         if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done, this group's descriptors are in LDS
         if constexpr (REJECT) {
             // every wave publishes its thresholds in the (now dead) window area and takes the
             // maximum over the 16 waves: 32 KB of LDS traffic per group
-            if (g > 0) {
+            if (g > g_lo) {
                 float* ex = lds + BPF_DESC_OFS + 4 * BPF_DESC_MAX;        // [WPB][TILE]
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) ex[wv * TILE + slot_x(j)] = thr[j];
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             }
         }
         if (!(dbg & 2)) __syncthreads();
-        if (g + 1 < n_groups) prefetch_descriptors(groups[g + 1].first_win);
+        if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
 
         for (int rr = 0; rr < grp.n_run; ++rr) {
             const BpRun run = runs[grp.first_run + rr];
@@ -364,12 +370,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 }
 
 int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long tile_lo,
-                     long long tile_hi, hipStream_t stream, float* beam, int32_t* arg)
+                     long long tile_hi, hipStream_t stream, float* beam, int32_t* arg, int n_split,
+                     long long split_stride)
 {
     if (tile_hi <= tile_lo) return 0;
     const long long n_tiles = tile_hi - tile_lo;
     const size_t lds = std::max(pl->lds_bytes, (size_t)2 * BPF_WPB * BPF_TILE * sizeof(float));
-    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8));  // multiple of 8: XCD-aware tile order
+    dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)std::max(1, n_split));  // x: multiple of 8 (XCD-aware tile order)
     // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
     const int desc_waves = (int)std::min<size_t>(BPF_DESC_MAX, (2 * pl->S * pl->P + 63) / 64 * 64) / 64;
 #define BPF_LAUNCH(UNI)                                                                            \
@@ -380,7 +387,8 @@ int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, pl->d_fwins,                \
-            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, desc_waves); \
+            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, desc_waves, \
+            split_stride);                                                                          \
     } while (0)
     if (pl->fast_uniform) BPF_LAUNCH(true); else BPF_LAUNCH(false);
 #undef BPF_LAUNCH

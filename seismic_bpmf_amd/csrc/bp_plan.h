@@ -82,5 +82,6 @@ namespace bpmf {
 // bp_fast.hip: running (max, arg-max) over all sources for the tiles [tile_lo, tile_hi), every
 // one of which lies inside [-tmin_all, N - tmax_all) (no bounds test per source).
 int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long tile_lo,
-                     long long tile_hi, hipStream_t stream, float* beam, int32_t* arg);
+                     long long tile_hi, hipStream_t stream, float* beam, int32_t* arg,
+                     int n_split = 1, long long split_stride = 0);
 }

@@ -311,3 +311,41 @@ def test_bp_fast_path_short_traces_have_no_interior_tiles(oracle_lib):
         ob, oa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
         mb, ma = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds="strict")
         assert np.array_equal(mb, ob) and np.array_equal(ma, oa), N
+
+
+@pytest.mark.parametrize("N", [300, 1500, 3000, 6000, 20_000])
+def test_bp_short_series_split_into_group_ranges(oracle_lib, N, monkeypatch):
+    """A series of a few tiles (the reference's event relocation beamforms 1 500-3 000 samples over the
+    whole grid, BPMF/dataset.py:2174-2216) is computed by several workgroups per tile, each walking a
+    range of the plan's source groups; reduce="max" folds partial maxima (value, then lowest id),
+    reduce="none" needs no merge.  Automatic and forced split counts, both kernels (interior / edge
+    tiles), strict and flexible, ties between sources of different ranges: all bit-exact."""
+    from seismic_bpmf_amd import BeamformerGPU, synthetic as syn
+    geo = syn.make_bp_geometry((30, 30, 10), 20, 2, 50.0, n_closest=10)
+    tau, ws = geo["moveouts"], geo["weights_sources"]
+    rng = np.random.default_rng(N)
+    f = np.round(np.abs(rng.standard_normal((20, 3, N))) * 2).astype(np.float32)     # exact ties
+    wp = syn.phase_weights(20, 3, 2)
+    want = {oob: oracle_lib.beamform(f, tau, wp, ws, oob, "max") for oob in ("strict", "flexible")}
+    bf = BeamformerGPU(tau, ws)
+    try:
+        assert bf.plan_info()["n_groups"] >= 4
+        for split in (None, "1", "2", "7", "1000"):
+            if split is None:
+                monkeypatch.delenv("BPMF_BP_SPLIT", raising=False)
+            else:
+                monkeypatch.setenv("BPMF_BP_SPLIT", split)
+            for oob in ("strict", "flexible"):
+                mb, ma = bf.run(f, wp, "max", oob)
+                assert np.array_equal(mb.cpu().numpy(), want[oob][0]), (N, split, oob)
+                assert np.array_equal(ma.cpu().numpy(), want[oob][1]), (N, split, oob)
+        if N <= 3000:
+            full = oracle_lib.beamform(f, tau, wp, ws, "strict", "none")
+            for split in (None, "5"):
+                if split is None:
+                    monkeypatch.delenv("BPMF_BP_SPLIT", raising=False)
+                else:
+                    monkeypatch.setenv("BPMF_BP_SPLIT", split)
+                assert np.array_equal(bf.run(f, wp, "none", "strict").cpu().numpy(), full), (N, split)
+    finally:
+        bf.close()
