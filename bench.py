@@ -506,6 +506,22 @@ def main():
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
         if rank == 0:
             bp_obj["detection"] = bp_detection_stage(beam, arg, geo, bcfg)
+        if rank == 0 and world == 1:
+            # untimed extra: the path's second caller, the event relocation (BPMF/dataset.py:2174-2216):
+            # the whole grid over a series of 3 000 samples, full beam volume (reduce="none")
+            n_short = 3000
+            short = feat[:, :, :n_short].contiguous()
+            vol = bf.run(short, wp, "none", "strict")
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                vol = bf.run(short, wp, "none", "strict", out=vol)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            bp_obj["relocation"] = {"workload": f"{K_all} sources x {n_short} samples, reduce=none (the beam volume stays in HBM)",
+                                    "ms": round(min(ts), 3), "output_gb_per_s": round(K_all * n_short * 4 / (min(ts) * 1e-3) / 1e9, 1)}
+            del vol, short
         bf.close()
         if world == 1 and dist is None and not args.skip_e2e:
             h_f, h_wp = feat.cpu().numpy(), wp.cpu().numpy()
