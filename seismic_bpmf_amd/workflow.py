@@ -209,6 +209,34 @@ def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev
     return peaks, src, nodes
 
 
+def relocation_focus(beamformer, features, weights_phases, uncertainty_method="spatial",
+                     out_of_bounds="flexible"):
+    """The beamforming step of the reference's event relocation, ``Event.relocate_beam``
+    (BPMF/dataset.py:2186-2216), on a resident BeamformerGPU: the short feature array of one event
+    (N ~ 1 500-3 000 samples) is backprojected over the whole grid and the point of maximum focusing
+    is found on the device.
+
+    "spatial" (``reduce="none"``): the (K, N) beam volume stays in HBM; returns
+    ``(src_idx, time_idx, beam[:, time_idx])`` -- np.unravel_index(beam.argmax(), beam.shape), i.e.
+    the first maximum in source-major order, and the column the reference turns into its location
+    likelihood (K floats downloaded instead of K*N).  "temporal" (``reduce="max"``): returns
+    ``(src_idx, time_idx, maxbeam)`` with time_idx = maxbeam.argmax() (first maximum) and
+    src_idx = maxbeam_sources[time_idx].  `out_of_bounds` defaults to the reference's "flexible"
+    (:2186)."""
+    import torch
+    if uncertainty_method == "spatial":
+        vol = beamformer.run(features, weights_phases, "none", out_of_bounds)        # (K, N) on the device
+        flat = vol.reshape(-1)
+        first = int(torch.nonzero(flat == flat.max())[0, 0])                         # first maximum, as np.argmax
+        src_idx, time_idx = divmod(first, vol.shape[1])
+        return src_idx, time_idx, vol[:, time_idx].cpu().numpy()
+    if uncertainty_method == "temporal":
+        beam, arg = beamformer.run(features, weights_phases, "max", out_of_bounds)
+        time_idx = int(torch.nonzero(beam == beam.max())[0, 0])
+        return int(arg[time_idx]), time_idx, beam.cpu().numpy()
+    raise ValueError("uncertainty_method should be 'spatial' or 'temporal'")
+
+
 def backprojection_detections(features, moveouts, weights_phases, weights_sources, *, sr,
                               minimum_interevent_time, threshold_window_dur=None, n_dev=15.0,
                               overlap=0.75, threshold=None, out_of_bounds="strict", device=None,

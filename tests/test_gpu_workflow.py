@@ -235,3 +235,30 @@ def test_bp_detections_on_device_edge_cases():
     assert np.isnan(want_thr[-1]) and want_p.size > 3
     peaks, psrc, nodes = beam_detections_device(xd, sd, mpd=50, window=3_000, n_dev=3.0, overlap=0.0)
     assert np.array_equal(peaks, want_p) and np.array_equal(psrc, want_s) and np.isnan(nodes[1][-2])
+
+
+def test_relocation_focus_equals_numpy_on_the_oracle_volume(oracle_lib):
+    """workflow.relocation_focus (beam volume and its arg-max on the device) == the reference's lines
+    on the oracle's volume: np.unravel_index(beam.argmax(), beam.shape) and beam[:, time_idx]
+    (BPMF/dataset.py:2193-2216), with exact ties in the volume; and the "temporal" flavour."""
+    from seismic_bpmf_amd import BeamformerGPU, synthetic as syn
+    from seismic_bpmf_amd.workflow import relocation_focus
+    geo = syn.make_bp_geometry((12, 12, 6), 9, 2, 50.0, n_closest=5)
+    tau, ws = geo["moveouts"], geo["weights_sources"]
+    wp = syn.phase_weights(9, 3, 2)
+    rng = np.random.default_rng(4)
+    bf = BeamformerGPU(tau, ws)
+    try:
+        for n, ties in [(1500, False), (3000, True), (700, True)]:
+            f = np.abs(rng.standard_normal((9, 3, n))).astype(np.float32)
+            if ties:
+                f = np.round(f)                                              # many equal maxima
+            vol = oracle_lib.beamform(f, tau, wp, ws, "flexible", "none")
+            k, t = np.unravel_index(vol.argmax(), vol.shape)
+            src_idx, time_idx, column = relocation_focus(bf, f, wp, "spatial")
+            assert (src_idx, time_idx) == (int(k), int(t)) and np.array_equal(column, vol[:, t]), (n, ties)
+            mb, ma = oracle_lib.beamform(f, tau, wp, ws, "flexible", "max")
+            src_idx, time_idx, maxbeam = relocation_focus(bf, f, wp, "temporal")
+            assert time_idx == int(mb.argmax()) and src_idx == int(ma[time_idx]) and np.array_equal(maxbeam, mb)
+    finally:
+        bf.close()
