@@ -54,10 +54,8 @@ def beamform(waveform_features, time_delays, weights_phases, weights_sources, de
     indices, so ties keep the lowest index exactly like a single pass; an int or a list selects
     devices."""
     del num_threads  # CPU-only knob of the reference; accepted for call compatibility
-    if str(device).lower() not in GPU_DEVICES:
-        raise ValueError(
-            f"device={device!r}: seismic_bpmf_amd only implements the MI355X path "
-            "(device='gpu'); it has no CPU implementation")
+    from .matched_filter import require_gpu_arch
+    require_gpu_arch(device, "device")
     if mode != "direct":
         raise NotImplementedError("only mode='direct' is implemented")
     if reduce not in _REDUCE:

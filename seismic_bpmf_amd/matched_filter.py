@@ -15,12 +15,34 @@ Two levels:
     as device buffers).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
 from . import _lib
 
 GPU_ARCHS = ("gpu", "hip", "mi355x")
+_cpu_arch_notice = [False]
+
+
+def require_gpu_arch(value, keyword):
+    """The reference's call sites default to arch / device = "cpu" (BPMF/similarity_search.py:476, 729;
+    template_search.py:512).  This package has no CPU implementation and never falls back to one:
+    anything but a GPU name raises -- unless the user opted in with BPMF_AMD_ACCEPT_CPU_ARCH=1, which
+    serves such calls ON THE MI355X (one notice on stderr), so that an unedited BPMF run with its
+    default arguments works through the shims."""
+    if str(value).lower() in GPU_ARCHS:
+        return
+    if os.environ.get("BPMF_AMD_ACCEPT_CPU_ARCH", "0") not in ("", "0"):
+        if not _cpu_arch_notice[0]:
+            _cpu_arch_notice[0] = True
+            import sys
+            print(f"seismic_bpmf_amd: {keyword}={value!r} requested, BPMF_AMD_ACCEPT_CPU_ARCH is set: "
+                  "running on the MI355X (this package has no CPU path)", file=sys.stderr)
+        return
+    raise ValueError(
+        f"{keyword}={value!r}: seismic_bpmf_amd only implements the MI355X path ({keyword}='gpu'); "
+        "it has no CPU implementation (set BPMF_AMD_ACCEPT_CPU_ARCH=1 to serve such calls on the GPU)")
 
 FLAG_DATA_PREPARED = 1
 FLAG_FORCE_DIRECT = 2
@@ -100,10 +122,7 @@ def matched_filter(templates, moveouts, weights, data, step, arch="gpu", check_z
     inside the library (``bpmf_mf_run_multi``: one host thread per GPU; templates are independent,
     so no data crosses GPUs); an int or a list selects devices.
     """
-    if str(arch).lower() not in GPU_ARCHS:
-        raise ValueError(
-            f"arch={arch!r}: seismic_bpmf_amd only implements the MI355X path (arch='gpu'); "
-            "it has no CPU implementation")
+    require_gpu_arch(arch, "arch")
     if normalize != "short":
         raise NotImplementedError("only normalize='short' (no window-mean removal) is implemented; "
                                   "it is the only mode the BPMF workflow uses")
