@@ -1468,14 +1468,17 @@ namespace {
 // Group ranges per tile (gridDim.y of the beam kernels).  A workgroup owns a 512-sample tile and one
 // workgroup fills a CU, so a series of fewer than ~128 tiles -- the reference's event relocation
 // beamforms 1 500-3 000 samples over the whole grid (BPMF/dataset.py:2174-2216) -- leaves most of the
-// 256 CUs idle: the groups of the plan are then dealt to 256 / tiles workgroups per tile.
+// 256 CUs idle (and up to ~1000 tiles the last round of workgroups runs half empty): the groups of the
+// plan are then dealt to 1024 / tiles workgroups per tile.
 // BPMF_BP_SPLIT: 0/1 = off, n = force n ranges (tests).  Only the P = 2 packed kernels take it.
 int bp_split_count(const bpmf_bp_plan* pl, size_t N)
 {
     if (!pl || pl->tpt != 2 || !pl->wps || pl->n_groups < 2) return 1;
     if (pl->nsv != 4 && pl->nsv != 8 && pl->nsv != 12 && pl->nsv != 16 && pl->nsv != 32) return 1;   // dispatch_beam<2>'s packed kernels
     const long long n_tiles = (long long)((N + 511) / 512);
-    long long want = n_tiles * 2 > 256 ? 1 : 256 / n_tiles;
+    // enough workgroups for ~4 rounds over the 256 CUs (a split costs one merge pass and nothing else:
+    // the ranges stage disjoint windows), none from 1024 tiles (N >= 524 288) on
+    long long want = n_tiles >= 1024 ? 1 : (1024 + n_tiles - 1) / n_tiles;
     const int forced = env_int("BPMF_BP_SPLIT", -1);   // read per call: the tests switch it
     if (forced >= 0) want = forced < 1 ? 1 : forced;
     return (int)std::max<long long>(1, std::min<long long>(want, pl->n_groups));
