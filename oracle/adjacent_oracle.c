@@ -8,9 +8,13 @@
  * compiled in this container (tests/golden/make_goldens.py, oracle/_ref/libc.so),
  * always single-threaded because the reference's OpenMP loops race.
  *
- * Each function names the reference lines it follows.  The reference binary is built
- * with gcc's default -ffp-contract=fast on an FMA machine, so the places where that
- * build fuses a multiply-add are written as fmaf() here; they are marked "fused".
+ * Each function names the reference lines it follows.  The reference's Makefile compiles
+ * libc.c with -std=c99: in an ISO C mode gcc does NOT contract a*b+c into an FMA (the built
+ * oracle/_ref/libc.so holds no vfmadd instruction at all), so every multiply-add here is a
+ * separate multiply and add, and this file is itself built with -ffp-contract=off.  (Round 1
+ * had assumed fused operations at two places of time_dependent_threshold; the golden vectors
+ * happened not to tell the difference, the live comparison of tests/test_reference_live.py
+ * did: 1-ulp steps on a few windows.)
  */
 #include <math.h>
 #include <stddef.h>
@@ -54,7 +58,10 @@ long tdt_rms_cpu(const float *series, const float *gaussian, float num_dev, size
                  size_t half_window, size_t shift, float *scratch, float *threshold)
 {
     const size_t window = 2 * half_window;
-    if (window == 0 || shift == 0 || shift > window || n < window) return -1;
+    /* the reference computes (n - (window - shift)) / shift in size_t: an odd window with overlap 0
+     * gives shift = window + 1 here (window = 2 * (odd // 2)), the inner difference wraps to -1 and
+     * the count is (n + 1) / shift -- every window still lies inside the series */
+    if (window == 0 || shift == 0 || shift > window + 1 || n < window) return -1;
     const size_t n_win = (n - (window - shift)) / shift;
     if (n_win < 1) return -1;
 
@@ -86,20 +93,20 @@ long tdt_rms_cpu(const float *series, const float *gaussian, float num_dev, size
     }
     dev = sqrtf(dev / (float)n_nonzero);
 
-    /* zeros -> centre + g[i mod 500] * dev  (fused)            libc.c:606-612 */
+    /* zeros -> centre + g[i mod 500] * dev                     libc.c:606-612 */
     for (size_t i = 0; i < n; i++)
         scratch[i] = (series[i] == 0.0f)
-                         ? fmaf(gaussian[i % GAUSSIAN_SAMPLE_LEN], dev, centre)
+                         ? centre + gaussian[i % GAUSSIAN_SAMPLE_LEN] * dev
                          : series[i];
 
     float *win = (float *)malloc(n_win * sizeof(float));
     if (!win) return -1;
-    /* mean + num_dev * std per sliding window  (fused)          libc.c:615-627 */
+    /* mean + num_dev * std per sliding window                   libc.c:615-627 */
     for (size_t q = 0; q < n_win; q++) {
         const float *x = scratch + q * shift;
         float m = window_mean(x, window);
         float s = window_std(x, m, window);
-        win[q] = fmaf(num_dev, s, m);
+        win[q] = m + num_dev * s;
     }
     /* "delay the jump": a drop is postponed by one window, a rise is
      * anticipated by one window (always keep the larger value)  libc.c:631-651 */

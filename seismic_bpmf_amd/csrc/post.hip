@@ -116,7 +116,9 @@ __global__ void tdt_glob_std_kernel(const float* __restrict__ part,
 }
 
 // (5) per (row, sliding window): mean + num_dev * std of the window, with exact zeros replaced
-//     on the fly by centre + g[i mod 500] * dev (fused multiply-add, as the reference binary).
+//     on the fly by centre + g[i mod 500] * dev -- a separate multiply and add, like mean + num_dev * std
+//     below: the reference is compiled with -std=c99, an ISO mode in which gcc contracts nothing (its
+//     binary holds no FMA; round 1 had assumed fused operations here, oracle/adjacent_oracle.c).
 //                                                                            libc.c:606-627
 __global__ void tdt_window_kernel(const float* __restrict__ x, const float* __restrict__ gauss,
                                   const float* __restrict__ centre, const float* __restrict__ dev,
@@ -132,17 +134,17 @@ __global__ void tdt_window_kernel(const float* __restrict__ x, const float* __re
     float acc = 0.0f;
     unsigned g0 = (unsigned)(i0 % GAUSSIAN_LEN);  // gauss index of sample j: (g0 + j) mod 500
     tdt_stream(p, window, [&](float v, size_t j) {
-        if (v == 0.0f) v = __fmaf_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv, c);
+        if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
         acc += v;
     });
     const float mean = acc / (float)window;
     float ss = 0.0f;
     tdt_stream(p, window, [&](float v, size_t j) {
-        if (v == 0.0f) v = __fmaf_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv, c);
+        if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
         double d = (double)(v - mean);
         ss = (float)((double)ss + d * d);
     });
-    thr_win[idx] = __fmaf_rn(num_dev, sqrtf(ss / (float)window), mean);
+    thr_win[idx] = __fadd_rn(mean, __fmul_rn(num_dev, sqrtf(ss / (float)window)));
 }
 
 // (6) per row: "delay the jump" -- a drop is postponed by one window, a rise anticipated by
@@ -256,7 +258,9 @@ static int tdt_sizes(size_t n, size_t half_window, size_t shift, size_t* window,
                      size_t* n_win)
 {
     *window = 2 * half_window;
-    if (*window == 0 || shift == 0 || shift > *window || n < *window) return -1;
+    // (shift == window + 1: an odd sliding window with overlap 0 -- the reference's size_t
+    // arithmetic wraps to (n + 1) / shift windows, all inside the series: libc.c:528)
+    if (*window == 0 || shift == 0 || shift > *window + 1 || n < *window) return -1;
     *n_win = (n - (*window - shift)) / shift;
     *n_glob = n / *window;
     return *n_win >= 1 ? 0 : -1;

@@ -361,7 +361,7 @@ def bp_threshold_nodes(n, window, overlap, median, mad, n_dev):
     (BPMF/template_search.py:1452-1487) from the per-window medians / MADs: `median`, `mad` are
     float32 arrays of n_windows + 2 entries whose entries 1 .. n_windows are filled; the end fills
     are applied here.  Returns (centre float32, threshold float32), both n_windows + 2 long; the
-    threshold at sample t is np.interp(t, centre, threshold) with the end values outside."""
+    threshold at sample t is interp_threshold(t, centre, threshold), the end values outside."""
     shift = int((1.0 - overlap) * window)
     n_windows = int((n - window) // shift) + 1
     med = np.array(median, dtype=np.float32, copy=True)
@@ -377,9 +377,25 @@ def bp_threshold_nodes(n, window, overlap, median, mad, n_dev):
 
 def interp_threshold(samples, centre, nodes):
     """The reference's interp1d(kind="slinear", bounds_error=False, fill_value=(first, last)) at
-    `samples` (float64, like bp_time_dependent_threshold)."""
-    return np.interp(np.asarray(samples, dtype=np.float64), centre.astype(np.float64),
-                     nodes.astype(np.float64), left=nodes[0], right=nodes[-1])
+    `samples`, in float64 and in SciPy's own operation order, so that the threshold is bit-identical
+    to the reference's (checked live against it in tests/test_reference_live.py): an order-1
+    B-spline through the nodes, evaluated by de Boor's recursion -- on [xa, xb) with w = 1 / (xb - xa):
+    ya * (w * (xb - x)) + yb * (w * (x - xa)).  (np.interp's ya + slope * (x - xa) differs from it in
+    the last bit at a third of the samples.)"""
+    x = np.asarray(samples, dtype=np.float64)
+    t = np.asarray(centre, dtype=np.float64)
+    y = np.asarray(nodes, dtype=np.float64)
+    if t.size < 2 or np.any(np.diff(t) <= 0):
+        # duplicate knots (the empty last window of bp_threshold_nodes): SciPy refuses them; keep the
+        # piecewise-linear definition there
+        return np.interp(x, t, y, left=nodes[0], right=nodes[-1])
+    i = np.clip(np.searchsorted(t, x, side="right") - 1, 0, t.size - 2)
+    xa, xb = t[i], t[i + 1]
+    w = 1.0 / (xb - xa)
+    out = 0.0 + y[i] * (w * (xb - x))
+    out = out + y[i + 1] * (w * (x - xa))
+    out = np.where(x < t[0], np.float64(nodes[0]), out)
+    return np.where(x > t[-1], np.float64(nodes[-1]), out)
 
 
 def select_cc_indexes(cc_t, threshold, search_win, *, step, sr, data_duration_sec,

@@ -121,8 +121,7 @@ def bp_time_dependent_threshold_device(beam, window, n_dev, overlap=0.75):
     med[0], mad[0], centre[0] = med[1], mad[1], 0.0
     med[-1], mad[-1], centre[-1] = med[-2], mad[-2], n
     thr = (med + n_dev * mad).cpu().numpy()
-    return np.interp(np.arange(n, dtype=np.float64), centre.astype(np.float64), thr.astype(np.float64),
-                     left=thr[0], right=thr[-1])
+    return pp.interp_threshold(np.arange(n, dtype=np.float64), centre, thr)   # SciPy's operation order
 
 
 def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev=15.0, overlap=0.75,

@@ -69,8 +69,7 @@ def test_bp_threshold_on_device_equals_the_host_mirror():
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bp_threshold.npz"))
     got = bp_time_dependent_threshold_device(torch.as_tensor(g["maxbeam"], device="cuda"), int(g["window"]),
                                              float(g["n_dev"]), overlap=float(g["overlap"]))
-    # the golden comes from scipy's interp1d, which differs from np.interp in operation order only
-    assert np.abs(got - g["thr"]).max() <= 1e-12 * np.abs(g["thr"]).max()
+    assert np.array_equal(got, g["thr"])          # interpolation in SciPy's own operation order: the golden itself
     assert np.array_equal(got, pp.bp_time_dependent_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]),
                                                               float(g["overlap"])))
     rng = np.random.default_rng(8)

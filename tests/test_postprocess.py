@@ -90,13 +90,13 @@ def test_synthetic_generators_are_seeded_and_conditioned():
 
 
 def test_bp_time_dependent_threshold():
-    """Same windows / medians / MADs as the reference; the final linear interpolation differs from
-    scipy's interp1d only in operation order (<= 2e-15 relative), hence the tiny tolerance."""
+    """Same windows / medians / MADs as the reference, and the linear interpolation in SciPy's own
+    operation order (postprocess.interp_threshold): bit-identical to the reference's output."""
     g = load("bp_threshold.npz")
     thr = pp.bp_time_dependent_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]),
                                          float(g["overlap"]))
     assert thr.shape == g["thr"].shape
-    assert np.abs(thr - g["thr"]).max() <= 1e-12 * np.abs(g["thr"]).max()
+    assert thr.dtype == g["thr"].dtype and np.array_equal(thr, g["thr"])
     # and the detections it leads to are identical
     a = pp.find_beam_detections(g["maxbeam"], np.arange(g["maxbeam"].size), thr, 200)[0]
     b = pp.find_beam_detections(g["maxbeam"], np.arange(g["maxbeam"].size), g["thr"], 200)[0]

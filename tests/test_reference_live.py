@@ -1,0 +1,130 @@
+"""CPU, build container only: the host mirrors and the pinned C oracle against the REFERENCE ITSELF,
+imported from /root/reference with stub modules (tests/golden/make_goldens.py:import_reference), on
+seeded random inputs -- wider than the committed golden vectors.  Skipped where /root/reference does
+not exist (the GPU box); nothing here is needed by the product."""
+import importlib.util
+import os
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "BPMF")), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(here, "golden", "make_goldens.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    cwd = os.getcwd()
+    try:
+        BPMF, clib = mg.import_reference()           # chdir()s into a scratch directory: BPMF reads its cfg from the CWD
+    finally:
+        os.chdir(cwd)
+    from BPMF import similarity_search, template_search, utils
+    return types.SimpleNamespace(clib=clib, ss=similarity_search, ts=template_search, utils=utils, mg=mg)
+
+
+def test_live_sec_to_samp_and_detect_peaks(ref):
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(1)
+    for sr in (20.0, 25.0, 50.0, 100.0):
+        t = np.concatenate([rng.uniform(-200, 200, 500), np.round(rng.uniform(-5, 5, 200), 2)])
+        assert np.array_equal(pp.sec_to_samp(t, sr), ref.utils.sec_to_samp(t, sr=sr))
+    for j in range(30):
+        n = int(rng.choice([3, 10, 500, 4000]))
+        x = np.abs(rng.standard_normal(n))
+        if j % 3 == 0:
+            x = np.round(x, 1)                        # plateaus and exact ties (same NumPy sort on the same array)
+        if j % 5 == 0 and n > 20:
+            x[rng.integers(0, n, 3)] = np.nan
+        for mpd in (1, 2, 7, 60, 1000):
+            assert np.array_equal(pp.detect_peaks(x, mpd=mpd), ref.utils._detect_peaks(x.copy(), mpd=mpd)), (j, n, mpd)
+
+
+def test_live_thresholds(ref):
+    from oracle import oracle
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(2)
+    for j in range(8):
+        n = int(rng.choice([20_000, 43_200, 60_001]))
+        window = int(rng.choice([1_000, 3_000, 7_001]))
+        overlap = float(rng.choice([0.5, 0.75, 0.9]))
+        mb = (np.abs(rng.standard_normal(n)) + 6 * (rng.random(n) > 0.998)).astype(np.float32)
+        want = ref.ts.time_dependent_threshold(mb, window, overlap=overlap, CNR_threshold=12.0)
+        assert np.array_equal(pp.bp_time_dependent_threshold(mb, window, 12.0, overlap=overlap), want), (j, n, window, overlap)
+    for j in range(6):
+        n, window = int(rng.choice([30_000, 50_000])), int(rng.choice([2_000, 6_000]))
+        overlap = float(rng.choice([0.25, 0.5, 0.66]))
+        x = ref.mg.cc_like_series(rng, n, gaps=bool(j % 2))
+        wn = rng.standard_normal(int((x == 0).sum())).astype(np.float32)
+        want = ref.ss.time_dependent_threshold(x, window, overlap=overlap, threshold_type="mad", white_noise=wn)
+        assert np.array_equal(pp.time_dependent_threshold_mad(x, window, 8.0, overlap=overlap, white_noise=wn), want), j
+    # the reference's compiled libc.c (num_threads=1: its OpenMP loops race) against the C oracle, at
+    # sizes that keep the reference's own expansion index inside its table
+    done = 0
+    while done < 25:
+        n = int(rng.integers(20_000, 120_000))
+        window = int(rng.integers(1_000, 15_000))
+        overlap = float(rng.choice([0.0, 0.2, 0.25, 0.5]))
+        shift = int((1.0 - overlap) * window)
+        nsw = (n - (window - shift)) // shift
+        if nsw < 2 or (n - shift - 1) // shift > nsw - 1:      # (odd windows with overlap 0 -- shift = 2 (window // 2) + 1 -- included)
+            continue
+        x = ref.mg.cc_like_series(rng, n, gaps=bool(done % 2))
+        wn = rng.standard_normal(500).astype(np.float32)
+        want = ref.clib.time_dependent_threshold(x, window, 8.0, overlap=overlap, white_noise=wn, num_threads=1)
+        assert np.array_equal(oracle.time_dependent_threshold(x, window, 8.0, overlap, wn), want), (n, window, overlap)
+        done += 1
+
+
+def test_live_select_cc_indexes(ref):
+    from oracle import oracle
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(3)
+
+    class _Data:
+        sr = 25.0
+        duration = 1500.0
+    for j in range(10):
+        n = int(rng.choice([20_000, 60_000]))
+        win = int(rng.choice([1, 30, 250, 2_000]))
+        step = int(rng.choice([1, 1, 2]))
+        remove_edges = bool(j % 2)
+        acdf = float(rng.choice([0.0, 0.5]))
+        fake = MagicMock()
+        fake.data, fake.step, fake.threshold_type, fake.remove_edges = _Data(), step, "rms", remove_edges
+        x = ref.mg.cc_like_series(rng, n, gaps=False)
+        thr = (0.12 + 0.05 * rng.random() + 0.0 * x).astype(np.float32)
+        want = ref.ss.MatchedFilter.select_cc_indexes(fake, x, thr, win, anomalous_cdf_at_mean_plus_1sig=acdf)
+        got = pp.select_cc_indexes(x, thr, win, step=step, sr=25.0, data_duration_sec=1500.0, n_dev_threshold=8.0,
+                                   min_freq_hz=2.0, data_buffer_sec=500.0, remove_edges=remove_edges,
+                                   anomalous_cdf_at_mean_plus_1sig=acdf)
+        assert np.array_equal(np.asarray(got, dtype=np.int64), np.asarray(want, dtype=np.int64)), (j, n, win, step)
+        sel = ref.clib.select_cc_indexes(x, thr, win)
+        assert np.array_equal(oracle.select_cc_indexes(x, thr, win), np.asarray(sel)), (j, "C variant")
+
+
+def test_live_kurtosis_and_grid_decimation(ref):
+    from oracle import oracle
+    rng = np.random.default_rng(4)
+    for W in (1, 4, 50, 333):
+        sig = (rng.standard_normal((2, 2, 1500)) * np.array([1.0, 1e-3])[None, :, None]).astype(np.float32)
+        sig[0, 0, 300:700] = 0.0
+        assert np.array_equal(oracle.kurtosis(sig, W), ref.clib.kurtosis(sig, W), equal_nan=True), W
+    for j in range(4):
+        K, S = int(rng.choice([60, 300, 700])), int(rng.integers(3, 10))
+        lon, lat = rng.uniform(0, 1, K).astype(np.float32), rng.uniform(0, 1, K).astype(np.float32)
+        sta = rng.uniform(0, 1, (S, 2))
+        mv = np.round(np.hypot(lon[:, None] - sta[None, :, 0], lat[:, None] - sta[None, :, 1]) * 20, 1).astype(np.float32)
+        cl = np.linspace(-0.01, 1.01, int(rng.integers(2, 5))).astype(np.float32)
+        nd, thr = int(rng.integers(1, S + 1)), float(rng.choice([0.1, 0.4, 2.0]))
+        for method in ("closest", "smallest"):
+            want = ref.clib.find_similar_sources(mv, lon, lat, cl, cl, thr, num_threads=1,
+                                                 num_stations_for_diff=nd, method=method)
+            got = oracle.find_similar_sources(mv, lon, lat, cl, cl, thr, nd, method)
+            assert np.array_equal(np.asarray(got, bool), np.asarray(want, bool)), (j, method, K, S, nd, thr)
