@@ -20,13 +20,20 @@ def ref():
     spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(here, "golden", "make_goldens.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-    cwd = os.getcwd()
+    import sys
+    cwd, path0, mods0 = os.getcwd(), list(sys.path), set(sys.modules)
     try:
         BPMF, clib = mg.import_reference()           # chdir()s into a scratch directory: BPMF reads its cfg from the CWD
     finally:
         os.chdir(cwd)
     from BPMF import similarity_search, template_search, utils
-    return types.SimpleNamespace(clib=clib, ss=similarity_search, ts=template_search, utils=utils, mg=mg)
+    yield types.SimpleNamespace(clib=clib, ss=similarity_search, ts=template_search, utils=utils, mg=mg)
+    # leave no trace for the other test modules: the stub modules (fast_matched_filter, beampower, obspy ...)
+    # and the reference's path entry go away again
+    for name in set(sys.modules) - mods0:
+        if isinstance(sys.modules[name], MagicMock) or name == "BPMF" or name.startswith("BPMF."):
+            del sys.modules[name]
+    sys.path[:] = path0
 
 
 def test_live_sec_to_samp_and_detect_peaks(ref):
