@@ -135,3 +135,105 @@ def test_live_kurtosis_and_grid_decimation(ref):
                                                  num_stations_for_diff=nd, method=method)
             got = oracle.find_similar_sources(mv, lon, lat, cl, cl, thr, nd, method)
             assert np.array_equal(np.asarray(got, bool), np.asarray(want, bool)), (j, method, K, S, nd, thr)
+
+
+def test_live_source_weight_builders(ref):
+    """Beamformer.set_weights_sources and its builders (BPMF/template_search.py:779-895) through a fake
+    `self` carrying only the attributes they read, on random moveout tables with ties at the cut-off
+    and random offline stations, against postprocess.set_weights_sources."""
+    import pandas as pd
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(5)
+
+    class _BF:
+        pass
+    for name in ("_weights_sources_closest", "_weights_sources_max_moveout", "set_weights_sources",
+                 "_station_density_weights"):
+        setattr(_BF, name, getattr(ref.ts.Beamformer, name))
+    for j in range(30):
+        K, S, P = int(rng.integers(1, 200)), int(rng.integers(2, 14)), 2
+        names = [f"S{i:02d}" for i in range(S)]
+        mv = rng.integers(0, int(rng.choice([5, 60, 900])), (K, S, P)).astype(np.int64)     # small ranges: many ties
+        mv[:, :, 1] += mv[:, :, 0] // 2
+        mv -= mv.reshape(K, -1).min(axis=1)[:, None, None]
+        online = rng.random(S) > 0.25
+        if not online.any():
+            online[0] = True
+        with_avail = bool(j % 2)
+        xy = rng.uniform(0.0, 80.0, (S, 2))
+        dist = pd.DataFrame(np.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)), index=names, columns=names)
+        bf = _BF()
+        bf.n_sources, bf.n_stations, bf.stations, bf.moveouts = K, S, names, mv
+        bf.network = types.SimpleNamespace(n_stations=S, stations=names, interstation_distances=dist)
+        bf.data = types.SimpleNamespace(set_availability=lambda stations: None)
+        if with_avail:
+            bf.data.availability = True
+            bf.data.availability_per_sta = pd.Series(online, index=names)
+        kw = dict(normalize=bool(rng.random() < 0.5), n_min_stations=int(rng.choice([0, 0, 2, 5])))
+        if rng.random() < 0.6:
+            kw.update(method="closest_stations", num_closest_stations=int(rng.integers(0, S + 3)))
+        else:
+            kw.update(method="max_moveout", max_moveout=float(rng.choice([3.0, 40.0, 500.0])))
+        density = bool(rng.random() < 0.3)
+        dens = None
+        if density:
+            kw["weight_station_density"] = True
+            dens = pp.station_density_weights(dist.values)
+        bf.set_weights_sources(**kw)
+        kw.pop("weight_station_density", None)
+        got = pp.set_weights_sources(mv, online=online if with_avail else None, density_weights=dens, **kw)
+        want = np.asarray(bf.weights_sources)
+        assert got.shape == want.shape and np.array_equal(got, want.astype(got.dtype)), (j, K, S, kw, with_avail, density)
+
+
+def test_live_channel_weight_builders(ref):
+    """MatchedFilter.set_weights_channels and its builders (BPMF/similarity_search.py:288-474) through a
+    fake `self`, on random template sets with missing channels, dead templates and moveout ties,
+    against postprocess.set_weights_channels."""
+    import pandas as pd
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(6)
+
+    class _MF:
+        pass
+    for name in ("_weights_channels_simple", "_weights_channels_closest", "_weights_channels_max_moveout",
+                 "set_weights_channels", "_station_density_weights"):
+        setattr(_MF, name, getattr(ref.ss.MatchedFilter, name))
+    for j in range(30):
+        T, S, C = int(rng.integers(1, 25)), int(rng.integers(2, 10)), 3
+        names = [f"N{i:02d}" for i in range(S)]
+        wav = rng.standard_normal((T, S, C, 16)).astype(np.float32)
+        wav[rng.random((T, S, C)) < 0.3] = 0.0
+        if T > 2:
+            wav[1] = 0.0
+        n2t = ~(np.sum(wav, axis=-1) == 0.0)
+        avail = n2t.copy()
+        mv = rng.integers(0, int(rng.choice([4, 50, 700])), (T, S, 2)).astype(np.int32)
+        min_ch, min_st = int(rng.integers(1, 8)), int(rng.integers(1, 4))
+        xy = rng.uniform(0.0, 80.0, (S, 2))
+        dist = pd.DataFrame(np.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)), index=names, columns=names)
+        mf = _MF()
+        mf.min_channels, mf.min_stations = min_ch, min_st
+        mf.template_group = types.SimpleNamespace(network_to_template_map=n2t, n_templates=T, availability_arr=avail,
+                                                  stations=names, moveouts_arr=mv.copy(),
+                                                  templates=[types.SimpleNamespace(sr=25.0)])
+        mf.network = types.SimpleNamespace(n_stations=S, n_components=C, stations=names, interstation_distances=dist)
+        mf.data = types.SimpleNamespace()
+        r = rng.random()
+        if r < 0.35:
+            kw = dict(method="simple")
+        elif r < 0.7:
+            kw = dict(method="closest_stations", num_closest_stations=int(rng.integers(1, S + 3)))
+        else:
+            kw = dict(method="max_moveout", max_moveout_sec=float(rng.choice([0.1, 2.0, 30.0])))
+        kw.update(normalize=bool(rng.random() < 0.6), n_min_stations=int(rng.choice([0, 0, 3])))
+        dens = None
+        if rng.random() < 0.3:
+            kw["weight_station_density"] = True
+            dens = pp.station_density_weights(dist.values)
+        mf.set_weights_channels(**kw)
+        kw.pop("weight_station_density", None)
+        got = pp.set_weights_channels(density_weights=dens, present=pp.network_to_template_map(wav), moveouts=mv,
+                                      availability=avail, sr=25.0, min_channels=min_ch, min_stations=min_st, **kw)
+        want = np.asarray(mf.weights_channels)
+        assert got.shape == want.shape and np.array_equal(got, want.astype(got.dtype)), (j, T, S, kw)
