@@ -42,10 +42,27 @@ def merge_candidates(index, cc, search_win):
     return np.asarray(idx, dtype=np.int64)
 
 
+def row_excess_kurtosis(cc, rows_per_pass=8):
+    """scipy.stats.kurtosis (Fisher, biased: m4 / m2**2 - 3) of every row of a (T, n) device tensor, in
+    float64, a few rows at a time (a cfg2 CC matrix is 17 GB: no full-size temporaries).  Returns a
+    NumPy array; NaN for a constant row, like SciPy."""
+    import torch
+    out = []
+    for r0 in range(0, cc.shape[0], rows_per_pass):
+        x = cc[r0:r0 + rows_per_pass].to(torch.float64)
+        d = x - x.mean(dim=1, keepdim=True)
+        d2 = d * d
+        m2 = d2.mean(dim=1)
+        m4 = (d2 * d2).mean(dim=1)
+        out.append((m4 / (m2 * m2) - 3.0).cpu().numpy())
+    return np.concatenate(out) if out else np.zeros(0)
+
+
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                               threshold_window_dur, minimum_interevent_time, n_dev=8.0,
                               overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
-                              remove_edges=True, data_buffer_sec=None, data_duration_sec=None):
+                              remove_edges=True, data_buffer_sec=None, data_duration_sec=None,
+                              sanity_check=True, max_kurto=100.0):
     """Matched-filter search of one day: returns ({template: cc indices}, cc device tensor).
 
     `remove_edges` (the reference's default, BPMF/similarity_search.py:274-285) drops detections
@@ -53,7 +70,10 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     `data_duration_sec + data_buffer_sec`; it needs both durations and is skipped when
     `data_buffer_sec` is None (a day loaded without margins).  The optional anomalous-CDF
     validation of :253-272 is available through postprocess.select_cc_indexes on a downloaded
-    row; it is off in this device pipeline."""
+    row; it is off in this device pipeline.  `sanity_check` (the reference's default, :633-642): a
+    template whose CC series has an excess kurtosis above `max_kurto` -- most of the day missing --
+    yields no detection (the reference zeroes its CCs before the peak selection); the kurtosis is
+    scipy.stats.kurtosis' definition, evaluated on the device in float64."""
     weights = np.asarray(weights, dtype=np.float32)
     mf = MatchedFilterGPU(device=device)
     mf.set_data(data)
@@ -67,8 +87,12 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     cand = th.extract_candidates(cc, thr_win, window, overlap=overlap, row_cap=cap)
     min_iet = int(pp.sec_to_samp(minimum_interevent_time, sr))
     mv = np.asarray(moveouts)
+    rejected = row_excess_kurtosis(cc) > max_kurto if sanity_check else np.zeros(weights.shape[0], bool)
     out = {}
     for t in range(weights.shape[0]):
+        if rejected[t]:
+            out[t] = np.zeros(0, dtype=np.int64)
+            continue
         mine = cand[cand["row"] == t]
         win = search_window(mv[t].reshape(mv.shape[1], -1), min_iet, step)
         idx = merge_candidates(mine["index"], mine["cc"], win)

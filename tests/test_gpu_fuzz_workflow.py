@@ -119,6 +119,7 @@ def test_fuzz_workflow_matched_filter_detections(oracle_lib, seed):
     """workflow.matched_filter_detections (CC, RMS threshold, candidate compaction on the device, merge
     on the host) == the same chain from CPU pieces: oracle CC, oracle threshold (pinned to the
     reference's libc.c), postprocess.select_cc_indexes (pinned to the reference's Python)."""
+    from scipy.stats import kurtosis
     from seismic_bpmf_amd import postprocess as pp, synthetic as syn, workflow
     rng = np.random.default_rng(34_000 + seed)
     T, S, C = int(rng.integers(1, 5)), int(rng.integers(2, 6)), int(rng.integers(1, 4))
@@ -149,4 +150,6 @@ def test_fuzz_workflow_matched_filter_detections(oracle_lib, seed):
         want = pp.select_cc_indexes(cc_ref[t], thr, win, step=step, sr=sr, data_duration_sec=1e9,
                                     n_dev_threshold=n_dev, min_freq_hz=2.0, data_buffer_sec=0.0,
                                     remove_edges=False, anomalous_cdf_at_mean_plus_1sig=0.0)
+        if kurtosis(cc_ref[t].astype(np.float64)) > 100.0:        # the reference's sanity check (:633-642)
+            want = np.zeros(0, dtype=np.int64)
         assert np.array_equal(got[t], want), f"seed {seed} template {t}: T={T} S={S} C={C} L={L} N={N} step={step}"

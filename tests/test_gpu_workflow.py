@@ -261,3 +261,29 @@ def test_relocation_focus_equals_numpy_on_the_oracle_volume(oracle_lib):
             assert time_idx == int(mb.argmax()) and src_idx == int(ma[time_idx]) and np.array_equal(maxbeam, mb)
     finally:
         bf.close()
+
+
+def test_matched_filter_detections_sanity_check_rejects_gappy_days(oracle_lib):
+    """The reference's sanity check (BPMF/similarity_search.py:633-642, on by default): a template whose
+    CC series has an excess kurtosis above max_kurto yields no detection.  Decisions equal
+    scipy.stats.kurtosis on the oracle's CC rows; a day that is mostly a gap is rejected, a full day
+    is not."""
+    from scipy.stats import kurtosis
+    from seismic_bpmf_amd import synthetic as syn, workflow
+    m = syn.make_mf_inputs(T=3, S=4, C=3, L=64, N=60_000, seed=5, max_moveout=200, n_events=4)
+    kw = dict(step=1, sr=100.0, threshold_window_dur=50.0, minimum_interevent_time=2.0, remove_edges=False,
+              white_noise=np.random.default_rng(0).standard_normal(500).astype(np.float32))
+    full, cc = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], m["data"], **kw)
+    cc_ref = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1)
+    k = workflow.row_excess_kurtosis(cc)
+    assert np.allclose(k, kurtosis(cc_ref.astype(np.float64), axis=1), rtol=1e-9) and (k < 100).all()
+    assert all(len(full[t]) >= 1 for t in range(3))
+    gappy = m["data"].copy()
+    gappy[:, :, 1_500:] = 0.0                                   # 97 % of the day missing: CC exactly 0 there
+    cc_g = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], gappy, 1)
+    want_reject = kurtosis(cc_g.astype(np.float64), axis=1) > 100.0
+    assert want_reject.any()
+    on, _ = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], gappy, **kw)
+    off, _ = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], gappy, sanity_check=False, **kw)
+    for t in range(3):
+        assert (len(on[t]) == 0) if want_reject[t] else np.array_equal(on[t], off[t])
