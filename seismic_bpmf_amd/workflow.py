@@ -175,8 +175,11 @@ def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev
         # series is a whole number of non-overlapping windows) makes the interpolated threshold
         # NaN around it, where the reference then keeps no peak (`>` is false); the floor is the
         # smallest finite node
+        # smallest finite node -- less one float32 ulp: the interpolation (SciPy's order of operations,
+        # pp.interp_threshold) can land an ulp of float64 below two equal nodes, and a peak exactly as high
+        # as the node would then pass the reference's `>` but not the floor
         finite = thr[np.isfinite(thr)]
-        floor = float(finite.astype(np.float64).min()) if finite.size else float("nan")
+        floor = float(np.nextafter(np.float32(finite.min()), np.float32(-np.inf))) if finite.size else float("nan")
 
         def threshold_at(samples):
             return pp.interp_threshold(samples, centre, thr)

@@ -261,7 +261,7 @@ def test_candidate_based_beam_detections_equal_the_full_series_logic():
         full_thr = pp.bp_time_dependent_threshold(x, window, n_dev, overlap)
         assert np.array_equal(pp.interp_threshold(np.arange(n), centre, nodes), full_thr)
         want, _ = pp.find_beam_detections(x, np.zeros(n, np.int32), full_thr, mpd)
-        idx, h = local_maxima_above(x, float(nodes.astype(np.float64).min()))
+        idx, h = local_maxima_above(x, float(np.nextafter(np.float32(nodes.min()), np.float32(-np.inf))))
         got = pp.find_beam_detections_from_candidates(idx, h, lambda s: pp.interp_threshold(s, centre, nodes), mpd, n,
                                                       lambda i0, i1: x[i0:i1])
         assert np.array_equal(got, want) and want.size >= 5 and idx.size < n // 4
