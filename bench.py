@@ -156,10 +156,54 @@ def bp_detection_stage(beam, arg, geo, bcfg):
 
 
 # ----------------------------------------------------------------------- CPU baseline ---
+def host_cpu_facts():
+    """What this process may really use: logical CPUs, the affinity mask, the cgroup CPU quota."""
+    facts = {"logical_cpus": os.cpu_count() or 1}
+    try:
+        facts["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        facts["affinity_cpus"] = facts["logical_cpus"]
+    quota = None
+    try:                                                 # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+        facts["cgroup_cpu_max"] = f"{q} {per}"
+    except Exception:
+        try:                                             # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+            facts["cgroup_cpu_max"] = f"{q:g} {per:g}"
+        except Exception:
+            facts["cgroup_cpu_max"] = "unreadable"
+    facts["cgroup_quota_cpus"] = quota
+    usable = facts["affinity_cpus"]
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    facts["usable_cpus"] = usable
+    try:
+        facts["smt_active"] = open("/sys/devices/system/cpu/smt/active").read().strip() == "1"
+    except Exception:
+        facts["smt_active"] = None
+    try:
+        facts["loadavg_1min"] = float(open("/proc/loadavg").read().split()[0])
+    except Exception:
+        pass
+    try:
+        with open("/proc/cpuinfo") as f:
+            facts["cpu_model"] = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
+    except Exception:
+        facts["cpu_model"] = "unknown"
+    return facts
+
+
 def cpu_baseline(cfg, target_seconds):
     """Time the CPU oracle (rebuilt -march=native for this host) on (1) a bounded sample of the
-    headline workload's shape -- `value` -- and (2) BASELINE configs[0], the reference's own
-    CPU-runnable case, in full, on all threads and on one thread."""
+    headline workload's shape -- `value` --, (2) a smaller sample of the same shape on ONE thread and
+    on all threads (`scaling`: what the stated core count is worth), and (3) BASELINE configs[0], the
+    reference's own CPU-runnable case, in full, both ways, each repeated for >= 1 s of work
+    (SURVEY.md s8d).  `cores` is the number of threads used = the CPUs this process may run on
+    (affinity mask and cgroup quota applied), not os.cpu_count()."""
     from oracle import oracle
     from seismic_bpmf_amd import synthetic as syn
     try:
@@ -168,7 +212,8 @@ def cpu_baseline(cfg, target_seconds):
     except Exception:
         lib = oracle.load()
         march = "x86-64-v3"
-    cores = lib.bpmf_oracle_max_threads()
+    facts = host_cpu_facts()
+    cores = max(1, min(lib.bpmf_oracle_max_threads(), facts["usable_cpus"]))
     S, C, L = cfg["S"], cfg["C"], cfg["L"]
 
     def run(inp, nth):
@@ -177,56 +222,63 @@ def cpu_baseline(cfg, target_seconds):
                               num_threads=nth, lib=lib)
         return time.perf_counter() - t0
 
-    # calibrate on 8 x 480 000 samples (a smaller probe is dominated by thread start-up on a
-    # 128-core host), then size N (whole seconds of the same day) for ~target seconds
+    def repeat(inp, nth, seconds, max_runs=200):          # mean wall time over >= `seconds` of work
+        run(inp, nth)                                      # warm: thread pool, page cache
+        total, n = 0.0, 0
+        while total < seconds and n < max_runs:
+            total += run(inp, nth)
+            n += 1
+        return total / n, n
+
     T = min(cfg["T"], 8)
-    probe = syn.make_mf_inputs(T, S, C, L, 480_000, seed=9, n_events=0)
-    run(probe, cores)                                   # warm the thread pool / page in
-    rate = T * (480_000 - L + 1) / run(probe, cores)
+    # (2) scaling sample: sized so that one thread needs ~3 s
+    probe = syn.make_mf_inputs(T, S, C, L, 60_000, seed=9, n_events=0)
+    run(probe, 1)
+    rate1 = T * (60_000 - L + 1) / run(probe, 1)
+    n_s = int(min(cfg["N"], max(60_000, rate1 * 3.0 / T)))
+    n_s -= n_s % 1000
+    smp_s = syn.make_mf_inputs(T, S, C, L, n_s, seed=7, n_events=0)
+    d1, r1 = repeat(smp_s, 1, 2.5, max_runs=4)
+    dall, rall = repeat(smp_s, cores, 1.0)
+    speedup = d1 / dall
+    scaling = {"sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n_s}",
+               "seconds_1_thread": round(d1, 4), "runs_1_thread": r1,
+               f"seconds_{cores}_threads": round(dall, 5), f"runs_{cores}_threads": rall,
+               "value_1_thread": round(T * (n_s - L + 1) / d1 / 1e6, 4),
+               f"value_{cores}_threads": round(T * (n_s - L + 1) / dall / 1e6, 4),
+               "speedup": round(speedup, 2), "speedup_per_thread": round(speedup / cores, 3),
+               "gflops_1_thread": round(2.0 * L * S * C * T * (n_s - L + 1) / d1 / 1e9, 1)}
+    # (1) headline sample: whole seconds of the same day for ~target seconds on all threads
+    rate = T * (n_s - L + 1) / dall
     n = int(min(cfg["N"], max(120_000, rate * target_seconds / T)))
     n -= n % 1000
     smp = syn.make_mf_inputs(T, S, C, L, n, seed=8, n_events=0)
-    # all hardware threads, and one per physical core when SMT is on (FMA-bound code usually
-    # prefers the latter); the better of the two is the baseline
-    trials = [cores]
-    try:
-        if open("/sys/devices/system/cpu/smt/active").read().strip() == "1" and cores >= 4:
-            trials.append(cores // 2)
-    except Exception:
-        pass
-    value, dt, used = 0.0, 0.0, cores
-    for nth in trials:
-        d = run(smp, nth)
-        v = T * (n - L + 1) / d / 1e6
-        if v > value:
-            value, dt, used = v, d, nth
-    # BASELINE configs[0] in full: 4 templates x 8 stations x 3 comp, L = 128, 1 h @ 50 Hz
+    run(smp, cores)
+    dt = run(smp, cores)
+    import ctypes
+    ph = (ctypes.c_double * 4)()
+    lib.bpmf_oracle_last_phase_seconds(ph)
+    value = T * (n - L + 1) / dt / 1e6
+    # (3) BASELINE configs[0] in full: 4 templates x 8 stations x 3 comp, L = 128, 1 h @ 50 Hz
     c0 = syn.MF_CONFIGS["cfg1"]
     inp0 = syn.make_mf_inputs(c0["T"], c0["S"], c0["C"], c0["L"], c0["N"], seed=20260929)
     n0 = c0["T"] * (c0["N"] - c0["L"] + 1)
-    run(inp0, used)
-    d_all = min(run(inp0, used) for _ in range(3))
-    n_one, d_one_total = 0, 0.0                         # one thread: repeat until >= 2.5 s of work
-    while d_one_total < 2.5 and n_one < 64:
-        d_one_total += run(inp0, 1)
-        n_one += 1
-    d_one = d_one_total / n_one
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            model = next(ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name"))
-    except Exception:
-        pass
-    return {"value": round(value, 4), "unit": "M CC-samples/s", "cores": used,
-            "kind": "port", "cpu_model": model,
+    d_all, n_all = repeat(inp0, cores, 1.0)
+    d_one, n_one = repeat(inp0, 1, 2.0, max_runs=64)
+    return {"value": round(value, 4), "unit": "M CC-samples/s", "cores": cores,
+            "kind": "port", "cpu_model": facts["cpu_model"], "host": facts,
             "sample": f"{T} templates x {S} stations x {C} comp, L={L}, N={n} samples of the "
                       f"{cfg['N']}-sample day, step 1; oracle/bpmf_oracle.c mf_cpu (C99+OpenMP, "
-                      f"gcc -O3 -march={march}), {dt:.1f} s wall on {used} threads",
+                      f"gcc -O3 -march={march}), {dt:.1f} s wall on {cores} threads "
+                      f"(preparation {ph[0]:.2f} s, correlation loop {ph[1]:.2f} s)",
+            "gflops": round(2.0 * L * S * C * value * 1e6 / 1e9, 1),
+            "scaling": scaling,
             "configs0": {"workload": "BASELINE configs[0] in full: 4 templates x 8 stations x 3 comp, L=128, "
                                      "N=180000 (1 h @ 50 Hz), step 1",
-                         "value": round(n0 / d_all / 1e6, 4), "cores": used, "seconds": round(d_all, 4),
-                         "value_1_thread": round(n0 / d_one / 1e6, 5), "seconds_1_thread": round(d_one, 3),
-                         "repeats_1_thread": n_one,
+                         "value": round(n0 / d_all / 1e6, 4), "cores": cores, "seconds": round(d_all, 5),
+                         "repeats": n_all,
+                         "value_1_thread": round(n0 / d_one / 1e6, 5), "seconds_1_thread": round(d_one, 4),
+                         "repeats_1_thread": n_one, "speedup": round(d_one / d_all, 2),
                          "unit": "M CC-samples/s"}}
 
 
@@ -238,7 +290,7 @@ def cpu_baseline_bp(bcfg, geo, target_seconds):
         lib = oracle.load(oracle.build(march="native", out_dir="/tmp/bpmf_oracle_native"))
     except Exception:
         lib = oracle.load()
-    cores = os.cpu_count() or 1   # explicit: the 1-thread MF figure left OpenMP at one thread
+    cores = host_cpu_facts()["usable_cpus"]   # explicit: the 1-thread MF figure left OpenMP at one thread
     S, C, P = bcfg["S"], bcfg["C"], bcfg["P"]
     K = min(geo["moveouts"].shape[0], 2000)
     mv, ws = geo["moveouts"][:K], geo["weights_sources"][:K]

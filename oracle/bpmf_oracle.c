@@ -27,6 +27,7 @@
  * file must be compiled with -ffp-contract=off so that the association order
  * below is the one executed.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -39,6 +40,22 @@
 #define BPMF_CSUM_CHUNK 1024          /* hierarchical prefix-sum chunk (spec constant) */
 #define BPMF_MAX_NORM 1000.0f /* 1/sqrt(E_t*E_d) >= this (E_t*E_d <~ 1e-6) -> CC = 0, no Inf/NaN */
 #define LAGV 16                        /* lags evaluated side by side (vector lanes)     */
+#define LAGB 64                        /* lags per work item: 4 independent vectors of LAGV */
+
+#include <time.h>
+static double now_seconds(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+/* wall time of the last mf_cpu call: [0] preparation (energies, prefix sums, norms, allocation),
+ * [1] the correlation loop -- read by tools/probe_cpu.py and bench.py's cpu_baseline */
+static double g_phase_seconds[4];
+void bpmf_oracle_last_phase_seconds(double *out4)
+{
+    for (int i = 0; i < 4; i++) out4[i] = g_phase_seconds[i];
+}
 
 static void set_threads(int num_threads)
 {
@@ -84,22 +101,49 @@ void mf_template_energy(const float *templates, size_t n_channels_total, size_t 
  * double. */
 void mf_data_csum(const float *data, size_t n_channels, size_t N, double *csum)
 {
-#pragma omp parallel for schedule(static)
+    /* three passes, so that every thread has work whatever the channel count (the definition is
+     * hierarchical precisely so that it can be evaluated this way): chunk totals, the sequential
+     * scan of the totals per channel, then the chunk-local sums plus their offset */
+    const size_t n_chunks = (N + BPMF_CSUM_CHUNK - 1) / BPMF_CSUM_CHUNK;
+    double *off = (double *)malloc((n_channels * n_chunks + 1) * sizeof(double));
+    if (!off) return;
+#pragma omp parallel for collapse(2) schedule(static)
     for (size_t ch = 0; ch < n_channels; ch++) {
-        const float *d = data + ch * N;
-        double *cs = csum + ch * (N + 1);
-        double off = 0.0;
-        cs[0] = 0.0;
-        for (size_t q0 = 0; q0 < N; q0 += BPMF_CSUM_CHUNK) {
-            size_t q1 = q0 + BPMF_CSUM_CHUNK < N ? q0 + BPMF_CSUM_CHUNK : N;
+        for (size_t q = 0; q < n_chunks; q++) {
+            const float *d = data + ch * N;
+            const size_t q0 = q * BPMF_CSUM_CHUNK;
+            const size_t q1 = q0 + BPMF_CSUM_CHUNK < N ? q0 + BPMF_CSUM_CHUNK : N;
             double local = 0.0;
-            for (size_t n = q0; n < q1; n++) {
-                local += (double)d[n] * (double)d[n];
-                cs[n + 1] = off + local;
-            }
-            off += local;
+            for (size_t n = q0; n < q1; n++) local += (double)d[n] * (double)d[n];
+            off[ch * n_chunks + q] = local;
         }
     }
+#pragma omp parallel for schedule(static)
+    for (size_t ch = 0; ch < n_channels; ch++) {
+        double acc = 0.0;                         /* off[q] = sum of the totals of chunks 0..q-1 */
+        for (size_t q = 0; q < n_chunks; q++) {
+            const double tot = off[ch * n_chunks + q];
+            off[ch * n_chunks + q] = acc;
+            acc += tot;
+        }
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (size_t ch = 0; ch < n_channels; ch++) {
+        for (size_t q = 0; q < n_chunks; q++) {
+            const float *d = data + ch * N;
+            double *cs = csum + ch * (N + 1);
+            const size_t q0 = q * BPMF_CSUM_CHUNK;
+            const size_t q1 = q0 + BPMF_CSUM_CHUNK < N ? q0 + BPMF_CSUM_CHUNK : N;
+            const double o = off[ch * n_chunks + q];
+            double local = 0.0;
+            if (q == 0) cs[0] = 0.0;
+            for (size_t n = q0; n < q1; n++) {
+                local += (double)d[n] * (double)d[n];
+                cs[n + 1] = o + local;
+            }
+        }
+    }
+    free(off);
 }
 
 /* E_d[ch, j] = (float)(csum[j+L] - csum[j]),  j in [0, N-L]. */
@@ -107,12 +151,16 @@ void mf_window_energy(const double *csum, size_t n_channels, size_t N, size_t L,
                       float *energy)
 {
     if (N < L) return;
-    size_t nwin = N - L + 1;
-#pragma omp parallel for schedule(static)
+    const size_t nwin = N - L + 1;
+    const size_t blk = 65536, n_blk = (nwin + blk - 1) / blk;
+#pragma omp parallel for collapse(2) schedule(static)
     for (size_t ch = 0; ch < n_channels; ch++) {
-        const double *cs = csum + ch * (N + 1);
-        float *e = energy + ch * nwin;
-        for (size_t j = 0; j < nwin; j++) e[j] = (float)(cs[j + L] - cs[j]);
+        for (size_t b = 0; b < n_blk; b++) {
+            const double *cs = csum + ch * (N + 1);
+            float *e = energy + ch * nwin;
+            const size_t j1 = (b + 1) * blk < nwin ? (b + 1) * blk : nwin;
+            for (size_t j = b * blk; j < j1; j++) e[j] = (float)(cs[j + L] - cs[j]);
+        }
     }
 }
 
@@ -174,6 +222,7 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
 {
     if (step == 0 || L == 0 || N < L) return -1;
     set_threads(num_threads);
+    const double t_start = now_seconds();
     const size_t n_ch = S * C;
     const size_t nwin = N - L + 1;
     float *e_t = (float *)malloc(T * n_ch * sizeof(float));
@@ -192,68 +241,93 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
 
     const size_t out_per_t = network_sum ? n_corr : n_corr * n_ch;
     memset(out, 0, T * out_per_t * sizeof(float));
+    const double t_prep = now_seconds();
 
-    const size_t n_blocks = (n_corr + LAGV - 1) / LAGV;
-#pragma omp parallel for collapse(2) schedule(dynamic, 64)
+    /* Work items = (template, block of LAGB lags inside the template's valid range), dealt to the
+     * threads in equal contiguous shares (static): every item costs the same, and a thread walks
+     * consecutive lags of one template, so the data windows it reads stay in its L1/L2.  Inside an
+     * item the lags are evaluated LAGV at a time and -- where the whole block is valid and
+     * step == 1 -- LAGB = 4 x LAGV at a time: four independent vector fmaf chains per template
+     * sample, enough to cover the FMA latency (one chain alone runs at a quarter of the FMA rate).
+     * The arithmetic per lag is the same scalar chain either way. */
+    size_t *first_of = (size_t *)malloc(T * sizeof(size_t));
+    size_t *last_of = (size_t *)malloc(T * sizeof(size_t));
+    size_t *item0 = (size_t *)malloc((T + 1) * sizeof(size_t));
+    if (!first_of || !last_of || !item0) {
+        free(first_of); free(last_of); free(item0); free(e_t); free(e_d);
+        return -1;
+    }
+    item0[0] = 0;
     for (size_t t = 0; t < T; t++) {
-        for (size_t blk = 0; blk < n_blocks; blk++) {
+        size_t nb = 0;
+        if (mf_valid_range(moveouts + t * n_ch, weights + t * n_ch, n_ch, step, L, N, n_corr,
+                           &first_of[t], &last_of[t]))
+            nb = (last_of[t] - first_of[t]) / LAGB + 1;
+        else { first_of[t] = 1; last_of[t] = 0; }
+        item0[t + 1] = item0[t] + nb;
+    }
+    const size_t n_items = item0[T];
+#pragma omp parallel
+    {
+        int nth = 1, me = 0;
+#ifdef _OPENMP
+        nth = omp_get_num_threads();
+        me = omp_get_thread_num();
+#endif
+        const size_t it_lo = n_items * (size_t)me / (size_t)nth;
+        const size_t it_hi = n_items * ((size_t)me + 1) / (size_t)nth;
+        size_t t = 0;
+        for (size_t it = it_lo; it < it_hi; it++) {
+            while (item0[t + 1] <= it) t++;
             const int32_t *mv = moveouts + t * n_ch;
             const float *w = weights + t * n_ch;
-            size_t i_first, i_last;
-            if (!mf_valid_range(mv, w, n_ch, step, L, N, n_corr, &i_first, &i_last))
-                continue;
-            size_t i0 = blk * LAGV;
-            if (i0 > i_last || i0 + LAGV <= i_first) continue;
-            float cc_sum[LAGV];
-            int ok[LAGV];
-            for (int v = 0; v < LAGV; v++) {
-                cc_sum[v] = 0.0f;
-                ok[v] = (i0 + v >= i_first) && (i0 + v <= i_last);
-            }
+            const size_t i_last = last_of[t];
+            const size_t b0 = first_of[t] + (it - item0[t]) * LAGB;
+            const size_t nv = i_last - b0 + 1 < LAGB ? i_last - b0 + 1 : LAGB;   /* valid lags of the block */
+            float cc_sum[LAGB];
+            for (int v = 0; v < LAGB; v++) cc_sum[v] = 0.0f;
             for (size_t ch = 0; ch < n_ch; ch++) {
                 if (w[ch] == 0.0f) continue;
                 const float *tp = templates + (t * n_ch + ch) * L;
                 const float *d = data + ch * N;
                 const float *ed = e_d + ch * nwin;
                 const float et = e_t[t * n_ch + ch];
-                float num[LAGV];
-                /* offsets of the LAGV windows; invalid lags are parked on a safe one */
-                size_t off[LAGV];
-                for (int v = 0; v < LAGV; v++) {
-                    size_t i = ok[v] ? i0 + v : i_first;
-                    off[v] = (size_t)((int64_t)(i * step) + mv[ch]);
-                    num[v] = 0.0f;
-                }
-                if (step == 1 && ok[0] && ok[LAGV - 1]) {
-                    const float *dw = d + off[0];
+                float num[LAGB];
+                for (int v = 0; v < LAGB; v++) num[v] = 0.0f;
+                if (step == 1 && nv == LAGB) {
+                    const float *dw = d + (size_t)((int64_t)b0 + mv[ch]);
                     for (size_t l = 0; l < L; l++) {
                         const float tl = tp[l];
-                        for (int v = 0; v < LAGV; v++)
+#pragma omp simd
+                        for (int v = 0; v < LAGB; v++)
                             num[v] = fmaf(tl, dw[l + v], num[v]);
                     }
                 } else {
-                    for (size_t l = 0; l < L; l++) {
-                        const float tl = tp[l];
-                        for (int v = 0; v < LAGV; v++)
-                            num[v] = fmaf(tl, d[off[v] + l], num[v]);
+                    for (size_t v = 0; v < nv; v++) {
+                        const float *dw = d + (size_t)((int64_t)((b0 + v) * step) + mv[ch]);
+                        float acc = 0.0f;
+                        for (size_t l = 0; l < L; l++) acc = fmaf(tp[l], dw[l], acc);
+                        num[v] = acc;
                     }
                 }
-                for (int v = 0; v < LAGV; v++) {
-                    if (!ok[v]) continue;
-                    float nrm = et * ed[off[v]];
+                for (size_t v = 0; v < nv; v++) {
+                    const size_t off = (size_t)((int64_t)((b0 + v) * step) + mv[ch]);
+                    float nrm = et * ed[off];
                     float cc = 0.0f;
                     if (nrm < BPMF_MAX_NORM) cc = num[v] * nrm;
                     if (network_sum)
                         cc_sum[v] = fmaf(w[ch], cc, cc_sum[v]);
                     else
-                        out[(t * n_corr + i0 + v) * n_ch + ch] = cc;
+                        out[(t * n_corr + b0 + v) * n_ch + ch] = cc;
                 }
             }
             if (network_sum)
-                for (int v = 0; v < LAGV; v++)
-                    if (ok[v]) out[t * n_corr + i0 + v] = cc_sum[v];
+                for (size_t v = 0; v < nv; v++) out[t * n_corr + b0 + v] = cc_sum[v];
         }
     }
+    free(first_of); free(last_of); free(item0);
+    g_phase_seconds[0] = t_prep - t_start;
+    g_phase_seconds[1] = now_seconds() - t_prep;
     free(e_t);
     free(e_d);
     return 0;

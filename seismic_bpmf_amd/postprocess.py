@@ -65,9 +65,30 @@ def normalize_templates(waveforms, method="rms"):
     return w
 
 
-def network_to_template_map(waveforms):
-    """BPMF/dataset.py:5001: a template channel counts as present unless its samples sum to 0."""
-    return ~(np.sum(np.asarray(waveforms), axis=-1) == 0.0)
+def network_to_template_map(waveforms, selected_stations=None):
+    """TemplateGroup.set_network_to_template_map, BPMF/dataset.py:4977-5008: channel (t, s, c) is
+    used when (1) its samples do not sum to 0 (:5001) AND (2) station s is one of the stations
+    selected on template t (`tp.stations`, :5003-5007 -- what n_closest_stations /
+    n_best_SNR_stations leave on a template).
+
+    `selected_stations`: a (T, S) boolean array, or one sequence of network station indexes per
+    template (the reference's `network.station_indexes.loc[tp.stations]`); None = every station of
+    every template is selected (templates that carry the whole network)."""
+    present = ~(np.sum(np.asarray(waveforms), axis=-1) == 0.0)
+    if selected_stations is None:
+        return present
+    T, S = present.shape[:2]
+    if isinstance(selected_stations, np.ndarray) and selected_stations.dtype == bool:
+        sel = selected_stations
+        if sel.shape != (T, S):
+            raise ValueError(f"selected_stations must have shape {(T, S)}, got {sel.shape}")
+    else:
+        if len(selected_stations) != T:
+            raise ValueError("selected_stations needs one entry per template")
+        sel = np.zeros((T, S), dtype=bool)
+        for t, idx in enumerate(selected_stations):
+            sel[t, np.asarray(idx, dtype=np.int64)] = True
+    return present & sel[:, :, None]
 
 
 def station_density_weights(interstation_distances, cutoff_dist=None, lower_percentile=0.0,

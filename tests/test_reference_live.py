@@ -26,8 +26,8 @@ def ref():
         BPMF, clib = mg.import_reference()           # chdir()s into a scratch directory: BPMF reads its cfg from the CWD
     finally:
         os.chdir(cwd)
-    from BPMF import similarity_search, template_search, utils
-    yield types.SimpleNamespace(clib=clib, ss=similarity_search, ts=template_search, utils=utils, mg=mg)
+    from BPMF import similarity_search, template_search, utils, dataset
+    yield types.SimpleNamespace(clib=clib, ss=similarity_search, ts=template_search, utils=utils, ds=dataset, mg=mg)
     # leave no trace for the other test modules: the stub modules (fast_matched_filter, beampower, obspy ...)
     # and the reference's path entry go away again
     for name in set(sys.modules) - mods0:
@@ -206,8 +206,23 @@ def test_live_channel_weight_builders(ref):
         wav[rng.random((T, S, C)) < 0.3] = 0.0
         if T > 2:
             wav[1] = 0.0
-        n2t = ~(np.sum(wav, axis=-1) == 0.0)
-        avail = n2t.copy()
+        # the map as the reference builds it (dataset.py:4977-5008): non-zero channels AND the
+        # stations selected on each template (a random subset, as n_closest_stations leaves them)
+        chosen = [sorted(rng.choice(S, size=int(rng.integers(1, S + 1)), replace=False).tolist()) for _ in range(T)]
+        tg = types.SimpleNamespace(
+            n_templates=T, waveforms_arr=wav,
+            network=types.SimpleNamespace(n_stations=S, n_components=C,
+                                          station_indexes=pd.Series(np.arange(S), index=names)),
+            templates=[types.SimpleNamespace(stations=[names[i] for i in ch]) for ch in chosen])
+        ref.ds.TemplateGroup.set_network_to_template_map(tg)
+        n2t = np.asarray(tg._network_to_template_map)
+        mine = pp.network_to_template_map(wav, chosen)
+        assert np.array_equal(mine, n2t), j
+        sel = np.zeros((T, S), dtype=bool)
+        for t, ch in enumerate(chosen):
+            sel[t, ch] = True
+        assert np.array_equal(pp.network_to_template_map(wav, sel), n2t), j
+        avail = ~(np.sum(wav, axis=-1) == 0.0)
         mv = rng.integers(0, int(rng.choice([4, 50, 700])), (T, S, 2)).astype(np.int32)
         min_ch, min_st = int(rng.integers(1, 8)), int(rng.integers(1, 4))
         xy = rng.uniform(0.0, 80.0, (S, 2))
@@ -233,7 +248,7 @@ def test_live_channel_weight_builders(ref):
             dens = pp.station_density_weights(dist.values)
         mf.set_weights_channels(**kw)
         kw.pop("weight_station_density", None)
-        got = pp.set_weights_channels(density_weights=dens, present=pp.network_to_template_map(wav), moveouts=mv,
+        got = pp.set_weights_channels(density_weights=dens, present=mine, moveouts=mv,
                                       availability=avail, sr=25.0, min_channels=min_ch, min_stations=min_st, **kw)
         want = np.asarray(mf.weights_channels)
         assert got.shape == want.shape and np.array_equal(got, want.astype(got.dtype)), (j, T, S, kw)
