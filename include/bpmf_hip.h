@@ -54,6 +54,20 @@ void bpmf_profile_enable(int enable); /* enabling clears the log; disabling keep
 int bpmf_profile_count(int which_kernel); /* launches logged since enable */
 int bpmf_profile_get_ms(int which_kernel, int launch_index, float *milliseconds);
 
+/* Execution options.  The library reads NOTHING from the environment.  An option selects among
+ * code paths and sizes that produce identical results (kernel family, LDS budget, batch sizes of
+ * the host-pointer calls, group ranges per tile): the GPU tests use them to drive every kernel
+ * family through the same parity cases, tools/ to measure alternatives.  Process-wide, thread
+ * safe; plans already built keep the variant they were built with.  Names:
+ *   bp.lds_kb bp.max_group bp.tpt bp.reorder bp.dual bp.packed bp.wps bp.uvgpr bp.fast
+ *   bp.fast_uniform bp.split bp.wpb bp.smeta bp.verbose
+ *   mf.wave_kernel mf.max_mfma_step mf.host_batch_kb mf.host_piece_kb mf.verbose
+ * (The reference's counterpart is the `device=` / `arch=` string it forwards to the third-party
+ * back-ends, BPMF/similarity_search.py:532, BPMF/template_search.py:554.)
+ * -1 for an unknown name or a value outside the option's range. */
+int bpmf_set_option(const char *name, long value);
+int bpmf_get_option(const char *name, long *value, long *default_value);
+
 /* ------------------------------------------------------------ matched filter --- */
 /*
  * Serves fast_matched_filter.matched_filter(templates, moveouts, weights, data, step,

@@ -8,8 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BPMF_HIP_LIB: path of an alternative build of the same library (experiments, ablations)
-LIBPATH = os.environ.get("BPMF_HIP_LIB") or os.path.join(_HERE, "lib", "libbpmf_hip.so")
+LIBPATH = os.path.join(_HERE, "lib", "libbpmf_hip.so")
 
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int32)
@@ -28,6 +27,8 @@ SIGNATURES = {
     "bpmf_last_error": (C.c_char_p, []),
     "bpmf_device_count": (C.c_int, []),
     "bpmf_device_info": (C.c_int, [C.c_int, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(C.c_int)]),
+    "bpmf_set_option": (C.c_int, [C.c_char_p, C.c_long]),
+    "bpmf_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "bpmf_profile_enable": (None, [C.c_int]),
     "bpmf_profile_count": (C.c_int, [C.c_int]),
     "bpmf_profile_get_ms": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -121,6 +122,38 @@ def device_info(device=0):
 
 
 KERNEL_MF_MAIN, KERNEL_BP_BEAM = 0, 1
+
+
+def set_option(name, value):
+    """bpmf_set_option: choose among code paths with identical results (see include/bpmf_hip.h)."""
+    check(lib().bpmf_set_option(name.encode(), int(value)), f"bpmf_set_option({name})")
+
+
+def get_option(name):
+    val, dflt = C.c_long(0), C.c_long(0)
+    check(lib().bpmf_get_option(name.encode(), C.byref(val), C.byref(dflt)), f"bpmf_get_option({name})")
+    return val.value, dflt.value
+
+
+class options:
+    """Context manager: set execution options, restore the previous values on exit.
+
+        with _lib.options(**{"bp.fast": 0, "bp.split": 3}): ...
+    """
+
+    def __init__(self, **kv):
+        self.kv = {k.replace("__", "."): v for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: get_option(k)[0] for k in self.kv}
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False
 
 
 def profile_enable(on=True):

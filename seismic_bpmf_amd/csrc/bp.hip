@@ -648,14 +648,8 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
         out_beam += (size_t)blockIdx.y * (size_t)split_stride;
         out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     }
-#ifndef BP_DBG
-#define BP_DBG 0
-#endif
-    constexpr bool GLOCAL = B64 && REDUCE == BPMF_BP_REDUCE_MAX && !(BP_DBG & 1);
-    constexpr bool SPAIR = SMETA && !(BP_DBG & 2);
-    constexpr bool FASTP = !(BP_DBG & 4);
-    // timing ablations (results are WRONG with these): 8 no epilogue, 16 no metadata reload, 32 no fma
-    constexpr bool AB_NOEPI = BP_DBG & 8, AB_NOLOAD = BP_DBG & 16, AB_NOFMA = BP_DBG & 32;
+    constexpr bool GLOCAL = B64 && REDUCE == BPMF_BP_REDUCE_MAX;
+    constexpr bool SPAIR = SMETA;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -815,8 +809,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {  // phase P then phase S of a station, as the oracle
-                    if constexpr (AB_NOFMA) { if (jj == 0 && (u & 7) == 0) BP_PKFMA(ac[0], X[u & 3][1], X[u & 3][2]); asm volatile("" :: "v"(X[u & 3][jj])); }
-                    else if constexpr (SPAIR) BP_PKFMA_S(ac[jj], sp, X[u & 3][jj]);
+                    if constexpr (SPAIR) BP_PKFMA_S(ac[jj], sp, X[u & 3][jj]);
                     else BP_PKFMA(ac[jj], bb, X[u & 3][jj]);
                 }
             }
@@ -855,7 +848,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
             }
 #undef BP_SWITCH
 #undef BP_CASE
-            if constexpr (SMETA && !AB_NOLOAD) m.issue(srcs4, recs, k_next);
+            if constexpr (SMETA) m.issue(srcs4, recs, k_next);
             // strict bounds as a wave-uniform window [lo, hi) of the tile: 0 <= t + tmin and
             // t + tmax < N with t = t0 + x
             int lo = 0, hi = TILE;
@@ -865,9 +858,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
                 hi = (int)(hi64 < 0 ? 0 : (hi64 > TILE ? TILE : hi64));
             }
             if (nsta <= 0) hi = 0;
-            if (AB_NOEPI) {
-                if (acc[0] == 123.456f) best[0] = acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7];
-            } else if (GLOCAL && FASTP && lo == 0 && hi == TILE) {  // whole tile inside the bounds (wave-uniform)
+            if (GLOCAL && lo == 0 && hi == TILE) {  // whole tile inside the bounds (wave-uniform)
 #pragma unroll
                 for (int j = 0; j < TPW; ++j) {
                     const bool take = acc[j] > bestg[j];
@@ -1193,12 +1184,6 @@ int upload(const std::vector<Tv>& v, Tv** d)
     return 0;
 }
 
-int env_int(const char* name, int dflt)
-{
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 }  // namespace
 
 extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sources, size_t K,
@@ -1214,11 +1199,11 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         return -1;
     }
     // tuning knobs (defaults chosen on MI355X)
-    const size_t soft_kb = (size_t)std::max(8, env_int("BPMF_BP_LDS_KB", 80));
-    const int max_group = std::max(1, env_int("BPMF_BP_MAX_GROUP", 4096));
-    const int tpt_first = env_int("BPMF_BP_TPT", 2);
+    const size_t soft_kb = (size_t)std::max(8, (int)option(OPT_BP_LDS_KB));
+    const int max_group = std::max(1, (int)option(OPT_BP_MAX_GROUP));
+    const int tpt_first = (int)option(OPT_BP_TPT);
     const int chunk = 4;  // terms gathered side by side by the generic kernel (8 measured equal)
-    const bool reorder = env_int("BPMF_BP_REORDER", 1) != 0;
+    const bool reorder = (int)option(OPT_BP_REORDER) != 0;
     const size_t hard = BP_LDS_MAX / sizeof(float);
     const size_t soft = std::min(hard, soft_kb * 1024 / sizeof(float));
 
@@ -1228,8 +1213,8 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     // dual windows, one 16-wave workgroup per CU with the whole LDS.  When one source's dual
     // windows do not fit, fall through to the single-window plans.
     bool dual = false;
-    if (P == 2 && env_int("BPMF_BP_DUAL", 1) && env_int("BPMF_BP_PACKED", 1) &&
-        env_int("BPMF_BP_WPS", 1) && tpt_first == 2) {
+    if (P == 2 && (int)option(OPT_BP_DUAL) && (int)option(OPT_BP_PACKED) &&
+        (int)option(OPT_BP_WPS) && tpt_first == 2) {
         size_t max_sta = 0;
         for (size_t k = 0; k < K; ++k) {
             size_t n = 0;
@@ -1273,14 +1258,14 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     pl->id_offset = source_id_offset;
     pl->mean_group = (double)K / (double)ph.groups.size();
     pl->dual = dual;
-    if (env_int("BPMF_BP_VERBOSE", 0))
+    if ((int)option(OPT_BP_VERBOSE))
         fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B dual=%d\n",
                 K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes, (int)dual);
     int rc = 0;
     // fast-path copy of the term table: {byte offset, weight} pairs padded to ntv per source
     const int ntv_opts[4] = {8, 16, 24, 32};
-    const bool want_uv = env_int("BPMF_BP_UVGPR", 1) != 0;
-    pl->wps = env_int("BPMF_BP_WPS", 1);
+    const bool want_uv = (int)option(OPT_BP_UVGPR) != 0;
+    pl->wps = (int)option(OPT_BP_WPS);
     std::vector<BpTermV> tv;
     for (int o = 0; o < 4 && want_uv && !pl->ntv; ++o)
         if (ph.NT <= ntv_opts[o]) pl->ntv = ntv_opts[o];
@@ -1292,7 +1277,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         if ((rc = upload(tv, (BpTermV**)&pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
     }
     // packed per-station records for the two-phase fast kernel
-    if (P == 2 && ph.NT <= 64 && env_int("BPMF_BP_PACKED", 1)) {
+    if (P == 2 && ph.NT <= 64 && (int)option(OPT_BP_PACKED)) {
         const int nsta_max = ph.NT / 2;   // NT is a multiple of 4
         const int opts[5] = {4, 8, 12, 16, 32};
         for (int o = 0; o < 5 && !pl->nsv; ++o)
@@ -1320,9 +1305,9 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     }
     // Interior-tile fast path (bp_fast.hip): the sources of every group once more, partitioned into
     // runs of equal (even-padded) station count, one fixed-stride record each.
-    if (dual && pl->nsv && pl->nsv <= 16 && env_int("BPMF_BP_FAST", 1)) {
+    if (dual && pl->nsv && pl->nsv <= 16 && (int)option(OPT_BP_FAST)) {
         const int NT = ph.NT;
-        bool uniform = env_int("BPMF_BP_FAST_UNIFORM", 1) != 0;
+        bool uniform = (int)option(OPT_BP_FAST_UNIFORM) != 0;
         int tmin_all = 0, tmax_all = 0;
         bool any = false;
         for (size_t q = 0; q < K; ++q) {
@@ -1413,7 +1398,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         pl->fast_rec_dw = rec_dw;
         pl->tmin_all = tmin_all;
         pl->tmax_all = tmax_all;
-        if (env_int("BPMF_BP_VERBOSE", 0))
+        if ((int)option(OPT_BP_VERBOSE))
             fprintf(stderr, "[bpmf] bp fast path: %zu runs, uniform=%d, rec=%d dwords, moveouts [%d, %d]\n",
                     fr.size(), (int)uniform, rec_dw, tmin_all, tmax_all);
     }
@@ -1470,7 +1455,7 @@ namespace {
 // beamforms 1 500-3 000 samples over the whole grid (BPMF/dataset.py:2174-2216) -- leaves most of the
 // 256 CUs idle (and up to ~1000 tiles the last round of workgroups runs half empty): the groups of the
 // plan are then dealt to 1024 / tiles workgroups per tile.
-// BPMF_BP_SPLIT: 0/1 = off, n = force n ranges (tests).  Only the P = 2 packed kernels take it.
+// option bp.split: 0/1 = off, n = force n ranges (tests), -1 = automatic.  Only the P = 2 packed kernels take it.
 int bp_split_count(const bpmf_bp_plan* pl, size_t N)
 {
     if (!pl || pl->tpt != 2 || !pl->wps || pl->n_groups < 2) return 1;
@@ -1479,7 +1464,7 @@ int bp_split_count(const bpmf_bp_plan* pl, size_t N)
     // enough workgroups for ~4 rounds over the 256 CUs (a split costs one merge pass and nothing else:
     // the ranges stage disjoint windows), none from 1024 tiles (N >= 524 288) on
     long long want = n_tiles >= 1024 ? 1 : (1024 + n_tiles - 1) / n_tiles;
-    const int forced = env_int("BPMF_BP_SPLIT", -1);   // read per call: the tests switch it
+    const int forced = (int)option(OPT_BP_SPLIT);   // read per call: the tests switch it
     if (forced >= 0) want = forced < 1 ? 1 : forced;
     return (int)std::max<long long>(1, std::min<long long>(want, pl->n_groups));
 }
@@ -1658,13 +1643,13 @@ int dispatch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, int oob
     // NSV <= 16: metadata in SGPRs, 12 waves per workgroup, 2 workgroups (24 waves) per CU --
     // ds_read_b32-class gathers need >= 4 waves/SIMD to reach the LDS rate.  Above 16 stations
     // the SGPR set no longer fits and the VGPR-metadata variant (8 waves/CU) runs.
-    static const int wpb = env_int("BPMF_BP_WPB", 12);
+    const int wpb = (int)option(OPT_BP_WPB);
     if constexpr (NSV <= 16) {
         if (pl->dual) return dispatch_beam_wps2b<16, NSV, true, true>(pl, U, N, oob, reduce, stream, beam, arg);
         if (wpb == 8) return dispatch_beam_wps2b<8, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
         return dispatch_beam_wps2b<12, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
     }
-    static const int smeta = env_int("BPMF_BP_SMETA", 1);
+    const int smeta = (int)option(OPT_BP_SMETA);
     if constexpr (NSV % 16 == 0) {
         if (smeta) return dispatch_beam_wps2b<16, NSV, true>(pl, U, N, oob, reduce, stream, beam, arg);
     }

@@ -79,25 +79,6 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const int g_hi = (int)((long long)n_groups * (blockIdx.y + 1) / gridDim.y);
     out_beam += (size_t)blockIdx.y * (size_t)split_stride;
     out_arg += (size_t)blockIdx.y * (size_t)split_stride;
-    // timing ablations (build with -DBPF_DBG=<bits>, see tools/ablate_bp_fast.sh): 1 skips the staging,
-    // 2 the barriers, 8 the record refills (every source re-uses the first record), 16 the max
-    // update -- results are WRONG with any of them.  Measured at cfg3 (profiles/r02_bp_ablation.txt).
-#ifndef BPF_DBG
-#define BPF_DBG 0
-#endif
-    constexpr int dbg = BPF_DBG;
-    // BPF_REJECT (default 0; measured dead end, kept for tools/ab_bp_reject.sh): the max / arg-max
-    // update of a source first tests, with 8 compares, an s_or tree and one wave-uniform branch,
-    // whether ANY of the wave's 512 beams reaches the best value known for its sample in the whole
-    // workgroup (`thr`, exchanged between the 16 waves through LDS at every group boundary), and
-    // only then runs the full update (value, then lowest id).  After the first groups almost no
-    // source passes the test, and the update shrinks from 24 to 8 VALU -- but the compare -> SALU ->
-    // branch chain stalls the wave at every source: 159.6 ms against 156.5 ms for the
-    // unconditional update on the same box (cfg3, profiles/r02_bp_reject_ab.txt).
-#ifndef BPF_REJECT
-#define BPF_REJECT 0
-#endif
-    constexpr bool REJECT = BPF_REJECT != 0;
     extern __shared__ float lds[];
     constexpr int TPW = 8, TILE = BPF_TILE, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     const int tid = threadIdx.x;
@@ -117,9 +98,6 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     int arg[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
-    float thr[TPW];      // REJECT: >= best[j]; the largest beam any wave of the workgroup has seen at the sample
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) thr[j] = 0.0f;
     for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
     const long long rec_stride = (long long)rec_dw * 4 * WPB;   // bytes between a wave's sources
 
@@ -139,23 +117,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 
     for (int g = g_lo; g < g_hi; ++g) {
         const BpFastGroup grp = groups[g];
-        if (!(dbg & 2)) __syncthreads();  // previous group's gathers are done, this group's descriptors are in LDS
-        if constexpr (REJECT) {
-            // every wave publishes its thresholds in the (now dead) window area and takes the
-            // maximum over the 16 waves: 32 KB of LDS traffic per group
-            if (g > g_lo) {
-                float* ex = lds + BPF_DESC_OFS + 4 * BPF_DESC_MAX;        // [WPB][TILE]
-#pragma unroll
-                for (int j = 0; j < TPW; ++j) ex[wv * TILE + slot_x(j)] = thr[j];
-                __syncthreads();
-#pragma unroll 1
-                for (int w2 = 0; w2 < WPB; ++w2) {
-#pragma unroll
-                    for (int j = 0; j < TPW; ++j) thr[j] = fmaxf(thr[j], ex[w2 * TILE + slot_x(j)]);
-                }
-                __syncthreads();   // before the staging overwrites the area
-            }
-        }
+        __syncthreads();  // previous group's gathers are done, this group's descriptors are in LDS
         // ---- staging by LDS-DMA: a window (tile + moveout spread floats of one prestacked row) goes
         // global -> LDS in pieces of 256 floats, ONE instruction per piece and wave (16 bytes per
         // lane, destination = wave-uniform base + 16 * lane; an unaligned global source is fine),
@@ -164,7 +126,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         // version of round 1 paid two dependent round trips per 8 chunks per wave: 5.5 % of the
         // kernel at cfg3, this one 2 %.  The copies count in vmcnt; __syncthreads() waits for them
         // (vmcnt(0)) before the barrier.
-        if (!(dbg & 1)) {
+        {
             const i32x4* dsc = (const i32x4*)(lds + BPF_DESC_OFS);
             for (int wi = wv; wi < grp.n_win; wi += WPB) {
                 const i32x4 d = dsc[wi];                       // {row, first sample relative to t0, LDS float offset, floats}
@@ -179,7 +141,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 }
             }
         }
-        if (!(dbg & 2)) __syncthreads();
+        __syncthreads();
         if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
 
         for (int rr = 0; rr < grp.n_run; ++rr) {
@@ -189,12 +151,10 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             const int* p_first = recs + ((long long)run.first_rec + wv) * rec_dw;
             // group-local running max of this run: sources arrive by ascending id, so a plain
             // strict > keeps the lowest id on ties; the full tie rule merges the run into best/arg
-            float bestg[REJECT ? 1 : TPW];
-            int argg[REJECT ? 1 : TPW];
-            if constexpr (!REJECT) {
+            float bestg[TPW];
+            int argg[TPW];
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
-            }
+            for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
 
             auto walk = [&](auto nst_c) {
                 constexpr int NST = decltype(nst_c)::value;
@@ -245,8 +205,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     i32x2 sp_u;
                     // the header of the next source (the table is padded by one round of records: no clamp)
                     p = (const int*)((const char*)p + rec_stride);
-                    if (!(dbg & 8)) BPF_LOADX2(h_next, vzero, p, 0);
-                    else h_next = h_cur;
+                    BPF_LOADX2(h_next, vzero, p, 0);
 #pragma unroll
                     for (int u = 0; u < NU; ++u) {
                         // ---- keep three units in flight ahead of unit u: the unit issued now belongs to
@@ -275,7 +234,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             else BPF_PKFMA(ac[jj], sp, X[u & 3][jj]);
                         }
                         // ---- quad u / 4 is consumed (addresses issued, weights multiplied): refill it
-                        if (u % 4 == 3 && !(dbg & 8)) {
+                        if (u % 4 == 3) {
                             switch (u >> 2) {
                                 case 0: BPF_LOADQ(0); break; case 1: BPF_LOADQ(1); break;
                                 case 2: BPF_LOADQ(2); break; case 3: BPF_LOADQ(3); break;
@@ -286,26 +245,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     }
                     // ---- max / arg-max update, strict >: 8 compares, then 16 selects; the next source's
                     // first three units are in flight meanwhile
-                    if constexpr (REJECT) {
-                        if (!(dbg & 16)) {
-                            unsigned long long mk[TPW];
-#pragma unroll
-                            for (int j = 0; j < TPW; ++j)
-                                asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(mk[j]) : "v"(ac[j >> 1][j & 1]), "v"(thr[j]));
-                            const unsigned long long any = ((mk[0] | mk[1]) | (mk[2] | mk[3])) | ((mk[4] | mk[5]) | (mk[6] | mk[7]));
-                            if (any != 0) {   // wave-uniform, rare after the first groups
-                                const int sid = h_cur[0];
-#pragma unroll
-                                for (int j = 0; j < TPW; ++j) {
-                                    const float a = ac[j >> 1][j & 1];
-                                    const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
-                                    best[j] = take ? a : best[j];
-                                    arg[j] = take ? sid : arg[j];
-                                    thr[j] = a > thr[j] ? a : thr[j];
-                                }
-                            }
-                        }
-                    } else if (!(dbg & 16)) {
+                    {
                         unsigned long long mk[TPW];
 #pragma unroll
                         for (int j = 0; j < TPW; ++j)
@@ -335,13 +275,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 case 16: walk(std::integral_constant<int, 16>{}); break;
                 default: break;
             }
-            if constexpr (!REJECT) {
 #pragma unroll
-                for (int j = 0; j < TPW; ++j) {
-                    const bool take = (bestg[j] > best[j]) | ((bestg[j] == best[j]) & (argg[j] < arg[j]));
-                    best[j] = take ? bestg[j] : best[j];
-                    arg[j] = take ? argg[j] : arg[j];
-                }
+            for (int j = 0; j < TPW; ++j) {
+                const bool take = (bestg[j] > best[j]) | ((bestg[j] == best[j]) & (argg[j] < arg[j]));
+                best[j] = take ? bestg[j] : best[j];
+                arg[j] = take ? argg[j] : arg[j];
             }
         }
     }

@@ -19,6 +19,19 @@ void profile_mark(int which, int edge, hipStream_t stream);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Execution options (util.hip, C ABI: bpmf_set_option / bpmf_get_option).  Every option selects
+// among code paths and sizes that produce IDENTICAL results -- kernel family, LDS budget, staging
+// batch sizes, group ranges per tile; none of them can change an output bit, and the library reads
+// nothing from the environment.  The defaults are the tuned production values; the GPU tests use
+// the options to force every kernel family through the same parity cases.
+enum Option {
+    OPT_BP_LDS_KB, OPT_BP_MAX_GROUP, OPT_BP_TPT, OPT_BP_REORDER, OPT_BP_DUAL, OPT_BP_PACKED,
+    OPT_BP_WPS, OPT_BP_UVGPR, OPT_BP_FAST, OPT_BP_FAST_UNIFORM, OPT_BP_SPLIT, OPT_BP_WPB,
+    OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
+    OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_COUNT
+};
+long option(Option which);
+
 // Binds the calling thread to `device` for the lifetime of the guard and restores the device
 // that was current before: a host entry point must not change the caller's (or torch's)
 // current device as a side effect.  ok() is false if either runtime call failed.

@@ -38,19 +38,6 @@ __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t
     e_t[i] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
 }
 
-// Toeplitz band image of every (template, channel) row as the wave kernel keeps it in LDS:
-// band[15 + l] = tmpl[l], zeros around, band_len floats -- the source of the LDS-DMA staging
-// (a DMA copy has no per-dword bounds check to produce the zeros).
-__global__ void mf_band_image_kernel(const float* __restrict__ tmpl, size_t n_rows, int L, int band_len,
-                                     float* __restrict__ band)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows * (size_t)band_len) return;
-    const size_t row = i / (size_t)band_len;
-    const int l = (int)(i % (size_t)band_len) - 15;
-    band[i] = (l >= 0 && l < L) ? tmpl[row * (size_t)L + l] : 0.0f;
-}
-
 // Valid lag range [first, last] of each template (first > last = empty).
 // Also writes the template's compact list of used channels, one int4 {channel, moveout,
 // weight bits, r_t bits} per channel with w != 0, in channel order, closed by two {-1,..}
@@ -247,14 +234,9 @@ __host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L
 // XCD x owns the contiguous lag blocks [x * per_xcd, (x + 1) * per_xcd); inside an XCD the template
 // index is fastest, so the workgroups in flight on one L2 share one or two lag blocks' windows.
 // The grid is 8 * per_xcd * T workgroups; the ones past the last lag block exit at once.
-__device__ __forceinline__ bool mf_tile_of_block(unsigned bid, int T, int n_lag_blocks, int xcd_map,
-                                                 int& t, long long& lag_block)
+__device__ __forceinline__ bool mf_tile_of_block(unsigned bid, int T, int n_lag_blocks, int& t,
+                                                 long long& lag_block)
 {
-    if (!xcd_map) {
-        t = (int)(bid % (unsigned)T);
-        lag_block = bid / (unsigned)T;
-        return true;
-    }
     const unsigned xcd = bid & 7u, i = bid >> 3;
     const int per_xcd = (n_lag_blocks + 7) >> 3;
     t = (int)(i % (unsigned)T);
@@ -309,7 +291,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate, int t_batch, int n_lag_blocks)
+    float* __restrict__ out, int n_lag_blocks)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -323,24 +305,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const int a = lane & 15;   // tile column (and band row for the A operand)
     const int kq = lane >> 4;  // k index of the operands / row group of the results
 
-    // Workgroup order: templates in batches of t_batch; inside a batch the template index is
-    // fastest, then the lag block: the workgroups in flight share a few lag blocks' data
-    // windows (L2) while touching at most t_batch rows of the output at a time.
+    // XCD-aware workgroup order (mf_tile_of_block)
     int t;
-    long long lag0;
-    if (t_batch >= T) {  // default: XCD-aware order (mf_tile_of_block)
-        long long lag_block;
-        if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
-        lag0 = lag_block * MF_LAGS_PER_WG;
-    } else {
-        const long long per_batch = (long long)t_batch * n_lag_blocks;
-        const int batch = (int)(blockIdx.x / per_batch);
-        const int rem = (int)(blockIdx.x - batch * per_batch);
-        if (batch * t_batch >= T) return;
-        const int tb = min(t_batch, T - batch * t_batch);
-        t = batch * t_batch + rem % tb;
-        lag0 = (long long)(rem / tb) * MF_LAGS_PER_WG;
-    }
+    long long lag_block;
+    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
+    const long long lag0 = lag_block * MF_LAGS_PER_WG;
     // `range` holds CC indices; the kernel works on data-sample offsets (lag = index * step) and
     // simply skips the offsets that are not multiples of step
     const int2 rgi = range[t];
@@ -419,22 +388,20 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                 // valid range reads up to 3 floats outside this channel's row of norms -- the
                 // neighbouring row or the slack around the array -- and those lanes are masked in
                 // the epilogue (`ok`).
-                if (ablate & 8) {
-                    ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (wg_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
+                if (wg_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
                     ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
-            if (rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
+            if (rec1.x >= 0) issue_stage(rec1.x, rec1.y);
 
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             // K loop: 16 band rows = 4 k-steps per trip; the operands of k-step j+2 are
             // requested before the MFMAs of k-step j issue (4 rotating register slots).
-            const int nq = (ablate & 4) ? 0 : Kpad >> 4;
+            const int nq = Kpad >> 4;
             // K loop: 16 band rows = 4 k-steps per trip.  The 5 operands of k-step j+2 are
             // requested from LDS before the 4 MFMAs of k-step j issue, in 4 rotating register
             // slots.  The reads are inline asm with COUNTED waits: hipcc's own waitcnt insertion
@@ -501,7 +468,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 #undef MF_REQ
 #undef MF_STEP
 
-            if (NETWORK_SUM && STEP1 && wg_inside && !(ablate & 1)) {
+            if (NETWORK_SUM && STEP1 && wg_inside) {
                 // every lag of this workgroup is inside the template's valid range: no range tests
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -521,8 +488,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                     // STEP1 builds carry no division at all; otherwise 32-bit (lags < 2^31)
                     const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
-                    if (ablate & 1) cc = acc[u][r] * ed[u][r];
-                    else if (ok) {
+                    if (ok) {
                         const float nrm = et * ed[u][r];  // r_t * r_d
                         if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
                         if (!NETWORK_SUM)
@@ -565,15 +531,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // execute in order): single-buffered, 6.6 KB per wave instead of 9.9 KB.  The price is the
 // 256-float overlap between neighbouring waves' windows (25 % more staging traffic from L2).
 // Used for L <= 257 (window 1280 floats = 20 staging registers per lane).
-// DMA: the LDS-DMA staging variant (see below); it computes only the waves whose windows lie
-// inside the trace for every channel, the register-staged variant (DMA = false) launched with
-// `band_img` set computes exactly the others.
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, bool DMA = false>
-__global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
+__global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int ablate, int n_lag_blocks, const float* __restrict__ band_img)
+    float* __restrict__ out, int n_lag_blocks)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -594,13 +557,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
     // "MF: lag blocks per workgroup experiment": FETCH_SIZE 88.4 / 82.0 / 81.3 / 92.2 M KiB and
     // 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for 1 / 2 / 4 / 8 blocks, profiles/r02_mf_nsub.txt;
     // the loop also cost 7 spilled registers.  One block per workgroup.)
-    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, ablate & 16 ? 0 : 1, t, lag_block)) return;
-    // experiment (BPMF_MF_ABLATE bits 8..): stagger the waves of a SIMD by (hardware wave slot & 3)
-    // x (ablate >> 8) x 64 cycles, so that their per-channel store / epilogue phases do not coincide
-    if (ablate >> 8) {
-        const int slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3;   // HW_ID.wave_id
-        for (int i = 0; i < slot * (ablate >> 8); ++i) __builtin_amdgcn_s_sleep(1);
-    }
+    if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
     const int2 rgi = range[t];
     const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
@@ -621,19 +578,17 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
         const int b_base = 18 * a + kq;  // window padded 2 floats per 16: conflict-free B reads
         const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
 
-        float rd[DMA ? 1 : MAXR], rt[DMA ? 1 : MAXT];
+        float rd[MAXR], rt[MAXT];
         auto issue_stage = [&](int ch, int mvc) {
-            if constexpr (DMA) return;
             const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(data + (size_t)ch * (size_t)N), 0, (int)(N * 4), 0x00020000);
-            mf_stage_rows<DMA ? 1 : MAXR, 64>(rd, rs_d, lag0 + mvc, lane);
+            mf_stage_rows<MAXR, 64>(rd, rs_d, lag0 + mvc, lane);
             const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
-            mf_stage_band<DMA ? 1 : MAXT, 64>(rt, rs_t, lane);
+            mf_stage_band<MAXT, 64>(rt, rs_t, lane);
         };
         const bool full_window = Ww == 64 * MAXR;  // L = 241..257: every staging register is used
         auto write_stage = [&]() {
-            if constexpr (DMA) return;
             if (full_window) {
 #pragma unroll
                 for (int r = 0; r < MAXR; ++r) {
@@ -654,59 +609,13 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
             }
         };
 
-        // ---- LDS-DMA staging (band_img != nullptr, waves whose windows lie inside the trace for
-        // every channel): the next channel's window and band go global -> LDS with 6 + 2
-        // global_load_lds_dwordx4 (16 bytes per lane, lane-linear destination) issued after the
-        // epilogue, instead of 25 loads into registers during the K loop and 25 + 5 ds_write_b32
-        // after it.  The window keeps its padded layout (2 floats per 16): LDS slot j (floats
-        // 4j .. 4j+3) of group g = 4j / 18, position r = 4j % 18 is ONE contiguous 16-byte read at
-        // data[g0 + 16 g + min(r, 14)] -- the pad positions of a slot receive neighbouring samples
-        // that no operand read ever addresses.  The wave waits for its copies (vmcnt(0)) at the top
-        // of the next channel; the other waves of the SIMD keep the matrix pipe busy meanwhile.
-        const int n_slots = (Ww + 2 * (Ww >> 4) + 3) >> 2;
-        const bool wave_dma = band_img != nullptr && wave_inside && n_slots <= 6 * 64 &&
-                              lag0 + MF_LAGS_PER_WAVE - 1 + 24 <= rg.y;
-        if (wave_dma != DMA) return;       // the other variant's launch computes this wave
-        auto dma_stage = [&](int ch, int mvc) {
-            if constexpr (!DMA) return;
-            const float* src = data + (size_t)ch * (size_t)N + (lag0 + mvc);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                // source sample of this lane's slot in piece q (floats, relative to the window start)
-                const int p4 = 4 * (64 * q + lane);
-                const int g = p4 / 18, r = p4 - 18 * g;
-                const int xo = 16 * g + (r < 14 ? r : 14);
-                if (64 * q + lane < n_slots)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + xo),
-                                                     (__attribute__((address_space(3))) void*)(dw + 256 * q), 16, 0, 0);
-            }
-            const float* bsrc = band_img + ((size_t)t * n_ch + ch) * (size_t)tp_len + 4 * lane;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (4 * (64 * q + lane) < tp_len)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + 256 * q),
-                                                     (__attribute__((address_space(3))) void*)(tp + 256 * q), 16, 0, 0);
-        };
-
         int4 rec = recs[0];
         int4 rec1 = recs[1];
         int ri = 0;
-        // experiment (-DMF_EARLY_STAGE=1): the next channel's LDS stores (or LDS-DMA copies) go right
-        // behind the K loop, BEFORE the epilogue of the current channel, so that their latency runs
-        // under the epilogue's VALU work instead of in front of the next K loop
-#ifndef MF_EARLY_STAGE
-#define MF_EARLY_STAGE 0
-#endif
-        constexpr bool EARLY = MF_EARLY_STAGE != 0;
-        if (rec.x >= 0) { if (wave_dma) dma_stage(rec.x, rec.y); else issue_stage(rec.x, rec.y); }
-        if (EARLY && !wave_dma && rec.x >= 0) write_stage();
+        if (rec.x >= 0) issue_stage(rec.x, rec.y);
         while (rec.x >= 0) {
             const int ch = rec.x;
-            if (wave_dma) {
-                // each wave stages its own buffers: its copies are in LDS once vmcnt retires them
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            else if (!EARLY) write_stage();  // in place: this wave finished reading the previous channel
+            write_stage();  // in place: this wave finished reading the previous channel
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
@@ -720,20 +629,18 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
                 // valid range reads up to 3 floats outside this channel's row of norms -- the
                 // neighbouring row or the slack around the array -- and those lanes are masked in
                 // the epilogue (`ok`).
-                if (ablate & 8) {
-                    ed[u] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-                } else if (wave_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
+                if (wave_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
                     ed[u] = *(const f32x4u*)(edc + lag + mvc);
                 } else {
                     ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
-            if (!wave_dma && rec1.x >= 0 && !(ablate & 2)) issue_stage(rec1.x, rec1.y);
+            if (rec1.x >= 0) issue_stage(rec1.x, rec1.y);
 
             f32x4 acc[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            const int nq = (ablate & 4) ? 0 : Kpad >> 4;
+            const int nq = Kpad >> 4;
             unsigned ap = (unsigned)(size_t)(tp + a_base), bp = (unsigned)(size_t)(dw + b_base);
             float sa[4], sb[4][4];
             // counted waits as in mf_mfma_kernel; the ds_writes above are older than every read
@@ -775,9 +682,6 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
     MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
     __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
-            // experiment (BPMF_MF_ABLATE bit 32): raise this wave's issue priority for the K loop, so
-            // that MFMA-issuing waves win the arbitration against waves in their store / epilogue phase
-            if (ablate & 32) __builtin_amdgcn_s_setprio(2);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
@@ -789,15 +693,12 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
                 bp += 72;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (ablate & 32) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
 #undef MF_LDS_READ
 #undef MF_MFMA
 #undef MF_REQ
 #undef MF_STEP
-            if (EARLY && rec1.x >= 0) { if (wave_dma) dma_stage(rec1.x, rec1.y); else write_stage(); }
-
-            if (NETWORK_SUM && STEP1 && wave_inside && !(ablate & 1)) {
+            if (NETWORK_SUM && STEP1 && wave_inside) {
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
                 // but the first and last tiles of a day): no per-lag range tests
 #pragma unroll
@@ -818,8 +719,7 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
                     // STEP1 builds carry no division at all; otherwise 32-bit (lags < 2^31)
                     const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
-                    if (ablate & 1) cc = acc[u][r] * ed[u][r];
-                    else if (ok) {
+                    if (ok) {
                         const float nrm = et * ed[u][r];  // r_t * r_d
                         if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
                         if (!NETWORK_SUM)
@@ -829,9 +729,6 @@ __global__ __launch_bounds__(MF_THREADS, DMA ? 5 : 4) void mf_mfma_wave_kernel(
                 }
             }
             }
-            // LDS-DMA staging: the K loop is done with the buffers (lgkmcnt(0) above), the next
-            // channel's window and band can land in place
-            if (!EARLY && wave_dma && rec1.x >= 0) dma_stage(rec1.x, rec1.y);
             rec = rec1;
             rec1 = rec2;
             ++ri;
@@ -903,7 +800,6 @@ struct MfWorkspace {
     float* e_t;     // [T, n_ch]
     int2* range;    // [T]
     int4* chan_rec; // [T, n_ch + 2] compact used-channel records
-    float* band;    // [T, n_ch, band_len] Toeplitz band images (LDS-DMA staging of the wave kernel)
     size_t bytes;
 };
 
@@ -922,7 +818,6 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
     ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
-    ws.band = (float*)(p + o);   o += align_up(T * n_ch * (size_t)mf_band_len((int)L) * sizeof(float) + 64, 256);
     ws.bytes = o;
     return ws;
 }
@@ -1020,12 +915,6 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         mf_template_energy_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
             d_templates, n, (int)L, ws.e_t);
         BPMF_LAUNCH_CHECK();
-        if (getenv("BPMF_MF_DMA") && atoi(getenv("BPMF_MF_DMA")) && mf_kpad((int)L) <= 272) {   // LDS-DMA staging (experiment)
-            const size_t nb = n * (size_t)mf_band_len((int)L);
-            mf_band_image_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream>>>(
-                d_templates, n, (int)L, mf_band_len((int)L), ws.band);
-            BPMF_LAUNCH_CHECK();
-        }
         mf_range_kernel<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, stream>>>(
             d_moveouts, d_weights, ws.e_t, (int)T, (int)n_ch, (long long)step, (long long)L,
             (long long)N, (long long)n_corr, ws.range, ws.chan_rec);
@@ -1035,16 +924,14 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
 
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
-    size_t lds = mf_lds_bytes((int)L);
-    if (const char* ex = getenv("BPMF_MF_LDS_EXTRA_KB")) lds += (size_t)atoi(ex) * 1024;  // occupancy experiments
+    const size_t lds = mf_lds_bytes((int)L);
     // the MFMA kernels evaluate every data-sample offset and keep the multiples of `step`
     const size_t n_offsets = (n_corr - 1) * step + 1;
     const size_t n_lag_blocks = (n_offsets + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
     // staging registers needed per thread (window / band), rounded to a compiled variant
     const int need_r = (mf_window_len((int)L) + MF_THREADS - 1) / MF_THREADS;
     const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
-    const char* mse = getenv("BPMF_MF_MAX_MFMA_STEP");
-    const size_t max_mfma_step = mse ? (size_t)atoi(mse) : 64;  // beyond this the direct kernel wins
+    const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);  // beyond this (64) the direct kernel wins
     // (the MFMA kernels address the data through buffer descriptors with 32-bit byte offsets:
     // traces of 2^30 samples or more take the generic kernel)
     const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
@@ -1054,11 +941,6 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         // 8 XCDs x ceil(n_lag_blocks / 8) lag blocks x T templates (mf_tile_of_block)
         dim3 grid((unsigned)(T * 8 * ((n_lag_blocks + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
-        const char* abl = getenv("BPMF_MF_ABLATE");  // kernel-phase ablation, profiling only
-        const int ablate = abl ? atoi(abl) : 0;
-        const char* tbe = getenv("BPMF_MF_TBATCH");
-        int t_batch = tbe ? atoi(tbe) : (int)T;
-        if (t_batch < 1 || t_batch > (int)T) t_batch = (int)T;
 #define BPMF_MF_LAUNCH2(NS, R, TT, S1)                                                            \
     do {                                                                                              \
         auto kfn = mf_mfma_kernel<NS, R, TT, S1>;                                                     \
@@ -1067,31 +949,19 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         kfn<<<grid, dim3(MF_THREADS), lds, stream>>>(                                                 \
             d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,         \
-            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, t_batch, (int)n_lag_blocks);   \
+            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks);                     \
     } while (0)
 #define BPMF_MF_LAUNCH(NS, R, TT) \
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
-        const char* wke = getenv("BPMF_MF_WAVE_KERNEL");
-        const bool wave_kernel = (wke ? atoi(wke) != 0 : true) && mf_kpad((int)L) <= 272;
+        const bool wave_kernel = option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
             dim3 grid_w = grid;
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
-            const char* dme = getenv("BPMF_MF_DMA");
-            const bool use_dma = dme && atoi(dme) != 0;
-            const float* band_arg = use_dma ? ws.band : nullptr;
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                           \
-    do {                                                                                         \
-        mf_mfma_wave_kernel<NS, 20, 5, S1, false><<<grid_w, dim3(MF_THREADS), wl, stream>>>(     \
-            d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,    \
-            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks,        \
-            band_arg);                                                                           \
-        if (use_dma)                                                                             \
-            mf_mfma_wave_kernel<NS, 20, 5, S1, true><<<grid_w, dim3(MF_THREADS), wl, stream>>>(  \
-                d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T, \
-                (int)n_ch, (long long)n_corr, (int)step, d_cc_out, ablate, (int)n_lag_blocks,    \
-                band_arg);                                                                 \
-    } while (0)
+    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid_w, dim3(MF_THREADS), wl, stream>>>(                \
+        d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks)
             if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
             else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);
@@ -1165,12 +1035,11 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     BPMF_BIND_DEVICE(device);
     const size_t n_ch = S * C;
     const size_t row_bytes = n_corr * (network_sum ? 1 : n_ch) * sizeof(float);   // per template
-    // BPMF_MF_HOST_BATCH_KB / BPMF_MF_HOST_PIECE_KB: sizes of a batch's output and of a pinned piece
+    // options mf.host_batch_kb / mf.host_piece_kb: sizes of a batch's output and of a pinned piece
     // (defaults 1 GB / 64 MB; the tests shrink them to cross every batch and piece boundary)
-    const char* e_b = getenv("BPMF_MF_HOST_BATCH_KB");
-    const char* e_p = getenv("BPMF_MF_HOST_PIECE_KB");
-    const size_t batch_bytes = e_b && atoll(e_b) > 0 ? (size_t)atoll(e_b) << 10 : (size_t)1 << 30;
-    const size_t PIECE = e_p && atoll(e_p) > 0 ? (size_t)atoll(e_p) << 10 : (size_t)64 << 20;
+    const long e_b = option(OPT_MF_HOST_BATCH_KB), e_p = option(OPT_MF_HOST_PIECE_KB);
+    const size_t batch_bytes = e_b > 0 ? (size_t)e_b << 10 : (size_t)1 << 30;
+    const size_t PIECE = e_p > 0 ? (size_t)e_p << 10 : (size_t)64 << 20;
     size_t TB = std::max<size_t>(1, batch_bytes / std::max<size_t>(row_bytes, 1));
     if (!e_b) TB = std::max<size_t>(TB, 8);   // a launch of fewer templates wastes the device
     TB = std::min(T, TB);
@@ -1218,7 +1087,7 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
         if (!r) MF_TRY(hipEventRecord(ev_batch[b & 1], s_run), "event record");
         return r;
     };
-    const bool verbose = getenv("BPMF_MF_VERBOSE") != nullptr;
+    const bool verbose = option(OPT_MF_VERBOSE) != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_wait = 0.0, t_copy = 0.0;

@@ -2,6 +2,7 @@
 #include "common.h"
 #include "../../include/bpmf_hip.h"
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 
@@ -22,6 +23,83 @@ void set_error(const char* fmt, ...)
 }
 
 }  // namespace bpmf
+
+// ---- execution options (see common.h: identical results whatever their values) ----
+namespace bpmf {
+namespace {
+struct OptionDef { const char* name; long dflt; long lo, hi; };
+const OptionDef OPTION_DEFS[OPT_COUNT] = {
+    {"bp.lds_kb", 80, 8, 160},          // soft LDS budget of a group (single-window plans)
+    {"bp.max_group", 4096, 1, 1 << 20}, // sources per group at most
+    {"bp.tpt", 2, 1, 4},                // samples per thread of the generic kernels (tile = 256 x tpt)
+    {"bp.reorder", 1, 0, 1},            // kd-tree processing order of the sources
+    {"bp.dual", 1, 0, 1},               // dual (shifted) windows + 8-byte gathers where they fit
+    {"bp.packed", 1, 0, 1},             // packed per-station records (P = 2)
+    {"bp.wps", 1, 0, 1},                // wave-per-source kernels
+    {"bp.uvgpr", 1, 0, 1},              // uniform-VGPR metadata kernels
+    {"bp.fast", 1, 0, 1},               // interior-tile kernel of bp_fast.hip
+    {"bp.fast_uniform", 1, 0, 1},       // ready-made addresses when a source's weights are uniform
+    {"bp.split", -1, -1, 1 << 16},      // group ranges per tile: -1 = automatic (short series)
+    {"bp.wpb", 12, 8, 12},              // waves per workgroup of the 4-byte-gather kernel
+    {"bp.smeta", 1, 0, 1},              // SGPR metadata for 32-station records
+    {"bp.verbose", 0, 0, 1},
+    {"mf.wave_kernel", 1, 0, 1},        // independent-wave kernel for L <= 257
+    {"mf.max_mfma_step", 64, 0, 1 << 20},  // larger steps take the generic kernel
+    {"mf.host_batch_kb", 0, 0, 1L << 30},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
+    {"mf.host_piece_kb", 0, 0, 1L << 30},  // host-pointer call: pinned piece (0 = 64 MB)
+    {"mf.verbose", 0, 0, 1},
+};
+std::atomic<long> g_options[OPT_COUNT];
+std::once_flag g_options_once;
+void init_options()
+{
+    for (int i = 0; i < OPT_COUNT; ++i) g_options[i].store(OPTION_DEFS[i].dflt, std::memory_order_relaxed);
+}
+int find_option(const char* name)
+{
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(name, OPTION_DEFS[i].name) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+long option(Option which)
+{
+    std::call_once(g_options_once, init_options);
+    return g_options[which].load(std::memory_order_relaxed);
+}
+}  // namespace bpmf
+
+extern "C" int bpmf_set_option(const char* name, long value)
+{
+    std::call_once(bpmf::g_options_once, bpmf::init_options);
+    const int i = bpmf::find_option(name);
+    if (i < 0) {
+        bpmf::set_error("bpmf_set_option: unknown option '%s'", name ? name : "(null)");
+        return -1;
+    }
+    const bpmf::OptionDef& d = bpmf::OPTION_DEFS[i];
+    if (value < d.lo || value > d.hi) {
+        bpmf::set_error("bpmf_set_option: %s = %ld outside [%ld, %ld]", d.name, value, d.lo, d.hi);
+        return -1;
+    }
+    bpmf::g_options[i].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int bpmf_get_option(const char* name, long* value, long* default_value)
+{
+    std::call_once(bpmf::g_options_once, bpmf::init_options);
+    const int i = bpmf::find_option(name);
+    if (i < 0) {
+        bpmf::set_error("bpmf_get_option: unknown option '%s'", name ? name : "(null)");
+        return -1;
+    }
+    if (value) *value = bpmf::g_options[i].load(std::memory_order_relaxed);
+    if (default_value) *default_value = bpmf::OPTION_DEFS[i].dflt;
+    return 0;
+}
 
 // ---- optional per-kernel timing (bench.py's roofline leg) -------------------------
 // Every launch of a dominant kernel gets its own start/stop event pair, recorded on the

@@ -20,3 +20,23 @@ def oracle_lib():
     if not os.path.exists(path):
         oracle.build()
     return oracle
+
+
+@pytest.fixture
+def hip_opts():
+    """Set execution options of libbpmf_hip.so (bpmf_set_option: kernel family, plan sizes, ... --
+    never a result); everything touched goes back to its default when the test ends."""
+    from seismic_bpmf_amd import _lib
+    touched = set()
+
+    def set_(name, value):
+        touched.add(name)
+        _lib.set_option(name, value)
+
+    def reset(name):
+        _lib.set_option(name, _lib.get_option(name)[1])
+
+    set_.reset = reset
+    yield set_
+    for name in touched:
+        reset(name)

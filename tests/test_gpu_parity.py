@@ -209,12 +209,12 @@ def test_device_resident_api_matches_host_api():
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch_kb,piece_kb", [(64, 16), (200, 1000), (1, 1), (10_000, 7)])
 @pytest.mark.parametrize("network_sum", [True, False])
-def test_mf_host_api_batches_and_pieces(oracle_lib, batch_kb, piece_kb, network_sum, monkeypatch):
+def test_mf_host_api_batches_and_pieces(oracle_lib, batch_kb, piece_kb, network_sum, hip_opts):
     """bpmf_mf_run pipelines template batches and pinned pieces; shrink both so that a small case
     crosses every boundary (last batch / last piece shorter, one template per batch, ...)."""
     from seismic_bpmf_amd import matched_filter
-    monkeypatch.setenv("BPMF_MF_HOST_BATCH_KB", str(batch_kb))
-    monkeypatch.setenv("BPMF_MF_HOST_PIECE_KB", str(piece_kb))
+    hip_opts("mf.host_batch_kb", batch_kb)
+    hip_opts("mf.host_piece_kb", piece_kb)
     rng = np.random.default_rng(batch_kb + piece_kb)
     T, S, C, L, N = 7, 3, 2, 40, 9000 if network_sum else 2500
     tp = rng.standard_normal((T, S, C, L)).astype(np.float32)

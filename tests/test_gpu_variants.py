@@ -33,11 +33,11 @@ def test_mf_template_length_variants(oracle_lib, L):
         _same(got, oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"MF L={L} network_sum={ns}")
 
 
-@pytest.mark.parametrize("wave_kernel", ["0", "1"])
-def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, monkeypatch):
+@pytest.mark.parametrize("wave_kernel", [0, 1])
+def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, hip_opts):
     """L <= 257 defaults to the independent-wave kernel; the workgroup kernel must agree too."""
     from seismic_bpmf_amd import matched_filter
-    monkeypatch.setenv("BPMF_MF_WAVE_KERNEL", wave_kernel)
+    hip_opts("mf.wave_kernel", wave_kernel)
     rng = np.random.default_rng(77)
     T, S, C, L, N = 3, 5, 3, 200, 30_000
     tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
@@ -52,13 +52,11 @@ def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, monkeypatch):
 
 @pytest.mark.parametrize("L", [48, 130, 256, 257])
 @pytest.mark.parametrize("step", [1, 3])
-def test_mf_lds_dma_staging_variant(oracle_lib, L, step, monkeypatch):
-    """BPMF_MF_DMA=1: interior waves stage window and band by LDS-DMA (padded-slot source mapping,
-    band image from the workspace), the waves at the ends of a template's valid lag range run the
-    register-staged variant in a second launch; together bit-identical to the oracle, negative
-    moveouts, zero-weight channels and both output layouts included."""
+def test_mf_negative_moveouts_zero_weights_steps(oracle_lib, L, step):
+    """Negative moveouts, zero-weight channels, both output layouts, steps 1 and 3 at four template
+    lengths (the inputs that exposed the buffer-load zero-fill defect in round 2, when they drove
+    an LDS-DMA staging experiment since removed)."""
     from seismic_bpmf_amd import matched_filter
-    monkeypatch.setenv("BPMF_MF_DMA", "1")
     rng = np.random.default_rng(1000 + L + step)
     T, S, C, N = 3, 4, 3, 41_000
     tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
@@ -68,12 +66,12 @@ def test_mf_lds_dma_staging_variant(oracle_lib, L, step, monkeypatch):
     d = rng.standard_normal((S, C, N)).astype(np.float32)
     for ns in (True, False):
         _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
-              oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"DMA staging L={L} step={step} ns={ns}")
+              oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"L={L} step={step} ns={ns}")
 
 
 @pytest.mark.parametrize("L", [48, 64, 300, 1100])
 @pytest.mark.parametrize("first", [-1, -2, -3, -74, -253, -271, -1023, -1025])
-def test_mf_first_samples_of_the_trace_with_negative_moveouts(oracle_lib, L, first, monkeypatch):
+def test_mf_first_samples_of_the_trace_with_negative_moveouts(oracle_lib, L, first, hip_opts):
     """A template whose most negative moveout is not a multiple of 4 has its first valid lags read
     samples 0..2 of the trace through staging loads whose neighbours lie before the trace: on gfx950 a
     raw buffer load WITH an immediate offset zeroes the whole 4-lane group there
@@ -88,8 +86,8 @@ def test_mf_first_samples_of_the_trace_with_negative_moveouts(oracle_lib, L, fir
     mv[1, 2, 0] = first + 1 if first < -1 else first
     w = (rng.random((T, S, C)) + 0.1).astype(np.float32)
     d = rng.standard_normal((S, C, N)).astype(np.float32)
-    for wave in ("1", "0"):
-        monkeypatch.setenv("BPMF_MF_WAVE_KERNEL", wave)
+    for wave in (1, 0):
+        hip_opts("mf.wave_kernel", wave)
         for step in (1, 2):
             for ns in (True, False):
                 _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
@@ -194,14 +192,14 @@ def test_bp_term_count_variants(oracle_lib, S, P, density, label):
     _bp_check(oracle_lib, f, tau, wp, ws, label)
 
 
-@pytest.mark.parametrize("env", [{"BPMF_BP_WPS": "0"}, {"BPMF_BP_UVGPR": "0"}, {"BPMF_BP_PACKED": "0"},
-                                 {"BPMF_BP_TPT": "1", "BPMF_BP_WPS": "0"}, {"BPMF_BP_TPT": "4", "BPMF_BP_WPS": "0"},
-                                 {"BPMF_BP_REORDER": "0"}, {"BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "5"},
-                                 {"BPMF_BP_DUAL": "0"}, {"BPMF_BP_DUAL": "0", "BPMF_BP_WPB": "8"},
-                                 {"BPMF_BP_DUAL": "0", "BPMF_BP_LDS_KB": "24"}, {"BPMF_BP_MAX_GROUP": "3"}])
-def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
+@pytest.mark.parametrize("env", [{"bp.wps": 0}, {"bp.uvgpr": 0}, {"bp.packed": 0},
+                                 {"bp.tpt": 1, "bp.wps": 0}, {"bp.tpt": 4, "bp.wps": 0},
+                                 {"bp.reorder": 0}, {"bp.lds_kb": 24}, {"bp.max_group": 5},
+                                 {"bp.dual": 0}, {"bp.dual": 0, "bp.wpb": 8},
+                                 {"bp.dual": 0, "bp.lds_kb": 24}, {"bp.max_group": 3}])
+def test_bp_kernel_and_plan_knobs(oracle_lib, env, hip_opts):
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        hip_opts(k, v)
     rng = np.random.default_rng(99)
     f, tau, wp, ws = _bp_inputs(rng, 200, 8, 2, 3000, 250, 0.7)
     _bp_check(oracle_lib, f, tau, wp, ws, str(env))
@@ -211,12 +209,12 @@ def test_bp_kernel_and_plan_knobs(oracle_lib, env, monkeypatch):
                                                         ("1", 20, 17, 4, 16), ("1", 20, 20, 4, 16),
                                                         ("1", 34, 31, 4, 16), ("1", 34, 32, 4, 16),
                                                         ("1", 34, 33, 4, 8)])
-def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, waves, monkeypatch):
+def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, waves, hip_opts):
     """Dual (8-byte gather) plans for <= 16 weighted stations per source, 4-byte gathers otherwise;
     both must give the oracle's result, ties included (many equal beams: integer-valued features)."""
     import torch
     from seismic_bpmf_amd import BeamformerGPU
-    monkeypatch.setenv("BPMF_BP_DUAL", dual)
+    hip_opts("bp.dual", int(dual))
     rng = np.random.default_rng(5 + S_used)
     K, P, N = 400, 2, 4000
     f = rng.integers(0, 3, (S, 3, N)).astype(np.float32)      # exact ties between sources
@@ -264,12 +262,12 @@ def test_bad_arguments_raise_with_a_message():
 @pytest.mark.parametrize("n_used,uniform", [(1, True), (3, True), (4, False), (7, True), (10, False),
                                             (13, True), (16, True), (16, False)])
 @pytest.mark.parametrize("oob", ["strict", "flexible"])
-def test_bp_fast_path_station_counts_and_weight_kinds(oracle_lib, n_used, uniform, oob, monkeypatch):
+def test_bp_fast_path_station_counts_and_weight_kinds(oracle_lib, n_used, uniform, oob, hip_opts):
     """bp_beam_fast_kernel (csrc/bp_fast.hip): every station-count class 4..16 (1-3 stations are
     padded to 4 with zero-slab terms), uniform weights (ready-made address records) and per-station
     weights (packed records), mixed counts inside a group (several runs), a source without any
     station, negative moveouts (edge tiles at the START of the trace as well), exact ties; against
-    the oracle and against the general kernel (BPMF_BP_FAST=0), bit for bit."""
+    the oracle and against the general kernel (option bp.fast = 0), bit for bit."""
     from seismic_bpmf_amd import BeamformerGPU
     rng = np.random.default_rng(100 * n_used + int(uniform))
     K, S, C, P, N = 700, 18, 3, 2, 9000
@@ -287,7 +285,7 @@ def test_bp_fast_path_station_counts_and_weight_kinds(oracle_lib, n_used, unifor
     ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
     got = {}
     for fast in ("1", "0"):
-        monkeypatch.setenv("BPMF_BP_FAST", fast)
+        hip_opts("bp.fast", int(fast))
         bf = BeamformerGPU(tau, ws)
         b, a = bf.run(f, wp, "max", oob)
         got[fast] = (b.cpu().numpy(), a.cpu().numpy())
@@ -314,7 +312,7 @@ def test_bp_fast_path_short_traces_have_no_interior_tiles(oracle_lib):
 
 
 @pytest.mark.parametrize("N", [300, 1500, 3000, 6000, 20_000])
-def test_bp_short_series_split_into_group_ranges(oracle_lib, N, monkeypatch):
+def test_bp_short_series_split_into_group_ranges(oracle_lib, N, hip_opts):
     """A series of a few tiles (the reference's event relocation beamforms 1 500-3 000 samples over the
     whole grid, BPMF/dataset.py:2174-2216) is computed by several workgroups per tile, each walking a
     range of the plan's source groups; reduce="max" folds partial maxima (value, then lowest id),
@@ -331,10 +329,7 @@ def test_bp_short_series_split_into_group_ranges(oracle_lib, N, monkeypatch):
     try:
         assert bf.plan_info()["n_groups"] >= 4
         for split in (None, "1", "2", "7", "1000"):
-            if split is None:
-                monkeypatch.delenv("BPMF_BP_SPLIT", raising=False)
-            else:
-                monkeypatch.setenv("BPMF_BP_SPLIT", split)
+            hip_opts("bp.split", -1 if split is None else int(split))
             for oob in ("strict", "flexible"):
                 mb, ma = bf.run(f, wp, "max", oob)
                 assert np.array_equal(mb.cpu().numpy(), want[oob][0]), (N, split, oob)
@@ -342,10 +337,7 @@ def test_bp_short_series_split_into_group_ranges(oracle_lib, N, monkeypatch):
         if N <= 3000:
             full = oracle_lib.beamform(f, tau, wp, ws, "strict", "none")
             for split in (None, "5"):
-                if split is None:
-                    monkeypatch.delenv("BPMF_BP_SPLIT", raising=False)
-                else:
-                    monkeypatch.setenv("BPMF_BP_SPLIT", split)
+                hip_opts("bp.split", -1 if split is None else int(split))
                 assert np.array_equal(bf.run(f, wp, "none", "strict").cpu().numpy(), full), (N, split)
     finally:
         bf.close()

@@ -6,7 +6,7 @@ from seismic_bpmf_amd import synthetic as syn
 t0 = time.time(); geo = syn.make_bp_geometry((125, 125, 64), 40, 2, 100.0, n_closest=10); t1 = time.time()
 K = geo["moveouts"].shape[0]
 print(f"geometry K={K}: {t1-t0:.1f}s, max moveout {geo['moveouts'].max()}")
-os.environ["BPMF_BP_VERBOSE"] = "1"
+from seismic_bpmf_amd import _lib; _lib.set_option("bp.verbose", 1)
 t0 = time.time(); b = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"]); t1 = time.time()
 print(f"plan: {t1-t0:.1f}s")
 N = 500_000

@@ -17,12 +17,9 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 feat = torch.randn((cfg["S"], cfg["C"], cfg["N"]), device="cuda", generator=g).abs_()
 wp = torch.as_tensor(syn.phase_weights(cfg["S"], cfg["C"], cfg["P"]), device="cuda")
 res = {}
-# timing ablations of the interior kernel are compile-time (-DBPF_DBG=<bits>, csrc/bp_fast.hip):
-# tools/ablate_bp_fast.sh builds the variants and runs this script against each (BPMF_HIP_LIB)
-dbg = os.environ.get("BPF_DBG_LABEL", "0")
-variants = [("0", dbg), ("1", dbg)] if dbg == "0" else [("1", dbg)]
-for fast, dbg in variants:
-    os.environ["BPMF_BP_FAST"] = fast
+dbg = "0"
+for fast, dbg in [("0", dbg), ("1", dbg)]:
+    _lib.set_option("bp.fast", int(fast))
     bf = sb.BeamformerGPU(geo["moveouts"], geo["weights_sources"])
     b, a = bf.run(feat, wp, "max", "strict")
     torch.cuda.synchronize()
