@@ -50,6 +50,7 @@ def parse():
                     help="default: cfg2 (configs[1]) on one GPU, cfg4_per_gpu (configs[3]'s share) on N > 1")
     ap.add_argument("--bp-config", default=None,
                     help="default: cfg3 (configs[2]) on one GPU, cfg5_per_gpu (configs[4]'s share) on N > 1")
+    ap.add_argument("--skip-dense", action="store_true", help="skip the dense-station-weight BP extras")
     ap.add_argument("--skip-e2e", action="store_true", help="skip the host-pointer end-to-end extra")
     ap.add_argument("--skip-bp", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
@@ -590,6 +591,49 @@ def main():
                                     "equals_resident_result": bool(np.array_equal(hb, beam.cpu().numpy()) and
                                                                    np.array_equal(ha, arg.cpu().numpy()))}
             del h_f, hb, ha
+        if rank == 0 and world == 1 and not args.skip_dense:
+            # untimed extras: DENSE station weights -- BASELINE's literal "x 20 / x 40 stations", what
+            # _weights_sources_closest returns for num_closest_stations >= n_stations
+            # (BPMF/template_search.py:779-798): every station of every source weighted.  Round 3: these
+            # run the 8-byte-gather kernel on tiles of 256 / 128 samples (csrc/bp_fast.hip).
+            del beam, arg
+            bp_obj["dense"] = {}
+            for name, reps in (("cfg3", 3), ("cfg5_per_gpu", 1)):
+                dcfg = dict(syn.BP_CONFIGS[name])
+                if name == args.bp_config:
+                    dgeo, dfeat, dwp = geo, feat, wp
+                else:
+                    del feat
+                    torch.cuda.empty_cache()
+                    dgeo, dfeat, dwp = bp_inputs(dcfg, device, 20260928, 0, 1)
+                    feat = dfeat
+                ws_dense = np.full(dgeo["weights_sources"].shape, 1.0 / dcfg["S"], dtype=np.float32)
+                t0 = time.perf_counter()
+                dbf = sb.BeamformerGPU(dgeo["moveouts"], ws_dense, device=local_rank)
+                plan_s = time.perf_counter() - t0
+                dbeam, darg = dbf.run(dfeat, dwp, "max", "strict")
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                for _ in range(reps):
+                    dbf.run(dfeat, dwp, "max", "strict", out=(dbeam, darg))
+                torch.cuda.synchronize()
+                _lib.profile_enable(False)
+                dms = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_BP_BEAM)))
+                dK = dgeo["moveouts"].shape[0]
+                dtbs = 4.0 * dcfg["S"] * dcfg["P"] * dK * dcfg["N"] / (dms * 1e-3) / 1e12
+                dinfo = dbf.plan_info()
+                dpeak = LDS_B32_PEAK_TBS * (2.0 if dinfo["gather_bytes"] == 8 else 1.0)
+                bp_obj["dense"][name] = {
+                    "workload": f"{dK} sources x {dcfg['S']} stations (ALL weighted) x {dcfg['P']} phases, N={dcfg['N']}, "
+                                "reduce=max, strict",
+                    "ms": round(dms, 2), "value": dK * dcfg["N"] / (dms * 1e-3), "unit": "grid-points x samples / s",
+                    "launches": reps, "plan_seconds": round(plan_s, 3),
+                    "roofline": {"kernel": f"bp_beam_fast_kernel<tile {dinfo['tile']}>" if dinfo["n_classes"] else "general kernels",
+                                 "bound": "lds-gather", "achieved": round(dtbs, 2), "peak": round(dpeak, 1), "unit": "TB/s",
+                                 "frac": round(dtbs / dpeak, 4), "plan": dinfo,
+                                 "algorithmic": "4*S*P gathered bytes per grid-point x sample"}}
+                dbf.close()
+                del dbeam, darg
         if rank == 0 and world == 1 and not args.skip_cpu:
             bp_obj["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
 

@@ -60,7 +60,7 @@ int bpmf_profile_get_ms(int which_kernel, int launch_index, float *milliseconds)
  * family through the same parity cases, tools/ to measure alternatives.  Process-wide, thread
  * safe; plans already built keep the variant they were built with.  Names:
  *   bp.lds_kb bp.max_group bp.tpt bp.reorder bp.dual bp.packed bp.wps bp.uvgpr bp.fast
- *   bp.fast_uniform bp.split bp.wpb bp.smeta bp.verbose
+ *   bp.fast_uniform bp.fast_tile bp.split bp.wpb bp.smeta bp.verbose
  *   mf.wave_kernel mf.max_mfma_step mf.host_batch_kb mf.host_piece_kb mf.verbose
  * (The reference's counterpart is the `device=` / `arch=` string it forwards to the third-party
  * back-ends, BPMF/similarity_search.py:532, BPMF/template_search.py:554.)
@@ -143,6 +143,13 @@ typedef struct {
     int32_t gather_bytes;  /* 8: dual (shifted) windows + ds_read_b64 gathers; 4: 4-byte gathers */
     int32_t stations_max;  /* padded station slots per source of the packed kernel (0: generic kernel) */
     int32_t waves_per_cu;  /* resident waves per CU of the beam kernel this plan dispatches to */
+    /* reduce="max": the interior tiles of a two-phase grid run the 8-byte-gather kernel once per
+     * station-count class of sources (<= 16, 17..32, 33..64 weighted stations), each class on the
+     * largest tile (512 / 256 / 128 samples) at which its dual windows fit the LDS.  0 classes: the
+     * general kernels compute everything.  With classes, tile / n_groups / lds_bytes above describe
+     * the class that holds most sources. */
+    int32_t n_classes;
+    int32_t class_tile[3], class_sources[3], class_groups[3], class_stations_max[3];
 } bpmf_bp_plan_stats;
 int bpmf_bp_plan_info(const bpmf_bp_plan *plan, bpmf_bp_plan_stats *out);
 

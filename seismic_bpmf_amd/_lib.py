@@ -19,8 +19,10 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bpmf_hip.h
 class BpPlanStats(C.Structure):
     """bpmf_bp_plan_stats of include/bpmf_hip.h."""
-    _fields_ = [(n, C.c_int32) for n in ("n_groups", "tile", "lds_bytes", "gather_bytes",
-                                         "stations_max", "waves_per_cu")]
+    _fields_ = ([(n, C.c_int32) for n in ("n_groups", "tile", "lds_bytes", "gather_bytes",
+                                          "stations_max", "waves_per_cu", "n_classes")] +
+                [(n, C.c_int32 * 3) for n in ("class_tile", "class_sources", "class_groups",
+                                              "class_stations_max")])
 
 
 SIGNATURES = {

@@ -110,7 +110,11 @@ class BeamformerGPU:
         """Shape of the device plan: dict of bpmf_bp_plan_stats (include/bpmf_hip.h)."""
         st = _lib.BpPlanStats()
         _lib.check(self.lib.bpmf_bp_plan_info(self._plan, C.byref(st)), "bpmf_bp_plan_info")
-        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+        out = {}
+        for n, _ in st._fields_:
+            v = getattr(st, n)
+            out[n] = int(v) if isinstance(v, int) else [int(x) for x in v]
+        return out
 
     def close(self):
         if getattr(self, "_plan", None) is not None and self._plan.value:

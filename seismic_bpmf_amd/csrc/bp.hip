@@ -106,13 +106,13 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int* __restrict__ srcs,
     const int* __restrict__ term_off, const float* __restrict__ term_beta, int NT,
-    int id_offset, float* __restrict__ out_beam, int* __restrict__ out_arg)
+    int id_offset, float* __restrict__ out_beam, int* __restrict__ out_arg, long long tile_base)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     constexpr int TILE = BP_THREADS * TPT;
-    const long long t0 = (long long)blockIdx.x * TILE;
+    const long long t0 = (tile_base + (long long)blockIdx.x) * TILE;
 
     float best[TPT];
     int arg[TPT];
@@ -269,13 +269,13 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg)
+    int* __restrict__ out_arg, long long tile_base)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     constexpr int TILE = BP_THREADS * TPT;
-    const long long t0 = (long long)blockIdx.x * TILE;
+    const long long t0 = (tile_base + (long long)blockIdx.x) * TILE;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     const char* lds_t = (const char*)lds + tid * 4;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg)
+    int* __restrict__ out_arg, long long tile_base)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const int wv = tid >> 6;
     constexpr int NW = BP_THREADS / 64;
     constexpr int TILE = 64 * TPW;
-    const long long t0 = (long long)blockIdx.x * TILE;
+    const long long t0 = (tile_base + (long long)blockIdx.x) * TILE;
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     // sample j of this lane inside the tile
@@ -653,8 +653,6 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = tid >> 8;        // staging sub-group of 256 threads
-    const int stid = tid & 255;
     // Consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each): give every XCD a
     // contiguous run of tiles, so that each L2 stages its own eighth of the prestack instead of
     // all of it.  (The grid is rounded up to a multiple of 8; tiles past N see only zero fill.)
@@ -950,12 +948,15 @@ __device__ __forceinline__ float ordered_to_f32(unsigned k)
 
 // reduce="max" of a short series computed in `n_split` group ranges per tile: fold the partial
 // (beam, arg) rows -- larger beam wins, lowest source id on equal beams, the rule of every other merge
+// Interior samples [lo_s, hi_s) hold `rows` partial rows (station-count classes x group ranges), the
+// edge samples around them -- computed by the general kernel over all sources -- `rows_edge`.
 __global__ void bp_merge_splits_kernel(const float* __restrict__ pbeam, const int* __restrict__ parg,
-                                       int n_split, size_t N, float* __restrict__ beam,
-                                       int* __restrict__ arg)
+                                       int rows, int rows_edge, long long lo_s, long long hi_s,
+                                       size_t N, float* __restrict__ beam, int* __restrict__ arg)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    const int n_split = ((long long)i >= lo_s && (long long)i < hi_s) ? rows : rows_edge;
     float b = pbeam[i];
     int a = parg[i];
     for (int y = 1; y < n_split; ++y) {
@@ -1039,8 +1040,9 @@ void bisect_order(const int32_t* mv, size_t SP, std::vector<int>& idx, size_t lo
 // dual: every window is staged twice, the second copy shifted by one sample, both at even
 // offsets; a term whose offset into the window is odd reads the shifted copy, so that ALL emitted
 // offsets are even (8-byte aligned pairs for the ds_read_b64 kernel).
-bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P, int tile,
-                int chunk, size_t soft_floats, const size_t hard_floats, int max_group, bool reorder,
+// `order_in`: the sources of this plan in processing order (all of them, or one station-count class).
+bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& order_in, size_t S, size_t P,
+                int tile, int chunk, size_t soft_floats, const size_t hard_floats, int max_group,
                 int32_t id_offset, bool dual, PlanHost& ph)
 {
     // a window is staged in 16-byte lanes: its length is rounded up to a multiple of 4 floats
@@ -1048,9 +1050,11 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     auto row_len = [&](int spread) -> size_t { return ((size_t)tile + (size_t)spread + 3) & ~(size_t)3; };
     auto row_cost = [&](int spread) -> size_t { return dual ? 2 * row_len(spread) : row_len(spread); };
     const size_t SP = S * P;
-    std::vector<int> order(K);
-    for (size_t k = 0; k < K; ++k) order[k] = (int)k;
-    if (reorder) bisect_order(mv, SP, order, 0, K, 16);
+    std::vector<int> order = order_in;
+    const size_t K = order.size();
+    // the zero slab: one tile of the generic kernels, a fixed 512 floats in front of the
+    // descriptor slab of the dual plans (bp_fast.hip, any tile)
+    const size_t zero_slab = dual ? (size_t)BPF_ZERO_SLAB : (size_t)tile;
 
     size_t max_terms = 1;
     ph.srcs.resize(K);
@@ -1081,7 +1085,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     // dual plans (bp_fast.hip) keep 4 KB behind the zero slab for the next group's window descriptors
     // (16 bytes per window; a group has at most 2 S P windows)
     const size_t slab_extra = dual ? (size_t)4 * std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64) : 0;
-    const size_t base_need = (size_t)tile + slab_extra + max_terms * row_cost(0);
+    const size_t base_need = zero_slab + slab_extra + max_terms * row_cost(0);
     // More than 16 stations (P = 2: 32 terms): the packed kernel runs one 16-wave workgroup per CU.
     if (base_need + max_terms * (row_cost(16) - row_cost(0)) > soft_floats || (P == 2 && max_terms > 32))
         soft_floats = hard_floats;
@@ -1096,7 +1100,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
     size_t first = 0;
     while (first < K) {
         std::fill(used.begin(), used.end(), 0);
-        size_t need = (size_t)tile + slab_extra, q = first;  // the zero slab (+ the descriptor slab)
+        size_t need = zero_slab + slab_extra, q = first;  // the zero slab (+ the descriptor slab)
         for (; q < K && (int)(q - first) < max_group; ++q) {
             const size_t k = (size_t)order[q];
             size_t need2 = need;
@@ -1131,7 +1135,7 @@ bool build_plan(const int32_t* mv, const float* ws, size_t K, size_t S, size_t P
         }
         // close group [first, q): lay the windows out after the zero slab, cut them in chunks
         BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
-        size_t o = (size_t)tile + slab_extra;
+        size_t o = zero_slab + slab_extra;
         for (size_t r = 0; r < SP; ++r) {
             base[r] = -1;
             if (!used[r]) continue;
@@ -1186,6 +1190,171 @@ int upload(const std::vector<Tv>& v, Tv** d)
 
 }  // namespace
 
+namespace {
+
+// ---- interior-tile fast path: host-side tables of one station-count class (bp_fast.hip) ----
+struct FastHost {
+    std::vector<BpFastGroup> fg;
+    std::vector<BpRun> fr;
+    std::vector<BpWindow> fw;
+    std::vector<int> rec;
+    bool uniform = true;
+    int rec_dw = 0, max_sta = 0;
+    size_t n_sources = 0;
+};
+
+// A source of `n` (even-padded) stations as `nparts` records of `tp` stations for the kernel of
+// this tile: the smallest padded total + 2 per part, then the fewest parts.  Part sizes the kernels instantiate:
+// tile 512: 4..16 even, one part; tile 256: 6..16 even; tile 128: 8, 12, 16, 20, 24.
+bool fast_parts(int n, int tile, int& tp, int& nparts)
+{
+    static const int t512[] = {4, 6, 8, 10, 12, 14, 16}, t256[] = {6, 8, 10, 12, 14, 16}, t128[] = {8, 12, 16, 20, 24};
+    const int* opts = tile == 512 ? t512 : (tile == 256 ? t256 : t128);
+    const int n_opts = tile == 512 ? 7 : (tile == 256 ? 6 : 5);
+    // A part boundary costs about as much as two stations at tiles 512 / 256 (header, refill
+    // pipeline restart).  At tile 128 a unit is a whole quad of the record and the distance between
+    // the request of a quad and its first use is (quads per part - 3) units: short parts stall on
+    // the record loads (5 parts of 8 stations: 0.26 of the gather rate at cfg5's share) -- prefer
+    // the longest parts.
+    const int part_cost = tile == 128 ? 8 : 2;
+    int best_total = 1 << 30;
+    tp = 0;
+    nparts = 0;
+    for (int i = 0; i < n_opts; ++i) {
+        const int k = std::max(1, (n + opts[i] - 1) / opts[i]);
+        if (tile == 512 && k > 1) continue;
+        if (k > 16) continue;
+        const int total = k * opts[i] + part_cost * k;
+        if (total < best_total || (total == best_total && k < nparts)) {
+            best_total = total;
+            tp = opts[i];
+            nparts = k;
+        }
+    }
+    return tp != 0;
+}
+
+// Relative time per time sample of the interior kernel on this plan: every group pays one staging
+// round (two barriers, the window copies: ~6000 cycles measured at cfg3), every source its gathers
+// (64 lanes x 8 bytes per ds_read_b64 at ~0.7 x 256 B/clk/CU, a little less on the small tiles,
+// whose units carry more address arithmetic per byte), all of it amortised over `tile` samples.
+double plan_cost(const PlanHost& ph, int tile)
+{
+    const double eff = tile == 512 ? 0.70 : (tile == 256 ? 0.66 : 0.58);
+    double cycles = 0.0;
+    for (const BpGroup& g : ph.groups) {
+        double terms = 0.0;
+        for (int q = g.first_src; q < g.first_src + g.n_src; ++q) terms += ph.srcs[q].nterm;
+        cycles += 6000.0 + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
+    }
+    return cycles / tile;
+}
+
+bool build_fast_host(const PlanHost& ph, int tile, bool allow_uniform, FastHost& fh)
+{
+    const int NT = ph.NT;
+    fh = FastHost();
+    fh.uniform = allow_uniform;
+    int tp_max = 4;
+    const size_t K = ph.srcs.size();
+    std::vector<int> tp_of(K, 0), np_of(K, 0);
+    for (size_t q = 0; q < K; ++q) {
+        const BpSource& sr = ph.srcs[q];
+        if (sr.nterm <= 0) continue;
+        ++fh.n_sources;
+        int tp, np;
+        if (!fast_parts(sr.nterm / 2, tile, tp, np)) return false;
+        tp_of[q] = tp;
+        np_of[q] = np;
+        tp_max = std::max(tp_max, tp);
+        fh.max_sta = std::max(fh.max_sta, sr.nterm / 2);
+        float w0 = 0.0f;
+        for (int j = 0; j < NT; j += 2) {
+            const float b = ph.beta[q * NT + j];
+            if (b == 0.0f) continue;
+            if (w0 == 0.0f) w0 = b;
+            else if (b != w0) fh.uniform = false;
+        }
+    }
+    if (fh.n_sources == 0) return false;
+    const int rec_dw = (2 + 2 * tp_max + 3) / 4 * 4;
+    fh.rec_dw = rec_dw;
+    std::vector<int> members;
+    for (const BpGroup& g : ph.groups) {
+        // the group's staging chunks (pieces of <= 256 floats), merged back into whole windows
+        BpFastGroup f{(int)fh.fr.size(), 0, (int)fh.fw.size(), 0};
+        for (int c = g.first_chunk; c < g.first_chunk + g.n_chunk; ++c) {
+            const BpChunk& ck = ph.chunks[c];
+            if ((int)fh.fw.size() > f.first_win && fh.fw.back().row == ck.row &&
+                fh.fw.back().gofs + fh.fw.back().len == ck.gofs && fh.fw.back().dst + fh.fw.back().len == ck.dst)
+                fh.fw.back().len += ck.n;
+            else
+                fh.fw.push_back(BpWindow{ck.row, ck.gofs, ck.dst, ck.n});
+        }
+        f.n_win = (int)fh.fw.size() - f.first_win;
+        if (f.n_win > BPF_DESC_MAX) return false;       // > 256 windows in a group: general kernel
+        // runs of equal (tp, nparts), ascending id inside a run (the plan lists a group's sources by
+        // ascending id); at most 16 x 16 combinations, most groups have one or two
+        for (int np = 1; np <= 16; ++np) {
+            for (int tp = 4; tp <= 24; tp += 2) {
+                members.clear();
+                for (int q = g.first_src; q < g.first_src + g.n_src; ++q)
+                    if (tp_of[q] == tp && np_of[q] == np) members.push_back(q);
+                if (members.empty()) continue;
+                const size_t first_rec = fh.rec.size() / rec_dw;
+                const size_t rounds = (members.size() + 15) / 16;
+                fh.rec.resize(fh.rec.size() + rounds * np * 16 * rec_dw, 0);
+                fh.fr.push_back(BpRun{(int)first_rec, (int)members.size(), tp, np});
+                ++f.n_run;
+                for (size_t m = 0; m < members.size(); ++m) {
+                    const int q = members[m];
+                    float w0 = 0.0f;
+                    for (int j = 0; j < NT && w0 == 0.0f; j += 2) w0 = ph.beta[(size_t)q * NT + j];
+                    for (int part = 0; part < np; ++part) {
+                        const size_t r0 = (first_rec + ((m / 16) * np + part) * 16 + m % 16) * rec_dw;
+                        fh.rec[r0] = ph.srcs[q].id;
+                        fh.rec[r0 + 1] = fh.uniform ? __builtin_bit_cast(int, w0) : 0;
+                        for (int i = 0; i < tp; ++i) {
+                            const int st = part * tp + i;
+                            const bool real = 2 * st + 1 < NT;  // beyond the term table: the zero slab, weight 0
+                            const int oP = real ? ph.off[(size_t)q * NT + 2 * st] : 0;
+                            const int oS = real ? ph.off[(size_t)q * NT + 2 * st + 1] : 0;
+                            if (fh.uniform) {                   // LDS byte addresses of the two windows
+                                fh.rec[r0 + 2 + 2 * i] = oP * 4;
+                                fh.rec[r0 + 3 + 2 * i] = oS * 4;
+                            } else {                            // {offs_P | offs_S << 16, weight}
+                                fh.rec[r0 + 2 + 2 * i] = (int)((unsigned)oP | ((unsigned)oS << 16));
+                                fh.rec[r0 + 3 + 2 * i] = real ? __builtin_bit_cast(int, ph.beta[(size_t)q * NT + 2 * st]) : 0;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        fh.fg.push_back(f);
+    }
+    fh.rec.resize(fh.rec.size() + (size_t)16 * rec_dw, 0);        // one round of records: the prefetch past the last part
+    fh.fw.resize(fh.fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});   // the descriptor prefetch past the last group
+    return true;
+}
+
+void free_fast_class(BpFastClass& fc)
+{
+    (void)hipFree(fc.d_groups);
+    (void)hipFree(fc.d_runs);
+    (void)hipFree(fc.d_wins);
+    (void)hipFree(fc.d_recs);
+    fc = BpFastClass();
+}
+
+struct ClassHost {
+    PlanHost ph;
+    FastHost fh;
+    int tile = 0;
+};
+
+}  // namespace
+
 extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sources, size_t K,
                                    size_t S, size_t P, int device, int32_t source_id_offset,
                                    bpmf_bp_plan** plan_out)
@@ -1198,50 +1367,123 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         set_error("bpmf_bp_plan_create: grid too large");
         return -1;
     }
-    // tuning knobs (defaults chosen on MI355X)
+    // options (defaults chosen on MI355X)
     const size_t soft_kb = (size_t)std::max(8, (int)option(OPT_BP_LDS_KB));
     const int max_group = std::max(1, (int)option(OPT_BP_MAX_GROUP));
     const int tpt_first = (int)option(OPT_BP_TPT);
     const int chunk = 4;  // terms gathered side by side by the generic kernel (8 measured equal)
-    const bool reorder = (int)option(OPT_BP_REORDER) != 0;
+    const bool reorder = option(OPT_BP_REORDER) != 0;
+    const bool verbose = option(OPT_BP_VERBOSE) != 0;
     const size_t hard = BP_LDS_MAX / sizeof(float);
     const size_t soft = std::min(hard, soft_kb * 1024 / sizeof(float));
+    const size_t SP = S * P;
 
-    PlanHost ph;
-    int tpt = 0;
-    // Two-phase grids with at most 16 weighted stations per source run the ds_read_b64 kernel:
-    // dual windows, one 16-wave workgroup per CU with the whole LDS.  When one source's dual
-    // windows do not fit, fall through to the single-window plans.
-    bool dual = false;
-    if (P == 2 && (int)option(OPT_BP_DUAL) && (int)option(OPT_BP_PACKED) &&
-        (int)option(OPT_BP_WPS) && tpt_first == 2) {
-        size_t max_sta = 0;
-        for (size_t k = 0; k < K; ++k) {
-            size_t n = 0;
-            for (size_t s = 0; s < S; ++s) n += w_sources[k * S + s] != 0.0f;
-            max_sta = std::max(max_sta, n);
+    // weighted stations per source, extreme used moveouts of the grid
+    std::vector<int> nsta(K, 0);
+    int max_sta = 0, tmin_all = 0, tmax_all = 0;
+    bool any_src = false;
+    for (size_t k = 0; k < K; ++k) {
+        int n = 0;
+        for (size_t s = 0; s < S; ++s) {
+            if (w_sources[k * S + s] == 0.0f) continue;
+            ++n;
+            for (size_t p = 0; p < P; ++p) {
+                const int tau = moveouts[(k * S + s) * P + p];
+                if (!any_src || tau < tmin_all) tmin_all = tau;
+                if (!any_src || tau > tmax_all) tmax_all = tau;
+                any_src = true;
+            }
         }
-        if (max_sta <= 16 &&
-            build_plan(moveouts, w_sources, K, S, P, BP_THREADS * 2, chunk, hard, hard, max_group,
-                       reorder, source_id_offset, true, ph)) {
-            tpt = 2;
-            dual = true;
-        }
+        nsta[k] = n;
+        max_sta = std::max(max_sta, n);
     }
-    const int candidates[3] = {tpt_first, 2, 1};
-    for (int c = 0; c < 3 && !tpt; ++c) {
-        const int cand = candidates[c];
-        if (cand != 1 && cand != 2 && cand != 4) continue;
-        ph = PlanHost();
-        if (build_plan(moveouts, w_sources, K, S, P, BP_THREADS * cand, chunk, soft, hard,
-                       max_group, reorder, source_id_offset, false, ph))
-            tpt = cand;
+    // processing order of the whole grid (kd-tree walk); a class keeps its members in this order
+    std::vector<int> order(K);
+    for (size_t k = 0; k < K; ++k) order[k] = (int)k;
+    if (reorder) bisect_order(moveouts, SP, order, 0, K, 16);
+
+    // ---- Two-phase grids: the ds_read_b64 kernel on dual windows (bp_fast.hip).  The sources are
+    // sorted into classes by their number of weighted stations -- <= 16, 17..32, 33..64 -- and
+    // every class gets the largest tile (512 / 256 / 128 samples) at which the dual windows of its
+    // groups fit the LDS with the lowest modelled cost; one 17-station source no longer moves a
+    // whole grid off the fast path, and dense 20- or 40-station weights run it on the small tiles.
+    std::vector<ClassHost> classes;
+    const bool want_dual = P == 2 && option(OPT_BP_DUAL) && option(OPT_BP_PACKED) &&
+                           option(OPT_BP_WPS) && tpt_first == 2;
+    if (want_dual && any_src && max_sta <= 64) {
+        static const int bound[4] = {0, 16, 32, 64};
+        static const int cand[3][3] = {{512, 256, 128}, {256, 128, 0}, {128, 0, 0}};
+        bool ok = true;
+        std::vector<int> members;
+        for (int c = 0; c < 3 && ok; ++c) {
+            members.clear();
+            for (size_t q = 0; q < K; ++q) {
+                const int n = nsta[order[q]];
+                // sources without any station ride along with the first class when the whole grid is
+                // one class (they are skipped by the kernels; the shared plan must list every source)
+                if ((n > bound[c] && n <= bound[c + 1]) || (c == 0 && n == 0 && max_sta <= 16))
+                    members.push_back(order[q]);
+            }
+            if (members.empty()) continue;
+            ClassHost best;
+            double best_cost = 0.0;
+            const int forced_tile = (int)option(OPT_BP_FAST_TILE);
+            for (int i = 0; i < 3 && cand[c][i]; ++i) {
+                if (forced_tile && cand[c][i] != forced_tile) continue;
+                ClassHost ch;
+                ch.tile = cand[c][i];
+                if (!build_plan(moveouts, w_sources, members, S, P, ch.tile, chunk, hard, hard, max_group,
+                                source_id_offset, true, ch.ph))
+                    continue;
+                const double cost = plan_cost(ch.ph, ch.tile);
+                if (verbose)
+                    fprintf(stderr, "[bpmf] bp class %d (%zu sources, %d..%d stations) tile %d: %zu groups, cost %.1f\n",
+                            c, members.size(), bound[c] + 1, bound[c + 1], ch.tile, ch.ph.groups.size(), cost);
+                if (!best.tile || cost < best_cost) {
+                    best = std::move(ch);
+                    best_cost = cost;
+                }
+                // groups of hundreds of sources: a smaller tile cannot win
+                if ((double)members.size() / (double)best.ph.groups.size() >= 256.0 && best.tile == cand[c][i]) break;
+            }
+            if (!best.tile || !build_fast_host(best.ph, best.tile, option(OPT_BP_FAST_UNIFORM) != 0, best.fh)) {
+                ok = false;
+                break;
+            }
+            classes.push_back(std::move(best));
+        }
+        if (!ok) classes.clear();
+    }
+    // A single class at tile 512 that lists every source doubles as the plan of the general kernels
+    // (their 8-byte-gather flavour): edge tiles and reduce="none" then gather 8 bytes too, and the
+    // grid is planned once.  Otherwise the general kernels get their own single-window plan.
+    const bool share = classes.size() == 1 && classes[0].tile == 512 && classes[0].ph.srcs.size() == K;
+    const bool use_fast = !classes.empty() && option(OPT_BP_FAST) != 0;
+    if (!share && !use_fast) classes.clear();
+
+    PlanHost ph_own;
+    int tpt = 0;
+    bool dual = false;
+    if (share) {
+        tpt = 2;
+        dual = true;
+    } else {
+        const int candidates[3] = {tpt_first, 2, 1};
+        for (int c = 0; c < 3 && !tpt; ++c) {
+            const int cnd = candidates[c];
+            if (cnd != 1 && cnd != 2 && cnd != 4) continue;
+            ph_own = PlanHost();
+            if (build_plan(moveouts, w_sources, order, S, P, BP_THREADS * cnd, chunk, soft, hard,
+                           max_group, source_id_offset, false, ph_own))
+                tpt = cnd;
+        }
     }
     if (!tpt) {
         set_error("bpmf_bp_plan_create: one source's %zu station-phase windows do not fit in LDS",
                   S * P);
         return -1;
     }
+    PlanHost& ph = share ? classes[0].ph : ph_own;
     if (ph.NT > 256) {
         set_error("bpmf_bp_plan_create: %d station-phase terms per source (max 256)", ph.NT);
         return -1;
@@ -1258,13 +1500,16 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     pl->id_offset = source_id_offset;
     pl->mean_group = (double)K / (double)ph.groups.size();
     pl->dual = dual;
-    if ((int)option(OPT_BP_VERBOSE))
-        fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B dual=%d\n",
-                K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes, (int)dual);
+    pl->tmin_all = tmin_all;
+    pl->tmax_all = tmax_all;
+    if (verbose)
+        fprintf(stderr, "[bpmf] bp plan: K=%zu groups=%d (mean %.1f src) tile=%d NT=%d chunk=%d lds=%zu B dual=%d classes=%zu\n",
+                K, pl->n_groups, pl->mean_group, BP_THREADS * tpt, pl->NT, chunk, pl->lds_bytes, (int)dual,
+                classes.size());
     int rc = 0;
     // fast-path copy of the term table: {byte offset, weight} pairs padded to ntv per source
     const int ntv_opts[4] = {8, 16, 24, 32};
-    const bool want_uv = (int)option(OPT_BP_UVGPR) != 0;
+    const bool want_uv = option(OPT_BP_UVGPR) != 0;
     pl->wps = (int)option(OPT_BP_WPS);
     std::vector<BpTermV> tv;
     for (int o = 0; o < 4 && want_uv && !pl->ntv; ++o)
@@ -1276,8 +1521,8 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 tv[q * pl->ntv + j] = BpTermV{ph.off[q * ph.NT + j] * 4, ph.beta[q * ph.NT + j]};
         if ((rc = upload(tv, (BpTermV**)&pl->d_termsv))) { bpmf_bp_plan_destroy(pl); return rc; }
     }
-    // packed per-station records for the two-phase fast kernel
-    if (P == 2 && ph.NT <= 64 && (int)option(OPT_BP_PACKED)) {
+    // packed per-station records for the two-phase kernel
+    if (P == 2 && ph.NT <= 64 && option(OPT_BP_PACKED)) {
         const int nsta_max = ph.NT / 2;   // NT is a multiple of 4
         const int opts[5] = {4, 8, 12, 16, 32};
         for (int o = 0; o < 5 && !pl->nsv; ++o)
@@ -1289,118 +1534,53 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         for (size_t q = 0; q < K; ++q) {
             int* r = (int*)&recs[q * (pl->nsv / 2)];
             const int nterm = ph.srcs[q].nterm;  // padded to the chunk (4): pairs of terms = stations
-            int nsta = 0;
+            int nst = 0;
             for (int j = 0; j + 1 < nterm; j += 2) {
                 const unsigned o0 = (unsigned)ph.off[q * ph.NT + j], o1 = (unsigned)ph.off[q * ph.NT + j + 1];
-                r[2 * nsta] = (int)(o0 | (o1 << 16));
-                r[2 * nsta + 1] = __builtin_bit_cast(int, ph.beta[q * ph.NT + j]);
-                ++nsta;
+                r[2 * nst] = (int)(o0 | (o1 << 16));
+                r[2 * nst + 1] = __builtin_bit_cast(int, ph.beta[q * ph.NT + j]);
+                ++nst;
             }
-            hdr[q] = make_int4(ph.srcs[q].id, ph.srcs[q].tmin, ph.srcs[q].tmax, (nsta + 1) / 2 * 2);
+            hdr[q] = make_int4(ph.srcs[q].id, ph.srcs[q].tmin, ph.srcs[q].tmax, (nst + 1) / 2 * 2);
         }
         if ((rc = upload(recs, &pl->d_recs)) || (rc = upload(hdr, &pl->d_hdr2))) {
             bpmf_bp_plan_destroy(pl);
             return rc;
         }
     }
-    // Interior-tile fast path (bp_fast.hip): the sources of every group once more, partitioned into
-    // runs of equal (even-padded) station count, one fixed-stride record each.
-    if (dual && pl->nsv && pl->nsv <= 16 && (int)option(OPT_BP_FAST)) {
-        const int NT = ph.NT;
-        bool uniform = (int)option(OPT_BP_FAST_UNIFORM) != 0;
-        int tmin_all = 0, tmax_all = 0;
-        bool any = false;
-        for (size_t q = 0; q < K; ++q) {
-            const BpSource& sr = ph.srcs[q];
-            if (sr.nterm <= 0) continue;
-            if (!any || sr.tmin < tmin_all) tmin_all = sr.tmin;
-            if (!any || sr.tmax > tmax_all) tmax_all = sr.tmax;
-            any = true;
-            float w0 = 0.0f;
-            for (int j = 0; j < NT; j += 2) {
-                const float b = ph.beta[q * NT + j];
-                if (b == 0.0f) continue;
-                if (w0 == 0.0f) w0 = b;
-                else if (b != w0) uniform = false;
-            }
+    // interior-tile classes
+    if (use_fast) {
+        for (size_t c = 0; c < classes.size() && !rc; ++c) {
+            const ClassHost& ch = classes[c];
+            BpFastClass& fc = pl->cls[pl->n_classes];
+            fc.tile = ch.tile;
+            fc.uniform = ch.fh.uniform;
+            fc.rec_dw = ch.fh.rec_dw;
+            fc.n_groups = (int)ch.fh.fg.size();
+            fc.lds_bytes = ch.ph.lds_floats * sizeof(float);
+            fc.n_sources = ch.fh.n_sources;
+            fc.max_stations = ch.fh.max_sta;
+            fc.desc_waves = (int)std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64) / 64;
+            ++pl->n_classes;
+            if ((rc = upload(ch.fh.fg, &fc.d_groups)) || (rc = upload(ch.fh.fr, &fc.d_runs)) ||
+                (rc = upload(ch.fh.fw, &fc.d_wins)) || (rc = upload(ch.fh.rec, &fc.d_recs)))
+                break;
+            if (verbose)
+                fprintf(stderr, "[bpmf] bp fast class %zu: tile %d, %zu sources (<= %d stations), %d groups, %zu runs, uniform=%d, rec=%d dwords\n",
+                        c, fc.tile, fc.n_sources, fc.max_stations, fc.n_groups, ch.fh.fr.size(), (int)fc.uniform, fc.rec_dw);
         }
-        const int rec_dw = (2 + 2 * std::max(pl->nsv, 4) + 3) / 4 * 4;
-        std::vector<BpFastGroup> fg;
-        std::vector<BpRun> fr;
-        std::vector<BpWindow> fw;
-        std::vector<int> rec;
-        std::vector<int> order;
-        bool wins_ok = true;
-        for (const BpGroup& g : ph.groups) {
-            // the group's staging chunks (pieces of <= 256 floats), merged back into whole windows
-            BpFastGroup f{(int)fr.size(), 0, (int)fw.size(), 0};
-            for (int c = g.first_chunk; c < g.first_chunk + g.n_chunk; ++c) {
-                const BpChunk& ck = ph.chunks[c];
-                if (!fw.empty() && (int)fw.size() > f.first_win && fw.back().row == ck.row &&
-                    fw.back().gofs + fw.back().len == ck.gofs && fw.back().dst + fw.back().len == ck.dst)
-                    fw.back().len += ck.n;
-                else
-                    fw.push_back(BpWindow{ck.row, ck.gofs, ck.dst, ck.n});
-            }
-            f.n_win = (int)fw.size() - f.first_win;
-            wins_ok = wins_ok && f.n_win <= BPF_DESC_MAX;
-            for (int nst = 4; nst <= 16; nst += 2) {        // a group's sources are listed by ascending id
-                order.clear();                              // (1-2 stations: padded to 4 with zero-slab terms)
-                for (int q = g.first_src; q < g.first_src + g.n_src; ++q)
-                    if (ph.srcs[q].nterm == 2 * nst || (nst == 4 && ph.srcs[q].nterm > 0 && ph.srcs[q].nterm < 8))
-                        order.push_back(q);
-                if (order.empty()) continue;
-                fr.push_back(BpRun{(int)(rec.size() / rec_dw), (int)order.size(), nst, 0});
-                ++f.n_run;
-                for (int q : order) {
-                    const size_t r0 = rec.size();
-                    rec.resize(r0 + rec_dw, 0);
-                    float w0 = 0.0f;
-                    for (int j = 0; j < NT && w0 == 0.0f; j += 2) w0 = ph.beta[(size_t)q * NT + j];
-                    rec[r0] = ph.srcs[q].id;
-                    rec[r0 + 1] = uniform ? __builtin_bit_cast(int, w0) : 0;
-                    for (int st = 0; st < nst; ++st) {
-                        const bool real = 2 * st + 1 < NT;      // beyond the term table: the zero slab, weight 0
-                        const int oP = real ? ph.off[(size_t)q * NT + 2 * st] : 0, oS = real ? ph.off[(size_t)q * NT + 2 * st + 1] : 0;
-                        if (uniform) {                      // LDS byte addresses of the two windows
-                            rec[r0 + 2 + 2 * st] = oP * 4;
-                            rec[r0 + 3 + 2 * st] = oS * 4;
-                        } else {                            // {offs_P | offs_S << 16, weight}
-                            rec[r0 + 2 + 2 * st] = (int)((unsigned)oP | ((unsigned)oS << 16));
-                            rec[r0 + 3 + 2 * st] = real ? __builtin_bit_cast(int, ph.beta[(size_t)q * NT + 2 * st]) : 0;
-                        }
-                    }
-                }
-            }
-            fg.push_back(f);
-        }
-        rec.resize(rec.size() + (size_t)16 * rec_dw, 0);   // one round of records: the prefetch past the last source
-        fw.resize(fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});   // the descriptor prefetch past the last group
-        any = any && wins_ok;                              // > 256 windows in a group: general kernel
-        if (any && ((rc = upload(fg, &pl->d_fgroups)) || (rc = upload(fr, &pl->d_fruns)) ||
-                    (rc = upload(fw, &pl->d_fwins)) || (rc = upload(rec, &pl->d_frecs)))) {
+        if (rc) { bpmf_bp_plan_destroy(pl); return rc; }
+        hipError_t e1 = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
+        hipError_t e2 = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
+        hipError_t e3 = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            set_error("bpmf_bp_plan_create: side stream / events: %s",
+                      hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
             bpmf_bp_plan_destroy(pl);
-            return rc;
+            return -2;
         }
-        if (any) {
-            hipError_t e1 = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
-            hipError_t e2 = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
-            hipError_t e3 = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-                set_error("bpmf_bp_plan_create: side stream / events: %s",
-                          hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
-                bpmf_bp_plan_destroy(pl);
-                return -2;
-            }
-        }
-        pl->fast = any;
-        pl->fast_uniform = uniform;
-        pl->fast_rec_dw = rec_dw;
-        pl->tmin_all = tmin_all;
-        pl->tmax_all = tmax_all;
-        if ((int)option(OPT_BP_VERBOSE))
-            fprintf(stderr, "[bpmf] bp fast path: %zu runs, uniform=%d, rec=%d dwords, moveouts [%d, %d]\n",
-                    fr.size(), (int)uniform, rec_dw, tmin_all, tmax_all);
+        pl->fast = pl->n_classes > 0;
+        pl->fast_shares_generic = share;
     }
     if ((rc = upload(ph.groups, &pl->d_groups)) || (rc = upload(ph.chunks, &pl->d_chunks)) ||
         (rc = upload(ph.srcs, &pl->d_srcs)) || (rc = upload(ph.off, &pl->d_off)) ||
@@ -1426,10 +1606,7 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
-    (void)hipFree(pl->d_fgroups);
-    (void)hipFree(pl->d_fruns);
-    (void)hipFree(pl->d_fwins);
-    (void)hipFree(pl->d_frecs);
+    for (int c = 0; c < BPF_MAX_CLASSES; ++c) free_fast_class(pl->cls[c]);
     delete pl;
 }
 
@@ -1446,6 +1623,26 @@ extern "C" int bpmf_bp_plan_info(const bpmf_bp_plan* pl, bpmf_bp_plan_stats* out
     out->stations_max = pl->wps ? pl->nsv : 0;
     const bool packed = pl->wps && pl->nsv && pl->tpt == 2;
     out->waves_per_cu = !packed ? 8 : (pl->nsv > 16 ? 16 : (pl->dual ? 16 : 24));
+    // reduce="max": the interior tiles run the classes of bp_fast.hip (8-byte gathers, 16 waves per CU);
+    // tile / n_groups then describe the class that holds most sources
+    out->n_classes = pl->fast ? pl->n_classes : 0;
+    for (int c = 0; c < 3; ++c) {
+        const bool on = pl->fast && c < pl->n_classes;
+        out->class_tile[c] = on ? pl->cls[c].tile : 0;
+        out->class_sources[c] = on ? (int32_t)pl->cls[c].n_sources : 0;
+        out->class_groups[c] = on ? pl->cls[c].n_groups : 0;
+        out->class_stations_max[c] = on ? pl->cls[c].max_stations : 0;
+    }
+    if (pl->fast) {
+        int big = 0;
+        for (int c = 1; c < pl->n_classes; ++c)
+            if (pl->cls[c].n_sources > pl->cls[big].n_sources) big = c;
+        out->tile = pl->cls[big].tile;
+        out->n_groups = pl->cls[big].n_groups;
+        out->lds_bytes = (int32_t)pl->cls[big].lds_bytes;
+        out->gather_bytes = 8;
+        out->waves_per_cu = 16;
+    }
     return 0;
 }
 
@@ -1456,17 +1653,40 @@ namespace {
 // 256 CUs idle (and up to ~1000 tiles the last round of workgroups runs half empty): the groups of the
 // plan are then dealt to 1024 / tiles workgroups per tile.
 // option bp.split: 0/1 = off, n = force n ranges (tests), -1 = automatic.  Only the P = 2 packed kernels take it.
-int bp_split_count(const bpmf_bp_plan* pl, size_t N)
+bool generic_can_split(const bpmf_bp_plan* pl)
 {
-    if (!pl || pl->tpt != 2 || !pl->wps || pl->n_groups < 2) return 1;
-    if (pl->nsv != 4 && pl->nsv != 8 && pl->nsv != 12 && pl->nsv != 16 && pl->nsv != 32) return 1;   // dispatch_beam<2>'s packed kernels
+    if (pl->tpt != 2 || !pl->wps || pl->n_groups < 2) return false;
+    return pl->nsv == 4 || pl->nsv == 8 || pl->nsv == 12 || pl->nsv == 16 || pl->nsv == 32;   // dispatch_beam<2>'s packed kernels
+}
+
+long long split_wanted(size_t N)
+{
     const long long n_tiles = (long long)((N + 511) / 512);
     // enough workgroups for ~4 rounds over the 256 CUs (a split costs one merge pass and nothing else:
     // the ranges stage disjoint windows), none from 1024 tiles (N >= 524 288) on
     long long want = n_tiles >= 1024 ? 1 : (1024 + n_tiles - 1) / n_tiles;
     const int forced = (int)option(OPT_BP_SPLIT);   // read per call: the tests switch it
     if (forced >= 0) want = forced < 1 ? 1 : forced;
-    return (int)std::max<long long>(1, std::min<long long>(want, pl->n_groups));
+    return want;
+}
+
+// the general kernels alone (reduce="none", plans without interior classes)
+int bp_split_count(const bpmf_bp_plan* pl, size_t N)
+{
+    if (!pl || !generic_can_split(pl)) return 1;
+    return (int)std::max<long long>(1, std::min<long long>(split_wanted(N), pl->n_groups));
+}
+
+// reduce="max" on a plan with interior classes: group ranges per tile of every class kernel, and of
+// the general kernel on the edge tiles (1 when that kernel cannot split)
+void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int& n_split, int& n_split_edge)
+{
+    long long want = split_wanted(N);
+    for (int c = 0; c < pl->n_classes; ++c) want = std::min<long long>(want, pl->cls[c].n_groups);
+    const bool gsplit = generic_can_split(pl);
+    if (gsplit) want = std::min<long long>(want, pl->n_groups);
+    n_split = (int)std::max<long long>(1, want);
+    n_split_edge = gsplit ? n_split : 1;
 }
 }  // namespace
 
@@ -1474,13 +1694,38 @@ extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size
 {
     (void)C;
     if (!pl) return 0;
-    // the prestacked traces + (short series) the partial maxima of the group ranges
-    const size_t n_split = (size_t)bp_split_count(pl, N);
+    // the prestacked traces + the partial maxima: one row per group range of a short series
+    // (bp_split_count) and per station-count class of the interior kernel
+    size_t rows = (size_t)bp_split_count(pl, N);
+    if (pl->fast) {
+        int n_split, n_split_edge;
+        bp_fast_split_counts(pl, N, n_split, n_split_edge);
+        rows = std::max(rows, (size_t)n_split * (size_t)pl->n_classes);
+    }
     return align_up(pl->S * pl->P * N * sizeof(float), 256) +
-           (n_split > 1 ? align_up(n_split * N * (sizeof(float) + sizeof(int32_t)), 256) : 0);
+           (rows > 1 ? align_up(rows * N * (sizeof(float) + sizeof(int32_t)), 256) : 0);
 }
 
 namespace {
+
+// The caller (interior / edge split of bpmf_bp_run_dev) may restrict a launch of the general kernels
+// to the samples [t_samp_lo, t_samp_hi) -- multiples of 1024, i.e. whole tiles of every kernel -- and
+// then places the profile marks itself.  t_samp_hi < 0: the whole series.
+thread_local long long t_samp_lo = 0, t_samp_hi = -1;
+thread_local int t_n_split = 1;                  // group ranges per tile (short series, see bp_split_count)
+thread_local long long t_split_stride = 0;       // elements between the partial outputs of reduce="max"
+
+// tiles [base, base + count) of a kernel with `tile` samples per workgroup
+inline void tile_range(size_t N, size_t tile, long long& base, long long& count)
+{
+    base = 0;
+    count = (long long)((N + tile - 1) / tile);
+    if (t_samp_hi >= 0) {
+        const long long hi = std::min<long long>(t_samp_hi, (long long)N);
+        base = t_samp_lo / (long long)tile;
+        count = hi > t_samp_lo ? (hi + (long long)tile - 1) / (long long)tile - base : 0;
+    }
+}
 
 template <int TPT, int CHUNK, int NBLK, int OOB, int REDUCE>
 int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream, float* beam,
@@ -1491,14 +1736,16 @@ int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t st
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    const size_t tile = (size_t)BP_THREADS * TPT;
-    dim3 grid((unsigned)((N + tile - 1) / tile));
-    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    long long tile_base, n_tiles;
+    tile_range(N, (size_t)BP_THREADS * TPT, tile_base, n_tiles);
+    if (n_tiles <= 0) return 0;
+    dim3 grid((unsigned)n_tiles);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int*)pl->d_srcs, pl->d_off, pl->d_beta, pl->NT, pl->id_offset, beam, arg);
+        (const int*)pl->d_srcs, pl->d_off, pl->d_beta, pl->NT, pl->id_offset, beam, arg, tile_base);
     BPMF_LAUNCH_CHECK();
-    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 
@@ -1533,14 +1780,16 @@ int launch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    const size_t tile = (size_t)BP_THREADS * TPT;
-    dim3 grid((unsigned)((N + tile - 1) / tile));
-    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    long long tile_base, n_tiles;
+    tile_range(N, (size_t)BP_THREADS * TPT, tile_base, n_tiles);
+    if (n_tiles <= 0) return 0;
+    dim3 grid((unsigned)n_tiles);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg);
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base);
     BPMF_LAUNCH_CHECK();
-    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 
@@ -1568,14 +1817,16 @@ int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    const size_t tile = (size_t)64 * TPW;
-    dim3 grid((unsigned)((N + tile - 1) / tile));
-    profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    long long tile_base, n_tiles;
+    tile_range(N, (size_t)64 * TPW, tile_base, n_tiles);
+    if (n_tiles <= 0) return 0;
+    dim3 grid((unsigned)n_tiles);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), lds, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg);
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base);
     BPMF_LAUNCH_CHECK();
-    profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 
@@ -1592,10 +1843,6 @@ int dispatch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, int oob,
     return launch_beam_wps<TPW, NTV, BPMF_BP_FLEXIBLE, BPMF_BP_REDUCE_NONE>(pl, U, N, stream, beam, arg);
 }
 
-thread_local long long t_tile_base = 0, t_tile_count = -1;   // -1: all tiles
-thread_local int t_n_split = 1;                  // group ranges per tile (short series, see bp_split_count)
-thread_local long long t_split_stride = 0;       // elements between the partial outputs of reduce="max"
-
 template <int WPB, int NSV, int OOB, int REDUCE, bool SMETA, bool B64>
 int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t stream,
                      float* beam, int32_t* arg)
@@ -1606,20 +1853,17 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)BP_LDS_MAX));
-    // t_tile_*: the caller (interior / edge split of bpmf_bp_run_dev) may restrict the launch to a
-    // range of tiles and place the profile marks itself
-    const long long all_tiles = (long long)((N + 511) / 512);
-    const long long tile_base = t_tile_count >= 0 ? t_tile_base : 0;
-    const long long n_tiles = t_tile_count >= 0 ? t_tile_count : all_tiles;
+    long long tile_base, n_tiles;
+    tile_range(N, 512, tile_base, n_tiles);
     if (n_tiles <= 0) return 0;
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)t_n_split);  // x: multiple of 8 (XCD-aware tile order)
-    if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
                                                 (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,
                                                 pl->id_offset, beam, arg, tile_base, n_tiles,
                                                 t_split_stride);
     BPMF_LAUNCH_CHECK();
-    if (t_tile_count < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+    if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
 }
 
@@ -1730,63 +1974,86 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
                                                                (int)C, P, U);
     }
     BPMF_LAUNCH_CHECK();
-    // short series: several group ranges per tile (bp_split_count); reduce="max" goes through partial
-    // rows behind the prestack in the workspace and one merge launch
-    const int n_split = bp_split_count(pl, N);
-    float* const beam_final = d_beam_out;
-    int32_t* const arg_final = d_arg_out;
     struct SplitScope {          // the launchers read the thread-local pair; always reset on the way out
         SplitScope(int n, long long stride) { t_n_split = n; t_split_stride = stride; }
-        ~SplitScope() { t_n_split = 1; t_split_stride = 0; }
-    } split_scope(n_split, n_split > 1 && reduce == BPMF_BP_REDUCE_MAX ? (long long)N : 0);
+        ~SplitScope() { t_n_split = 1; t_split_stride = 0; t_samp_hi = -1; t_samp_lo = 0; }
+    };
+    float* const beam_final = d_beam_out;
+    int32_t* const arg_final = d_arg_out;
+    char* const part = (char*)d_workspace + align_up((size_t)S * P * N * sizeof(float), 256);
+    if (pl->fast && reduce == BPMF_BP_REDUCE_MAX) {
+        // Samples on which no source can leave the trace -- t + tmin_all >= 0 and t + tmax_all (+ the
+        // staging slack of 8 samples) < N, rounded to multiples of 1024 (whole tiles of every kernel) --
+        // run the interior kernel of bp_fast.hip, once per station-count class, which is the same for
+        // strict and flexible; the few tiles at the ends of the day run the general kernel over all
+        // sources.  Several classes, or several group ranges per tile on a short series, write
+        // partial rows behind the prestack, folded by one merge launch (value, then lowest id).
+        int n_split, n_split_edge;
+        bp_fast_split_counts(pl, N, n_split, n_split_edge);
+        const int rows = n_split * pl->n_classes;
+        long long lo_s = pl->tmin_all < 0 ? ((long long)(-pl->tmin_all) + 1023) / 1024 * 1024 : 0;
+        long long hi_s = ((long long)N - pl->tmax_all - 8) / 1024 * 1024;
+        if ((long long)N - pl->tmax_all - 8 < 0) hi_s = 0;
+        lo_s = std::min(lo_s, (long long)N);
+        hi_s = std::max(lo_s, std::min(hi_s, (long long)N));
+        float* pbeam = rows > 1 ? (float*)part : beam_final;
+        int32_t* parg = rows > 1 ? (int32_t*)(part + (size_t)rows * N * sizeof(float)) : arg_final;
+        profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+        int rc = 0;
+        const bool have_edge = lo_s > 0 || hi_s < (long long)N;
+        hipStream_t es = stream;          // edge tiles: on the side stream, beside the interior kernels
+        if (have_edge && pl->side_stream) {
+            BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
+            BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
+            es = pl->side_stream;
+        }
+        {
+            SplitScope scope(n_split_edge, rows > 1 ? (long long)N : 0);
+            auto edge = [&](long long from, long long to) {
+                if (to <= from || rc) return;
+                t_samp_lo = from; t_samp_hi = to;
+                switch (pl->tpt) {
+                    case 1: rc = dispatch_beam<1>(pl, U, N, out_of_bounds, reduce, es, pbeam, parg); break;
+                    case 2: rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, es, pbeam, parg); break;
+                    default: rc = dispatch_beam<4>(pl, U, N, out_of_bounds, reduce, es, pbeam, parg); break;
+                }
+                t_samp_hi = -1;
+            };
+            edge(0, lo_s);
+            edge(hi_s, (long long)N);
+        }
+        if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
+        for (int c = 0; c < pl->n_classes && !rc; ++c) {
+            const BpFastClass& fc = pl->cls[c];
+            rc = launch_beam_fast(fc, pl->id_offset, U, N, lo_s / fc.tile, hi_s / fc.tile, stream,
+                                  pbeam + (size_t)c * n_split * N, parg + (size_t)c * n_split * N, n_split,
+                                  rows > 1 ? (long long)N : 0);
+        }
+        if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
+        if (!rc && rows > 1) {
+            bp_merge_splits_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
+                pbeam, parg, rows, n_split_edge, lo_s, hi_s, N, beam_final, arg_final);
+            BPMF_LAUNCH_CHECK();
+        }
+        profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+        return rc;
+    }
+    // the general kernels over the whole series.  Short series: several group ranges per tile
+    // (bp_split_count); reduce="max" goes through partial rows and one merge launch
+    const int n_split = bp_split_count(pl, N);
+    SplitScope split_scope(n_split, n_split > 1 && reduce == BPMF_BP_REDUCE_MAX ? (long long)N : 0);
     if (n_split > 1 && reduce == BPMF_BP_REDUCE_MAX) {
-        char* part = (char*)d_workspace + align_up((size_t)S * P * N * sizeof(float), 256);
         d_beam_out = (float*)part;
         d_arg_out = (int32_t*)(part + (size_t)n_split * N * sizeof(float));
     }
     auto merge_splits = [&]() -> int {
         if (n_split > 1 && reduce == BPMF_BP_REDUCE_MAX) {
             bp_merge_splits_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
-                d_beam_out, d_arg_out, n_split, N, beam_final, arg_final);
+                d_beam_out, d_arg_out, n_split, n_split, 0, (long long)N, N, beam_final, arg_final);
             BPMF_LAUNCH_CHECK();
         }
         return 0;
     };
-    if (pl->fast && reduce == BPMF_BP_REDUCE_MAX && pl->tpt == 2) {
-        // Tiles on which no source can leave the trace -- t0 + tmin_all >= 0 and t0 + 512 + tmax_all
-        // (+ the staging slack of 8 samples) <= N -- run the interior kernel of bp_fast.hip, which is
-        // the same for strict and flexible; the few tiles at the ends of the day run the general one.
-        const long long n_all = (long long)((N + 511) / 512);
-        long long lo = pl->tmin_all < 0 ? ((long long)(-pl->tmin_all) + 511) / 512 : 0;
-        long long hi = ((long long)N - pl->tmax_all - 8) / 512;
-        if ((long long)N - pl->tmax_all - 8 < 0) hi = 0;
-        lo = std::min(lo, n_all);
-        hi = std::max(lo, std::min(hi, n_all));
-        profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
-        int rc = 0;
-        const bool have_edge = lo > 0 || hi < n_all;
-        hipStream_t es = stream;          // edge tiles: on the side stream, beside the interior kernel
-        if (have_edge && pl->side_stream) {
-            BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
-            BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
-            es = pl->side_stream;
-        }
-        auto edge = [&](long long base, long long count) {
-            if (count <= 0 || rc) return;
-            t_tile_base = base; t_tile_count = count;
-            rc = dispatch_beam<2>(pl, U, N, out_of_bounds, reduce, es, d_beam_out, d_arg_out);
-            t_tile_count = -1;
-        };
-        edge(0, lo);
-        edge(hi, n_all - hi);
-        if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
-        if (!rc) rc = launch_beam_fast(pl, U, N, lo, hi, stream, d_beam_out, d_arg_out, n_split,
-                                       n_split > 1 ? (long long)N : 0);
-        if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
-        if (!rc) rc = merge_splits();
-        profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
-        return rc;
-    }
     int rc;
     switch (pl->tpt) {
         case 1: rc = dispatch_beam<1>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out); break;

@@ -30,6 +30,16 @@
 //     max / arg-max update is hand-scheduled: 8 v_cmp into 8 SGPR pairs, then 16 v_cndmask -- no
 //     VALU-writes-SGPR wait states between a compare and its selects.
 //
+//
+// Round 3: DENSE STATION WEIGHTS.  The dual windows of n weighted stations need 2 n rows x 2 copies
+// x (tile + moveout spread) floats of LDS: at tile 512 that ends at n = 16, and rounds 1-2 sent a
+// whole grid to the 4-byte-gather kernels as soon as ONE source had 17 stations.  Now (a) the
+// kernel is a template on the samples per lane -- tile 512 / 256 / 128, one term of a source
+// costing 4 / 2 / 1 ds_read_b64 per lane, a "unit" of the gather ring always being 4 gathers --
+// and (b) a source may span several records ("parts" of <= 16 stations) whose accumulators are
+// carried, the max update following the last part.  bp.hip sorts the sources of a grid into
+// classes by station count and gives every class the largest tile its windows fit.
+//
 // Arithmetic (and therefore every output bit) is that of oracle/bpmf_oracle.c:bp_cpu: per source
 // an fmaf chain over (station outer, phase inner) starting from +0, strict > keeps the lowest id.
 #include "bp_plan.h"
@@ -37,6 +47,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 namespace bpmf {
 
@@ -63,10 +74,36 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
     asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #o : "=v"(dst) : "v"(vz), "s"(sptr))
 
 constexpr int BPF_WPB = 16;             // waves per workgroup = per CU (the dual windows take the LDS)
-constexpr int BPF_TILE = 512;           // 64 lanes x 4 sample pairs
 constexpr int BPF_THREADS = 64 * BPF_WPB;
 
-template <bool UNI>
+// ---- the rolling-record pipeline in numbers (all compile-time) ----
+// A PART is one record: `TP` stations = 2 TP (station, phase) terms = Q = TP / 2 quads of 4 body
+// dwords.  A source is `nparts` consecutive parts with the accumulators carried from part to part
+// (1 part for <= 16 stations; 2-4 parts for dense weights).  A lane owns TPW samples of the tile
+// (TPW / 2 pairs), so one term costs TPW / 2 ds_read_b64; a UNIT is the bundle of 4 gathers that
+// travels together through the ring of 4: TPU = 8 / TPW terms (tile 512: 1 term, 256: 2, 128: 4).
+// Quad q of the record is consumed -- its addresses issued, its weights multiplied -- when unit
+// bpf_ur(q) has been accumulated, and is then re-loaded with the NEXT part's quad q.
+constexpr int bpf_ur(int q, int tpu) { return (4 * q + 3) / tpu; }
+// refills of the current part already issued when step u starts (those behind units < u), quads > qq only
+constexpr int bpf_refills_before(int u, int qq, int Q, int tpu)
+{
+    int n = 0;
+    for (int j = qq + 1; j < Q; ++j)
+        if (bpf_ur(j, tpu) <= u - 1) ++n;
+    return n;
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void bpf_for_each(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// TPW: samples per lane (8 / 4 / 2 -> tile 512 / 256 / 128).  The smaller tiles exist for dense
+// station weights: the dual windows of 2 n rows must fit 160 KB -- n <= 16 at tile 512, ~28 at 256,
+// ~48 at 128 (bp.hip picks the tile per station-count class of sources).
+template <bool UNI, int TPW>
 __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
@@ -80,7 +117,10 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     out_beam += (size_t)blockIdx.y * (size_t)split_stride;
     out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     extern __shared__ float lds[];
-    constexpr int TPW = 8, TILE = BPF_TILE, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
+    static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
+    constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
+    constexpr int TPU = 8 / TPW;      // terms per unit
+    constexpr int RPT = TPW / 2;      // ds_read_b64 per term
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,8 +138,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     int arg[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
-    for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
-    const long long rec_stride = (long long)rec_dw * 4 * WPB;   // bytes between a wave's sources
+    for (int x = tid; x < BPF_ZERO_SLAB; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
+    const long long rec_stride = (long long)rec_dw * 4 * WPB;   // bytes between a wave's consecutive parts
 
     // Window descriptors of a group travel through a 4 KB slab of LDS: waves 0-3 copy the NEXT
     // group's descriptors there (LDS-DMA, 16 bytes per lane) right after the staging barrier of the
@@ -148,6 +188,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             const BpRun run = runs[grp.first_run + rr];
             const int n_mine = run.n_src > wv ? (run.n_src - wv + WPB - 1) / WPB : 0;   // sources of this wave
             if (n_mine == 0) continue;
+            const int nparts = run.nparts;
             const int* p_first = recs + ((long long)run.first_rec + wv) * rec_dw;
             // group-local running max of this run: sources arrive by ascending id, so a plain
             // strict > keeps the lowest id on ties; the full tie rule merges the run into best/arg
@@ -156,96 +197,146 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 #pragma unroll
             for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
 
-            auto walk = [&](auto nst_c) {
-                constexpr int NST = decltype(nst_c)::value;
-                constexpr int NU = 2 * NST, AH = 3, Q = NU / 4;   // units, units in flight ahead, quads
-                static_assert(NST >= 4 && NST % 2 == 0 && NST <= 16, "fast path: 4..16 stations, even");
-                // The record of the CURRENT source, rolling: quad q = body dwords 4q .. 4q+3 (the
-                // addresses -- or {offsets, weight} pairs -- of units 4q .. 4q+3).  Once step 4q+3 has
-                // accumulated its unit, quad q is re-loaded with the next source's quad q.
+            // TP stations per part; MULTI = false: every source is ONE part (compile-time: the
+            // accumulators start from the fma's constant-0 addend and the max update follows every
+            // part); MULTI = true: `nparts` parts per source, accumulators carried, the update
+            // behind the last part under a wave-uniform branch.
+            auto walk = [&](auto tp_c, auto multi_c) {
+                constexpr int TP = decltype(tp_c)::value;
+                constexpr bool MULTI = decltype(multi_c)::value;
+                constexpr int NTERM = 2 * TP, NU = NTERM / TPU, AH = 3, Q = NTERM / 4;
+                static_assert(TP >= 4 && TP % 2 == 0 && TP <= 24 && NTERM % TPU == 0 && Q <= 12, "4..24 stations per part, even");
+                static_assert(NU >= AH + 1 && bpf_ur(((AH - 1) * TPU) >> 2, TPU) <= NU - 2,
+                              "the next part's first units must find their quads requested");
+                // The record of the CURRENT part, rolling: quad q = body dwords 4q .. 4q+3 (the
+                // addresses -- or {offsets, weight} pairs -- of terms 4q .. 4q+3).  Once the unit that
+                // holds term 4q+3 has been accumulated, quad q is re-loaded with the next part's quad q.
                 i32x4 R[Q];
                 i32x2 h_cur, h_next;          // {id, weight}
                 const int* p = p_first;
                 BPF_LOADX2(h_cur, vzero, p, 0);
 #define BPF_LOADQ(q) \
     if constexpr ((q) < Q) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(R[(q) < Q ? (q) : 0]) : "v"(vzero), "s"(p), "n"(8 + 16 * (q)))
+#define BPF_LOADQC(q) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(R[q]) : "v"(vzero), "s"(p), "n"(8 + 16 * (q)))
                 BPF_LOADQ(0); BPF_LOADQ(1); BPF_LOADQ(2); BPF_LOADQ(3);
                 BPF_LOADQ(4); BPF_LOADQ(5); BPF_LOADQ(6); BPF_LOADQ(7);
+                BPF_LOADQ(8); BPF_LOADQ(9); BPF_LOADQ(10); BPF_LOADQ(11);
                 // vmcnt(0) with every register of the record as an in/out operand: nothing that uses
                 // them can be scheduled above the wait (tools/check_inflight.py checks the listing)
-#define BPF_VMWAIT_ALL()                                                                              \
-    do {                                                                                              \
-        if constexpr (Q == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]));            \
-        else if constexpr (Q == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2])); \
-        else if constexpr (Q == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3 % Q])); \
-        else if constexpr (Q == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3 % Q]), "+v"(R[4 % Q])); \
-        else if constexpr (Q == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3 % Q]), "+v"(R[4 % Q]), "+v"(R[5 % Q])); \
-        else if constexpr (Q == 7) asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3 % Q]), "+v"(R[4 % Q]), "+v"(R[5 % Q]), "+v"(R[6 % Q])); \
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur), "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3 % Q]), "+v"(R[4 % Q]), "+v"(R[5 % Q]), "+v"(R[6 % Q]), "+v"(R[7 % Q])); \
+#define BPF_VMWAIT_ALL()                                                                  \
+    do {                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(h_cur));                                 \
+        _Pragma("unroll") for (int qi = 0; qi < Q; ++qi) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[qi])); \
     } while (0)
                 BPF_VMWAIT_ALL();
-                f32x2 X[4][4];  // ring of 4 units in flight
-                // unit u of the source whose record R holds: 4 gathers of 8 bytes per lane
-#define BPF_ISSUE_U(u)                                                                         \
+                // ring of 4 units in flight, 4 gathers each.  Unit w of a part sits in slot (w + PH) & 3:
+                // the ring runs on across parts, so when a part has NU = 2 mod 4 units the phase PH
+                // alternates 0, 2, 0, ... from part to part (the loop below is then unrolled by two).
+                f32x2 X[4][4];
+                // LDS byte address of term `tm` of the part whose record R holds
+#define BPF_TERM_ADDR(tm)                                                                      \
+    (UNI ? v_base + (unsigned)R[(tm) >> 2][(tm) & 3]                                           \
+         : v_base + (((((tm) & 1) ? ((unsigned)R[(tm) >> 2][2 * (((tm) >> 1) & 1)] >> 16)      \
+                                  : ((unsigned)R[(tm) >> 2][2 * (((tm) >> 1) & 1)] & 0xffffu))) << 2))
+                // unit w: TPU terms x RPT gathers of 8 bytes per lane (plain C++ adds for the
+                // addresses: an inline-asm add would cost a hazard s_nop before the reads)
+#define BPF_ISSUE_U(w, sl)                                                                     \
     {                                                                                          \
-        unsigned a_;  /* plain C++ adds: an inline-asm add would cost a hazard s_nop before the reads */ \
-        if constexpr (UNI) {                                                                   \
-            a_ = v_base + (unsigned)R[(u) >> 2][(u) & 3];                                      \
+        if constexpr (TPU == 1) {                                                              \
+            const unsigned a_ = BPF_TERM_ADDR(w);                                              \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                  \
+            BPF_RD64(X[sl][2], a_, 1024); BPF_RD64(X[sl][3], a_, 1536);              \
+        } else if constexpr (TPU == 2) {                                                       \
+            const unsigned a_ = BPF_TERM_ADDR(2 * (w)), b_ = BPF_TERM_ADDR(2 * (w) + 1);       \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                  \
+            BPF_RD64(X[sl][2], b_, 0); BPF_RD64(X[sl][3], b_, 512);                  \
         } else {                                                                               \
-            const unsigned o_ = (unsigned)R[(u) >> 2][2 * (((u) >> 1) & 1)];                   \
-            a_ = v_base + ((((u) & 1) ? (o_ >> 16) : (o_ & 0xffffu)) << 2);                    \
+            const unsigned a_ = BPF_TERM_ADDR(4 * (w)), b_ = BPF_TERM_ADDR(4 * (w) + 1);       \
+            const unsigned c_ = BPF_TERM_ADDR(4 * (w) + 2), d_ = BPF_TERM_ADDR(4 * (w) + 3);   \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], b_, 0);                    \
+            BPF_RD64(X[sl][2], c_, 0); BPF_RD64(X[sl][3], d_, 0);                    \
         }                                                                                      \
-        BPF_RD64(X[(u) & 3][0], a_, 0); BPF_RD64(X[(u) & 3][1], a_, 512);                      \
-        BPF_RD64(X[(u) & 3][2], a_, 1024); BPF_RD64(X[(u) & 3][3], a_, 1536);                  \
     }
+                BPF_ISSUE_U(0, 0) BPF_ISSUE_U(1, 1) BPF_ISSUE_U(2, 2)
+                static_assert(AH == 3, "prologue");
+                f32x2 ac[RPT];
+                if constexpr (MULTI) {
 #pragma unroll
-                for (int u = 0; u < AH; ++u) BPF_ISSUE_U(u)
-                for (int it = 0; it < n_mine; ++it) {
-                    f32x2 ac[4];
+                    for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
+                }
+                int part = 0;                 // MULTI: parts of the current source already accumulated
+                const int n_it = MULTI ? n_mine * nparts : n_mine;
+                auto part_body = [&](auto ph_c) __attribute__((always_inline)) {
+                    constexpr int PH = decltype(ph_c)::value;
                     i32x2 sp_u;
-                    // the header of the next source (the table is padded by one round of records: no clamp)
+                    // the header of the next part (the table is padded by one round of records: no clamp)
                     p = (const int*)((const char*)p + rec_stride);
                     BPF_LOADX2(h_next, vzero, p, 0);
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        // ---- keep three units in flight ahead of unit u: the unit issued now belongs to
-                        // this source (u + 3 < NU) or is one of the first three of the NEXT source, whose
-                        // quad 0 was requested at step 3 and is followed by Q - 2 younger loads
-                        if (u + AH < NU) {
-                            if ((u + AH) % 4 == 0)   // first use of quad (u + 3) / 4, loaded one source ago
-                                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R[((u + AH) >> 2) % Q]) : "n"(Q - 1));
-                            BPF_ISSUE_U(u + AH)
+                    // one step per unit, u a compile-time constant (bpf_for_each: a fold over the
+                    // unit indices -- every wait count below is an immediate)
+                    auto unit_step = [&](auto uc) __attribute__((always_inline)) {
+                        constexpr int u = decltype(uc)::value;
+                        // (operands of an asm statement alone do not make a generic lambda capture)
+                        (void)&vzero; (void)&p; (void)&R; (void)&h_next; (void)&h_cur; (void)&X; (void)&ac; (void)&sp_u;
+                        constexpr int SL_ISSUE = (u + AH + PH) & 3, SL_USE = (u + PH) & 3;
+                        // ---- keep three units in flight ahead of unit u.  The unit issued now belongs
+                        // to this part (u + 3 < NU) or is one of the first three of the NEXT part.  The
+                        // first term of a quad is the first use of that quad's re-load: vector loads
+                        // return in order, so "at most n younger loads outstanding" = it has landed.
+                        if constexpr (u + AH < NU) {
+                            if constexpr (((u + AH) * TPU) % 4 == 0) {
+                                // quad qq was requested one part ago, followed by the rest of that part's
+                                // refills (Q - 1 - qq), this part's header and the refills behind units < u
+                                constexpr int qq = ((u + AH) * TPU) >> 2;
+                                constexpr int younger = (Q - 1 - qq) + 1 + bpf_refills_before(u, -1, Q, TPU);
+                                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(R[qq]) : "n"(younger));
+                            }
+                            BPF_ISSUE_U(u + AH, SL_ISSUE)
                         } else {
-                            if (u + AH == NU)
-                                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(R[0]), "+v"(h_next) : "n"(Q - 2));
-                            BPF_ISSUE_U(u + AH - NU)
+                            if constexpr (((u + AH - NU) * TPU) % 4 == 0) {
+                                // the next part's quad qq, requested in this part behind unit bpf_ur(qq);
+                                // younger: this part's refills of the quads > qq issued so far.  The header
+                                // of the next part is older than all of them.
+                                constexpr int qq = ((u + AH - NU) * TPU) >> 2;
+                                static_assert(bpf_ur(qq, TPU) <= u - 1, "quad not requested yet");
+                                constexpr int younger = bpf_refills_before(u, qq, Q, TPU);
+                                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(R[qq]), "+v"(h_next) : "n"(younger));
+                            }
+                            BPF_ISSUE_U(u + AH - NU, SL_ISSUE)
                         }
                         asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
                         // the weight reaches v_pk_fma_f32 as the high half of an SGPR pair: with three
                         // 64-bit VGPR operands the instruction is register-read bound (measured: the
                         // kernel lost 5 points of the LDS rate with the weight in a VGPR pair)
-                        i32x2 sp;
-                        if constexpr (UNI) { if (u == 0) { sp_u[0] = 0; sp_u[1] = __builtin_amdgcn_readfirstlane(h_cur[1]); } sp = sp_u; }
-                        else if ((u & 1) == 0) { sp_u[0] = 0; sp_u[1] = __builtin_amdgcn_readfirstlane(R[u >> 2][2 * ((u >> 1) & 1) + 1]); sp = sp_u; }
-                        else sp = sp_u;
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            if (u == 0) BPF_PKFMA0(ac[jj], sp, X[u & 3][jj]);
-                            else BPF_PKFMA(ac[jj], sp, X[u & 3][jj]);
-                        }
-                        // ---- quad u / 4 is consumed (addresses issued, weights multiplied): refill it
-                        if (u % 4 == 3) {
-                            switch (u >> 2) {
-                                case 0: BPF_LOADQ(0); break; case 1: BPF_LOADQ(1); break;
-                                case 2: BPF_LOADQ(2); break; case 3: BPF_LOADQ(3); break;
-                                case 4: BPF_LOADQ(4); break; case 5: BPF_LOADQ(5); break;
-                                case 6: BPF_LOADQ(6); break; default: BPF_LOADQ(7); break;
+                        for (int k = 0; k < TPU; ++k) {
+                            const int tm = u * TPU + k;      // term of the part: station tm / 2, phase tm % 2
+                            if constexpr (UNI) {
+                                if (tm == 0) { sp_u[0] = 0; sp_u[1] = __builtin_amdgcn_readfirstlane(h_cur[1]); }
+                            } else if ((tm & 1) == 0) {
+                                sp_u[0] = 0;
+                                sp_u[1] = __builtin_amdgcn_readfirstlane(R[tm >> 2][2 * ((tm >> 1) & 1) + 1]);
+                            }
+                            const i32x2 sp = sp_u;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) {
+                                if (!MULTI && tm == 0) BPF_PKFMA0(ac[r], sp, X[SL_USE][k * RPT + r]);
+                                else BPF_PKFMA(ac[r], sp, X[SL_USE][k * RPT + r]);
                             }
                         }
-                    }
-                    // ---- max / arg-max update, strict >: 8 compares, then 16 selects; the next source's
-                    // first three units are in flight meanwhile
-                    {
+                        // ---- quads whose last term this unit held are consumed: refill them
+                        if constexpr ((u * TPU + TPU) % 4 == 0) {
+                            constexpr int q0 = (u * TPU + TPU) / 4 - 1;
+                            static_assert(bpf_ur(q0, TPU) == u, "refill slot");
+                            BPF_LOADQC(q0);
+                        }
+                    };
+                    bpf_for_each(unit_step, std::make_integer_sequence<int, NU>{});
+                    // ---- max / arg-max update behind a source's last part, strict >: TPW compares, then
+                    // 2 TPW selects; the next part's first three units are in flight meanwhile
+                    bool last = true;
+                    if constexpr (MULTI) { ++part; last = part == nparts; }
+                    if (last) {
                         unsigned long long mk[TPW];
 #pragma unroll
                         for (int j = 0; j < TPW; ++j)
@@ -255,25 +346,76 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(bestg[j]) : "v"(ac[j >> 1][j & 1]), "s"(mk[j]));
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(argg[j]) : "v"(h_cur[0]), "s"(mk[j]));
                         }
+                        if constexpr (MULTI) {
+                            part = 0;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
+                        }
                     }
                     h_cur = h_next;
+                };
+                if constexpr (NU % 4 == 0) {
+                    for (int it = 0; it < n_it; ++it) part_body(std::integral_constant<int, 0>{});
+                } else {
+                    static_assert(NU % 4 == 2, "even number of units per part");
+                    int it = 0;
+                    for (; it + 1 < n_it; it += 2) {
+                        part_body(std::integral_constant<int, 0>{});
+                        part_body(std::integral_constant<int, 2>{});
+                    }
+                    if (it < n_it) part_body(std::integral_constant<int, 0>{});   // odd number of parts
                 }
-                // the three units issued past the wave's last source (they read whatever record follows:
-                // valid LDS addresses of some group, or the zero slab) and the last refills
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // the three units issued past the wave's last part (they read whatever record follows:
+                // valid LDS addresses of some group, or the zero slab) and the last refills.  Every
+                // register they load is an operand of the wait: the compiler must keep them apart and
+                // untouched until here, although nothing reads them any more.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                             : "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[0][2]), "+v"(X[0][3]), "+v"(X[1][0]), "+v"(X[1][1]),
+                               "+v"(X[1][2]), "+v"(X[1][3]), "+v"(X[2][0]), "+v"(X[2][1]), "+v"(X[2][2]), "+v"(X[2][3]),
+                               "+v"(X[3][0]), "+v"(X[3][1]), "+v"(X[3][2]), "+v"(X[3][3]), "+v"(h_cur)
+                             :: "memory");
+                BPF_VMWAIT_ALL();
 #undef BPF_ISSUE_U
+#undef BPF_TERM_ADDR
 #undef BPF_LOADQ
+#undef BPF_LOADQC
 #undef BPF_VMWAIT_ALL
             };
-            switch (run.nst) {   // wave-uniform, once per run
-                case 4: walk(std::integral_constant<int, 4>{}); break;
-                case 6: walk(std::integral_constant<int, 6>{}); break;
-                case 8: walk(std::integral_constant<int, 8>{}); break;
-                case 10: walk(std::integral_constant<int, 10>{}); break;
-                case 12: walk(std::integral_constant<int, 12>{}); break;
-                case 14: walk(std::integral_constant<int, 14>{}); break;
-                case 16: walk(std::integral_constant<int, 16>{}); break;
-                default: break;
+            using std::integral_constant;
+            using one_part = std::false_type;
+            using parts = std::true_type;
+            // wave-uniform, once per run.  Tile 512 serves <= 16 stations per source (one part);
+            // the smaller tiles take any number of parts.
+            if constexpr (TPW == 8) {
+                switch (run.tp) {
+                    case 4: walk(integral_constant<int, 4>{}, one_part{}); break;
+                    case 6: walk(integral_constant<int, 6>{}, one_part{}); break;
+                    case 8: walk(integral_constant<int, 8>{}, one_part{}); break;
+                    case 10: walk(integral_constant<int, 10>{}, one_part{}); break;
+                    case 12: walk(integral_constant<int, 12>{}, one_part{}); break;
+                    case 14: walk(integral_constant<int, 14>{}, one_part{}); break;
+                    case 16: walk(integral_constant<int, 16>{}, one_part{}); break;
+                    default: break;
+                }
+            } else if constexpr (TPW == 4) {
+                switch (run.tp) {
+                    case 6: walk(integral_constant<int, 6>{}, parts{}); break;
+                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
+                    case 10: walk(integral_constant<int, 10>{}, parts{}); break;
+                    case 12: walk(integral_constant<int, 12>{}, parts{}); break;
+                    case 14: walk(integral_constant<int, 14>{}, parts{}); break;
+                    case 16: walk(integral_constant<int, 16>{}, parts{}); break;
+                    default: break;
+                }
+            } else {
+                switch (run.tp) {
+                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
+                    case 12: walk(integral_constant<int, 12>{}, parts{}); break;
+                    case 16: walk(integral_constant<int, 16>{}, parts{}); break;
+                    case 20: walk(integral_constant<int, 20>{}, parts{}); break;
+                    case 24: walk(integral_constant<int, 24>{}, parts{}); break;
+                    default: break;
+                }
             }
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
@@ -307,28 +449,29 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     }
 }
 
-int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long tile_lo,
+int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_t N, long long tile_lo,
                      long long tile_hi, hipStream_t stream, float* beam, int32_t* arg, int n_split,
                      long long split_stride)
 {
     if (tile_hi <= tile_lo) return 0;
     const long long n_tiles = tile_hi - tile_lo;
-    const size_t lds = std::max(pl->lds_bytes, (size_t)2 * BPF_WPB * BPF_TILE * sizeof(float));
+    const size_t lds = std::max(fc.lds_bytes, (size_t)2 * BPF_WPB * fc.tile * sizeof(float));
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)std::max(1, n_split));  // x: multiple of 8 (XCD-aware tile order)
     // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
-    const int desc_waves = (int)std::min<size_t>(BPF_DESC_MAX, (2 * pl->S * pl->P + 63) / 64 * 64) / 64;
-#define BPF_LAUNCH(UNI)                                                                            \
+    const int desc_waves = fc.desc_waves;
+#define BPF_LAUNCH(UNI, TPW)                                                                       \
     do {                                                                                           \
-        auto kern = bp_beam_fast_kernel<UNI>;                                                      \
+        auto kern = bp_beam_fast_kernel<UNI, TPW>;                                                 \
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,                                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
-            U, (long long)N, pl->d_fgroups, pl->n_groups, pl->d_fruns, pl->d_fwins,                \
-            pl->d_frecs, pl->fast_rec_dw, pl->id_offset, tile_lo, n_tiles, beam, arg, desc_waves, \
-            split_stride);                                                                          \
+            U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
+            fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride);         \
     } while (0)
-    if (pl->fast_uniform) BPF_LAUNCH(true); else BPF_LAUNCH(false);
+    if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
+    else if (fc.tile == 256) { if (fc.uniform) BPF_LAUNCH(true, 4); else BPF_LAUNCH(false, 4); }
+    else { if (fc.uniform) BPF_LAUNCH(true, 2); else BPF_LAUNCH(false, 2); }
 #undef BPF_LAUNCH
     BPMF_LAUNCH_CHECK();
     return 0;

@@ -23,20 +23,40 @@ struct BpSource {
 };
 
 // ---- interior-tile fast path (bp_fast.hip) ----
-// A group's sources are listed once more, partitioned into RUNS of equal (even-padded) station
-// count, ascending id inside a run; one record of `rec_dw` dwords per source:
+// A group's sources are listed once more, partitioned into RUNS of equal (padded) station count,
+// ascending id inside a run.  A source is `nparts` PARTS of `tp` stations (tp even, <= 16, <= 24 at
+// tile 128; one part up to 16 stations); one record of `rec_dw` dwords per part:
 //   uniform weights : [id, weight, addrP_0, addrS_0, addrP_1, addrS_1, ...]   LDS byte addresses
 //   per-station     : [id, 0, offs_0, w_0, offs_1, w_1, ...]   offs = float offsets P | S << 16
 // Padding stations address the zero slab (offset 0) with the source's weight (or weight 0).
-struct BpRun { int first_rec, n_src, nst, pad; };          // nst: stations of the run (even, 2..16)
+// Records of a run are laid out so that a wave's consecutive parts are 16 records apart:
+// record (first_rec + ((m / 16) * nparts + part) * 16 + m % 16) for the m-th source of the run.
+struct BpRun { int first_rec, n_src, tp, nparts; };
 struct BpFastGroup { int first_run, n_run, first_win, n_win; };
 // one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
 // offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
 struct BpWindow { int row, gofs, dst, len; };
-// LDS floats [BPF_DESC_OFS, BPF_DESC_OFS + 4 * BPF_DESC_MAX) hold the NEXT group's window
-// descriptors (copied there while the current group is computed); plans with dual windows leave
-// this slab free behind the zero slab
-constexpr int BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
+// LDS floats [0, BPF_ZERO_SLAB) are the zero slab (padding terms read it), floats
+// [BPF_DESC_OFS, BPF_DESC_OFS + 4 * BPF_DESC_MAX) hold the NEXT group's window descriptors
+// (copied there while the current group is computed)
+constexpr int BPF_ZERO_SLAB = 512, BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
+
+// One station-count class of sources with its own tile (device tables of bp_fast.hip)
+struct BpFastClass {
+    int tile = 512;              // 512 / 256 / 128 time samples per workgroup
+    bool uniform = false;        // every source's non-zero weights are equal: ready-made addresses
+    int rec_dw = 0;              // dwords per record
+    int n_groups = 0;
+    int desc_waves = 1;          // waves that copy the next group's window descriptors
+    size_t lds_bytes = 0;
+    size_t n_sources = 0;
+    int max_stations = 0;        // diagnostics
+    BpFastGroup* d_groups = nullptr;
+    BpRun* d_runs = nullptr;
+    BpWindow* d_wins = nullptr;
+    int* d_recs = nullptr;
+};
+constexpr int BPF_MAX_CLASSES = 3;
 
 }  // namespace bpmf
 
@@ -62,26 +82,25 @@ struct bpmf_bp_plan {
     int4* d_recs = nullptr;      // [K, nsv/2]
     int4* d_hdr2 = nullptr;      // [K] headers with the station count in .w
     void* d_termsv = nullptr;    // [K, ntv] BpTermV (bp.hip)
-    // interior-tile fast path (dual plans with <= 16 stations per source)
+    // interior-tile fast path: 1-3 station-count classes of sources, each with its own tile
     bool fast = false;
-    bool fast_uniform = false;   // every source's non-zero weights are equal
-    int fast_rec_dw = 0;         // dwords per record
+    int n_classes = 0;
+    bpmf::BpFastClass cls[bpmf::BPF_MAX_CLASSES];
+    bool fast_shares_generic = false;  // the single class was built from the generic (dual) plan: the
+                                       // edge tiles run the 8-byte-gather flavour of the generic kernel
     int tmin_all = 0, tmax_all = 0;   // extreme used moveouts over all sources
     // the few edge tiles of a day run the general kernel on a side stream, beside the interior
     // kernel (fork / join through the two events): a serial launch of 3-6 workgroups would add the
     // full duration of one tile (5 ms at cfg3) to every call.  A plan serves one call at a time.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bpmf::BpFastGroup* d_fgroups = nullptr;
-    bpmf::BpRun* d_fruns = nullptr;
-    bpmf::BpWindow* d_fwins = nullptr;
-    int* d_frecs = nullptr;
 };
 
 namespace bpmf {
-// bp_fast.hip: running (max, arg-max) over all sources for the tiles [tile_lo, tile_hi), every
-// one of which lies inside [-tmin_all, N - tmax_all) (no bounds test per source).
-int launch_beam_fast(const bpmf_bp_plan* pl, const float* U, size_t N, long long tile_lo,
+// bp_fast.hip: running (max, arg-max) over the sources of one class for its tiles [tile_lo, tile_hi)
+// (units of fc.tile samples), every one of which lies inside [-tmin_all, N - tmax_all) (no bounds
+// test per source).
+int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_t N, long long tile_lo,
                      long long tile_hi, hipStream_t stream, float* beam, int32_t* arg,
                      int n_split = 1, long long split_stride = 0);
 }

@@ -27,7 +27,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 enum Option {
     OPT_BP_LDS_KB, OPT_BP_MAX_GROUP, OPT_BP_TPT, OPT_BP_REORDER, OPT_BP_DUAL, OPT_BP_PACKED,
     OPT_BP_WPS, OPT_BP_UVGPR, OPT_BP_FAST, OPT_BP_FAST_UNIFORM, OPT_BP_SPLIT, OPT_BP_WPB,
-    OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
+    OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_BP_FAST_TILE, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
     OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_COUNT
 };
 long option(Option which);

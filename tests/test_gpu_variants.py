@@ -205,16 +205,19 @@ def test_bp_kernel_and_plan_knobs(oracle_lib, env, hip_opts):
     _bp_check(oracle_lib, f, tau, wp, ws, str(env))
 
 
-@pytest.mark.parametrize("dual,S,S_used,gather,waves", [("1", 20, 10, 8, 16), ("0", 20, 10, 4, 24), ("1", 20, 16, 8, 16),
-                                                        ("1", 20, 17, 4, 16), ("1", 20, 20, 4, 16),
-                                                        ("1", 34, 31, 4, 16), ("1", 34, 32, 4, 16),
-                                                        ("1", 34, 33, 4, 8)])
-def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, waves, hip_opts):
-    """Dual (8-byte gather) plans for <= 16 weighted stations per source, 4-byte gathers otherwise;
-    both must give the oracle's result, ties included (many equal beams: integer-valued features)."""
+@pytest.mark.parametrize("dual,S,S_used,gather,waves,tile", [(1, 20, 10, 8, 16, 512), (0, 20, 10, 4, 24, 512), (1, 20, 16, 8, 16, 512),
+                                                             (1, 20, 17, 8, 16, 256), (1, 20, 20, 8, 16, 256),
+                                                             (1, 34, 31, 8, 16, 256), (1, 34, 32, 8, 16, 256),
+                                                             (1, 34, 33, 8, 16, 128), (0, 34, 33, 4, 8, 512),
+                                                             (0, 34, 31, 4, 16, 512)])
+def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, waves, tile, hip_opts):
+    """Dual (8-byte gather) plans whatever the number of weighted stations per source -- tile 512 up to
+    16 stations, 256 up to 32, 128 beyond (round 3; rounds 1-2 fell back to 4-byte gathers from 17
+    stations on) --, 4-byte gathers with bp.dual = 0; every variant must give the oracle's result,
+    ties included (many equal beams: integer-valued features)."""
     import torch
     from seismic_bpmf_amd import BeamformerGPU
-    hip_opts("bp.dual", int(dual))
+    hip_opts("bp.dual", dual)
     rng = np.random.default_rng(5 + S_used)
     K, P, N = 400, 2, 4000
     f = rng.integers(0, 3, (S, 3, N)).astype(np.float32)      # exact ties between sources
@@ -227,8 +230,12 @@ def test_bp_plan_info_and_gather_width(oracle_lib, dual, S, S_used, gather, wave
     ws[K // 3] = ws[K // 3 + 7]
     bf = BeamformerGPU(tau, ws)
     info = bf.plan_info()
-    assert info["gather_bytes"] == gather and info["tile"] == 512 and info["n_groups"] >= 1
-    assert info["waves_per_cu"] == waves
+    # (`tile`: the largest the class may take; the cost model goes smaller when the windows of this
+    # random geometry -- every group touches every station -- only fit tiny groups)
+    assert info["gather_bytes"] == gather and info["n_groups"] >= 1, info
+    assert info["tile"] == tile or (dual and info["tile"] in (256, 128) and info["tile"] < tile), info
+    assert info["waves_per_cu"] == waves, info
+    assert info["n_classes"] == (1 if dual else 0), info
     for oob in ("strict", "flexible"):
         mb, ma = bf.run(torch.as_tensor(f), wp, "max", oob)
         ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
@@ -292,6 +299,117 @@ def test_bp_fast_path_station_counts_and_weight_kinds(oracle_lib, n_used, unifor
         bf.close()
     for fast in ("1", "0"):
         assert np.array_equal(got[fast][0], ob) and np.array_equal(got[fast][1], oa), (fast, n_used, uniform, oob)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_used,uniform", [(17, True), (18, False), (20, True), (20, False), (23, True), (24, True),
+                                            (27, False), (32, True), (33, True), (40, True), (40, False), (47, True),
+                                            (64, True)])
+def test_bp_fast_path_dense_station_weights(oracle_lib, n_used, uniform, hip_opts):
+    """More than 16 weighted stations per source (round 3): the sources run the 8-byte-gather kernel
+    on tiles of 256 / 128 samples as 2-5 records ("parts") whose accumulators are carried.  Every
+    padded total the kernels serve, uniform and per-station weights, mixed counts inside a group,
+    negative moveouts (edge tiles through the general kernel), exact ties, strict and flexible --
+    against the oracle and against the general kernels alone (bp.fast = 0), bit for bit."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(1000 * n_used + int(uniform))
+    K, S, C, P, N = 300, max(24, n_used + 4), 3, 2, 7000
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4   # ties
+    tau = rng.integers(-60, 140, (K, S, P)).astype(np.int32)
+    tau[100:120] = tau[200:220]                                   # identical sources -> lowest id must win
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        n = n_used if k % 4 else max(17, n_used - (k // 4) % 5)    # mixed counts -> several runs per group
+        sel = rng.choice(S, n, replace=False)
+        ws[k, sel] = 0.125 if uniform else rng.uniform(0.1, 1.0, n).astype(np.float32)
+    ws[100:120] = ws[200:220]
+    ws[33] = 0.0
+    want = {oob: oracle_lib.beamform(f, tau, wp, ws, oob, "max") for oob in ("strict", "flexible")}
+    for fast in (1, 0):
+        hip_opts("bp.fast", fast)
+        bf = BeamformerGPU(tau, ws)
+        info = bf.plan_info()
+        if fast:
+            assert info["n_classes"] >= 1 and info["gather_bytes"] == 8 and info["tile"] in (256, 128), info
+        else:
+            assert info["n_classes"] == 0, info
+        for oob in ("strict", "flexible"):
+            b, a = bf.run(f, wp, "max", oob)
+            assert np.array_equal(b.cpu().numpy(), want[oob][0]), (fast, n_used, uniform, oob)
+            assert np.array_equal(a.cpu().numpy(), want[oob][1]), (fast, n_used, uniform, oob)
+        bf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [512, 256, 128])
+@pytest.mark.parametrize("uniform", [True, False])
+def test_bp_fast_path_every_part_size_on_every_tile(oracle_lib, tile, uniform, hip_opts):
+    """bp.fast_tile forces the tile of every class: station counts 1..16 then run the 256- and
+    128-sample kernels too (part sizes 6..16 resp. 8 / 12 / 16, one part), so that every
+    instantiated (tile, part size) pair is compared with the oracle."""
+    from seismic_bpmf_amd import BeamformerGPU
+    hip_opts("bp.fast_tile", tile)
+    rng = np.random.default_rng(tile + int(uniform))
+    K, S, C, P, N = 480, 18, 3, 2, 6000
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4
+    tau = rng.integers(-40, 160, (K, S, P)).astype(np.int32)
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        n = 1 + k % 16
+        ws[k, rng.choice(S, n, replace=False)] = 0.5 if uniform else rng.uniform(0.1, 1.0, n).astype(np.float32)
+    ob, oa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    bf = BeamformerGPU(tau, ws)
+    info = bf.plan_info()
+    assert info["n_classes"] == 1 and info["class_tile"][0] == tile, info
+    b, a = bf.run(f, wp, "max", "strict")
+    bf.close()
+    assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(a.cpu().numpy(), oa), (tile, uniform)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [2600, 9000])
+def test_bp_fast_path_mixed_station_count_classes(oracle_lib, N, hip_opts):
+    """One grid, three classes: most sources with <= 16 weighted stations (tile 512), a handful with
+    17-32 (tile 256) and with 33-48 (tile 128), one source without any station.  Each class kernel
+    writes its own partial rows; the merge keeps the larger beam and the lowest id -- checked with
+    sources of different classes that produce exactly equal beams.  Also with forced group ranges."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(N)
+    K, S, C, P = 500, 50, 3, 2
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 2).astype(np.float32) / 2
+    tau = rng.integers(-30, 120, (K, S, P)).astype(np.int32)
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        n = 10 if k % 50 else (17 if k % 100 else 40)
+        ws[k, rng.choice(S, n, replace=False)] = 1.0
+    ws[7] = 0.0
+    # three sources of three different classes with exactly equal beams: stations 12.. carry no signal
+    # (their terms add an exact 0), stations 0..4 a strong one; the lowest id must win the merge
+    f[12:] = 0.0
+    f[:5] *= 3.0
+    for k, n_silent in ((100, 5), (250, 35), (300, 20)):
+        ws[k] = 0.0
+        ws[k, :5] = 1.0
+        ws[k, 12:12 + n_silent] = 1.0
+        tau[k] = tau[100]
+    want = {oob: oracle_lib.beamform(f, tau, wp, ws, oob, "max") for oob in ("strict", "flexible")}
+    bf = BeamformerGPU(tau, ws)
+    info = bf.plan_info()
+    assert info["n_classes"] == 3 and info["class_tile"][2] == 128 and info["class_sources"] == [490, 5, 4], info
+    try:
+        for split in (-1, 1, 3):
+            hip_opts("bp.split", split)
+            for oob in ("strict", "flexible"):
+                b, a = bf.run(f, wp, "max", oob)
+                assert np.array_equal(b.cpu().numpy(), want[oob][0]), (N, split, oob)
+                assert np.array_equal(a.cpu().numpy(), want[oob][1]), (N, split, oob)
+        full = oracle_lib.beamform(f, tau, wp, ws, "strict", "none")
+        assert np.array_equal(bf.run(f, wp, "none", "strict").cpu().numpy(), full)
+    finally:
+        bf.close()
 
 
 @pytest.mark.gpu

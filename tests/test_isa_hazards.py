@@ -106,7 +106,8 @@ def test_beam_kernels_touch_no_register_in_flight(tmp_path):
 
 @pytest.mark.timeout(900)
 def test_fast_beam_kernels_touch_no_register_in_flight(tmp_path):
-    """bp_fast.hip: the interior-tile kernels (uniform-weight and per-station records)."""
+    """bp_fast.hip: the interior-tile kernels (uniform-weight and per-station records, tiles of
+    512 / 256 / 128 samples)."""
     from seismic_bpmf_amd.build import ARCH, CSRC, find_hipcc
     out = tmp_path / "bp_fast.s"
     cmd = [find_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
@@ -115,10 +116,10 @@ def test_fast_beam_kernels_touch_no_register_in_flight(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     kernels = check_inflight.split_kernels(out.read_text())
     names = [n for n in kernels if "bp_beam_fast_kernel" in n]
-    assert len(names) == 2
+    assert len(names) == 6
     for n in names:
         body = kernels[n]
-        assert sum(t.startswith("ds_read_b64") for t in body) > 500       # the unrolled gathers are there
+        assert sum(t.startswith("ds_read_b64") for t in body) > 100       # the unrolled gathers are there
         assert not any("scratch_" in t for t in body)                      # no spills
         bad = check_inflight.check_kernel(body)
         assert not bad, f"{n}: {bad[:4]}"
