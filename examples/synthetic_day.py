@@ -66,6 +66,7 @@ def matched_filter(full):
     det, cc = workflow.matched_filter_detections(
         mf["templates"], mf["moveouts"], mf["weights"], mf["data"], step=1, sr=sr,
         threshold_window_dur=1800.0 if full else 600.0, minimum_interevent_time=5.0, n_dev=8.0,
+        remove_edges=False,
         white_noise=np.random.default_rng(5).standard_normal(500).astype(np.float32))
     t1 = tic()
     n_det = sum(len(v) for v in det.values())

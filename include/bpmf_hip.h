@@ -269,6 +269,40 @@ int bpmf_extract_candidates_dev(const float *d_series, const float *d_thr_window
                                 bpmf_stream_t stream, uint32_t *d_count,
                                 bpmf_candidate *d_records);
 
+int bpmf_extract_candidates_mad_dev(const float *d_series, const float *d_thr_windows,
+                                    const float *d_row_cap, size_t n_rows, size_t n, size_t window,
+                                    size_t shift, uint32_t capacity, bpmf_stream_t stream,
+                                    uint32_t *d_count, bpmf_candidate *d_records);
+
+/* ------------------------------------------------- robust statistics (stats.hip) --- */
+/* np.median and MAD (median of |x - median|, float32 like NumPy) of every row of a (rows, n)
+ * device array; skip_zeros != 0: over the samples != 0 only (`a[a != 0]`).  NaN for an empty
+ * selection or a row that holds a NaN.  d_n_zero (may be NULL) receives the zeros per row.
+ * Serves saturated_envelopes (BPMF/template_search.py:1547-1561). */
+int bpmf_row_median_mad_dev(const float *d_x, size_t rows, size_t n, int skip_zeros,
+                            bpmf_stream_t stream, float *d_median, float *d_mad, int64_t *d_n_zero);
+
+/* time_dependent_threshold(time_series, sliding_window, overlap, threshold_type="mad",
+ * white_noise) of BPMF/similarity_search.py:1079-1113 for every row of a (rows, n) CC matrix:
+ * `window` = sliding_window, `shift` = int((1 - overlap) * sliding_window).  d_thr_windows
+ * (rows, n_windows) receives centre + num_dev * deviation after the two neighbour-maximum
+ * passes; d_thr_full (rows, n), if not NULL, the threshold of every sample.  Row r replaces its
+ * zeros, in order, by white_noise[0 .. n_zeros(r)) * deviation0 + centre0; -1 if a row holds
+ * more zeros than n_noise. */
+size_t bpmf_tdt_mad_num_windows(size_t n, size_t window, size_t shift);
+size_t bpmf_tdt_mad_workspace_bytes(size_t rows, size_t n, size_t window, size_t shift);
+int bpmf_tdt_mad_dev(const float *d_series, const float *d_white_noise, size_t n_noise,
+                     float num_dev, size_t rows, size_t n, size_t window, size_t shift,
+                     void *d_workspace, size_t workspace_bytes, bpmf_stream_t stream,
+                     float *d_thr_windows, float *d_thr_full, int64_t *d_n_zero);
+
+/* scipy.stats.kurtosis(row) (Fisher, biased: m4 / m2^2 - 3, NaN for a constant row) of every row,
+ * float32 with NumPy's pairwise summation order: the `sanity_check` of
+ * MatchedFilter._find_detections_t (BPMF/similarity_search.py:633-642). */
+size_t bpmf_row_kurtosis_workspace_bytes(size_t rows, size_t n);
+int bpmf_row_kurtosis_dev(const float *d_x, size_t rows, size_t n, void *d_workspace,
+                          size_t workspace_bytes, bpmf_stream_t stream, float *d_kurtosis);
+
 /* ------------------------------------------------------------ running kurtosis --- */
 /*
  * Device version of BPMF.clib.kurtosis (BPMF/clib.py:86-102 -> BPMF/libc.c:11-53): kurto[ch][n],

@@ -68,6 +68,14 @@ SIGNATURES = {
                                             C.c_int, C.c_int, _i]),
     "bpmf_extract_candidates_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp,
                                               _vp, _vp]),
+    "bpmf_extract_candidates_mad_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp,
+                                                  _vp, _vp]),
+    "bpmf_row_median_mad_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp]),
+    "bpmf_tdt_mad_num_windows": (_sz, [_sz, _sz, _sz]),
+    "bpmf_tdt_mad_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
+    "bpmf_tdt_mad_dev": (C.c_int, [_vp, _vp, _sz, C.c_float, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "bpmf_row_kurtosis_workspace_bytes": (_sz, [_sz, _sz]),
+    "bpmf_row_kurtosis_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
 }
 
 _lib = None

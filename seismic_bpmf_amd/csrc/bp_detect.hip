@@ -21,93 +21,10 @@
 // (utils.py:2334-2345) run on the list gives the same survivors above the threshold as the run on
 // all local maxima.  Suppression, the exact float64 threshold test at the few survivors, the
 // +-mpd/2 snap and np.unique run on that list on the host (seismic_bpmf_amd/workflow.py).
-#include "common.h"
+#include "select.h"
 #include "../../include/bpmf_hip.h"
 
 namespace bpmf {
-
-__device__ __forceinline__ unsigned f32_key(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key_f32(unsigned k)
-{
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
-constexpr int SEL_THREADS = 1024;
-constexpr int SEL_BINS = 2048;
-
-// k-th smallest (0-based) key of the window; DEV: keys of |x - centre| instead of x.
-// hist: SEL_BINS counters in LDS; sel: two words of LDS for the hand-over between levels.
-template <bool DEV>
-__device__ unsigned window_select(const float* __restrict__ x, int len, float centre, unsigned rank,
-                                  unsigned* hist, unsigned* sel)
-{
-    const int tid = threadIdx.x;
-    unsigned prefix = 0;          // the key bits fixed so far (right-aligned)
-    int done = 0;                 // how many
-#pragma unroll 1
-    for (int level = 0; level < 3; ++level) {
-        const int nbits = level == 2 ? 10 : 11;
-        const int shift = 32 - done - nbits;
-        for (int b = tid; b < SEL_BINS; b += SEL_THREADS) hist[b] = 0;
-        __syncthreads();
-        for (int i = tid; i < len; i += SEL_THREADS) {
-            float v = x[i];
-            if (DEV) v = fabsf(__fsub_rn(v, centre));
-            const unsigned k = f32_key(v);
-            if (done == 0 || (k >> (32 - done)) == prefix)
-                atomicAdd(&hist[(k >> shift) & ((1u << nbits) - 1)], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // lane l owns bins [32 l, 32 l + 32): its total, an inclusive scan over the lanes, then
-            // the lane whose range holds `rank` walks its bins
-            unsigned tot = 0;
-            for (int b = 0; b < 32; ++b) tot += hist[tid * 32 + b];
-            unsigned inc = tot;
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned o = __shfl_up(inc, d, 64);
-                if (tid >= d) inc += o;
-            }
-            const unsigned exc = inc - tot;
-            if (rank >= exc && rank < inc) {
-                unsigned r = rank - exc;
-                int b = 0;
-                for (; b < 32; ++b) {
-                    const unsigned h = hist[tid * 32 + b];
-                    if (r < h) break;
-                    r -= h;
-                }
-                sel[0] = (unsigned)(tid * 32 + b);
-                sel[1] = r;
-            }
-        }
-        __syncthreads();
-        prefix = (prefix << nbits) | sel[0];
-        rank = sel[1];
-        done += nbits;
-        __syncthreads();
-    }
-    return prefix;
-}
-
-// np.median of a float32 window: the middle order statistic, or the float32 mean of the two middle
-// ones; NaN if the window holds a NaN (np.median's own rule).
-template <bool DEV>
-__device__ float window_median(const float* __restrict__ x, int len, float centre, unsigned* hist,
-                               unsigned* sel)
-{
-    const unsigned hi = window_select<DEV>(x, len, centre, (unsigned)(len / 2), hist, sel);
-    float m = key_f32(hi);
-    if ((len & 1) == 0) {
-        const unsigned lo = window_select<DEV>(x, len, centre, (unsigned)(len / 2 - 1), hist, sel);
-        m = (key_f32(lo) + m) / 2.0f;      // float32 mean of the two middle values (exact halving)
-    }
-    return m;
-}
 
 // window q (1-based, as the reference's loop): samples [q shift, min(n, q shift + window))
 __global__ __launch_bounds__(SEL_THREADS) void bp_window_stats_kernel(
@@ -115,7 +32,7 @@ __global__ __launch_bounds__(SEL_THREADS) void bp_window_stats_kernel(
     float* __restrict__ med, float* __restrict__ mad)
 {
     __shared__ unsigned hist[SEL_BINS];
-    __shared__ unsigned sel[2];
+    __shared__ unsigned sel[4];
     __shared__ int has_nan;
     const long long q = (long long)blockIdx.x + 1;
     const long long i1 = q * shift;
@@ -136,8 +53,8 @@ __global__ __launch_bounds__(SEL_THREADS) void bp_window_stats_kernel(
         if (threadIdx.x == 0) { med[q] = __uint_as_float(0x7fc00000u); mad[q] = __uint_as_float(0x7fc00000u); }
         return;
     }
-    const float m = window_median<false>(x, len, 0.0f, hist, sel);
-    const float d = window_median<true>(x, len, m, hist, sel);
+    const float m = window_median<false>(x, len, len, 0.0f, hist, sel);
+    const float d = window_median<true>(x, len, len, m, hist, sel);
     if (threadIdx.x == 0) { med[q] = m; mad[q] = d; }
 }
 

@@ -10,6 +10,7 @@
 // (series, window) -- 24-32 k threads for a day of 500 templates -- each streaming its window.
 // This is the one HBM-bound stage of the workflow (reads the CC matrix four times).
 #include "common.h"
+#include <algorithm>
 #include "../../include/bpmf_hip.h"
 
 namespace bpmf {
@@ -188,7 +189,8 @@ __global__ void tdt_expand_kernel(const float* __restrict__ thr_win, size_t n_ro
 // Records are appended in arbitrary order; the host sorts the (few thousand) survivors.
 __global__ __launch_bounds__(256) void cand_extract_kernel(
     const float* __restrict__ x, const float* __restrict__ thr_win, const float* __restrict__ row_cap,
-    size_t n_rows, size_t n, size_t shift, size_t n_win, unsigned capacity,
+    size_t n_rows, size_t n, size_t shift, size_t n_win, unsigned head_len, unsigned head_win,
+    unsigned tail_start, unsigned tail_win, unsigned capacity,
     unsigned* __restrict__ count, int4* __restrict__ records)
 {
     // 4 consecutive samples per thread (one 16-byte load); the window of a sample costs a division,
@@ -198,9 +200,12 @@ __global__ __launch_bounds__(256) void cand_extract_kernel(
     const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const unsigned nn = (unsigned)n, sh = (unsigned)shift, nw = (unsigned)n_win;
     if (i0 >= nn) return;
+    // samples before head_len take window head_win, samples from tail_start on window tail_win (RMS
+    // threshold: the first / last `shift` samples take the first / last window; MAD threshold: the
+    // first half window and the last window - half samples repeat the ends of the indexed array)
     auto window_of = [&](unsigned i) -> unsigned {
-        if (i < sh) return 0u;
-        if (i >= nn - sh) return nw - 1;
+        if (i < head_len) return head_win;
+        if (i >= tail_start) return tail_win;
         const unsigned q = i / sh;
         return q > nw - 1 ? nw - 1 : q;   // clamp: documented deviation (tdt_window_of)
     };
@@ -345,8 +350,40 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
     }
     BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
     cand_extract_kernel<<<dim3((unsigned)((n + 1023) / 1024), (unsigned)n_rows), dim3(256), 0, stream>>>(
-        d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, capacity, d_count,
-        (int4*)d_records);
+        d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, (unsigned)shift, 0u,
+        (unsigned)(n - shift), (unsigned)(n_win - 1), capacity, d_count, (int4*)d_records);
+    BPMF_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same extraction against the window values of the MAD threshold (bpmf_tdt_mad_dev): sample i
+// takes window min(clamp(i, half, n - (window - half) - 1) / shift, n_win - 1)
+// (BPMF/similarity_search.py:1100-1112).
+extern "C" int bpmf_extract_candidates_mad_dev(const float* d_series, const float* d_thr_windows,
+                                               const float* d_row_cap, size_t n_rows, size_t n,
+                                               size_t window, size_t shift, uint32_t capacity,
+                                               bpmf_stream_t stream_, uint32_t* d_count,
+                                               bpmf_candidate* d_records)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_series || !d_thr_windows || !d_count || !d_records || n_rows == 0 || n_rows > 65535 ||
+        n > 0x7fffffffull || shift == 0 || window == 0 || n < window) {
+        set_error("bpmf_extract_candidates_mad_dev: bad argument");
+        return -1;
+    }
+    const size_t n_win = (n - window) / shift + 1;
+    const size_t half = window / 2;
+    if (n - (window - half) <= half) {   // a series of exactly one window: the indexed array is empty
+        set_error("bpmf_extract_candidates_mad_dev: series too short (n=%zu window=%zu)", n, window);
+        return -1;
+    }
+    const size_t tail_start = n - (window - half);
+    const size_t head_win = std::min(half / shift, n_win - 1);
+    const size_t tail_win = std::min((tail_start - 1) / shift, n_win - 1);
+    BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+    cand_extract_kernel<<<dim3((unsigned)((n + 1023) / 1024), (unsigned)n_rows), dim3(256), 0, stream>>>(
+        d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, (unsigned)half, (unsigned)head_win,
+        (unsigned)tail_start, (unsigned)tail_win, capacity, d_count, (int4*)d_records);
     BPMF_LAUNCH_CHECK();
     return 0;
 }

@@ -7,8 +7,8 @@ The semantics are pinned by a NumPy/SciPy restatement under oracle/ (oracle/feat
 infrastructure; bit for bit equal to the reference's own output, tests/golden/saturated_envelopes.npz).
 
 * :func:`saturated_envelopes` -- on the MI355X: the analytic signal through a float64 FFT
-  (hipFFT behind ``torch.fft``), the per-channel median / MAD by a device sort, everything else
-  element-wise.  Median, MAD, standardisation and clipping reproduce NumPy's float32 arithmetic
+  (hipFFT behind ``torch.fft``), the per-channel median / MAD by a radix select on the device
+  (csrc/stats.hip, one launch for all channels), everything else element-wise.  Median, MAD, standardisation and clipping reproduce NumPy's float32 arithmetic
   exactly.  The FFT cannot be reproduced bit for bit: the reference hands float32 traces to
   ``scipy.signal.hilbert``, and scipy.fft keeps that precision, so ITS envelopes carry a float32
   FFT's round-off -- a few ulp of the channel's largest value on every sample
@@ -60,41 +60,47 @@ def envelope(traces, device=None, channels_per_batch=16):
     return out.reshape(shape)
 
 
-def _numpy_median_f32(sorted_x):
-    """np.median of a float32 vector given its ascending sort: the middle element, or the float32
-    mean of the two middle ones."""
-    n = sorted_x.numel()
-    if n % 2:
-        return sorted_x[n // 2]
-    return (sorted_x[n // 2 - 1] + sorted_x[n // 2]) / 2
+def row_median_mad(x, skip_zeros=False, device=None):
+    """np.median and MAD of every row of a (rows, n) float32 device tensor (over the non-zero
+    samples only when `skip_zeros`), by radix select on the device (csrc/stats.hip).  Returns
+    (median, mad, n_zero) device tensors; nothing is synchronised."""
+    import ctypes as C
+    torch, dev = _torch_device(device)
+    x = x.to(device=dev, dtype=torch.float32).contiguous()
+    rows, n = x.shape
+    med = torch.empty(rows, dtype=torch.float32, device=dev)
+    mad = torch.empty(rows, dtype=torch.float32, device=dev)
+    nz = torch.empty(rows, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = _lib.lib().bpmf_row_median_mad_dev(C.c_void_p(x.data_ptr()), rows, n, int(bool(skip_zeros)),
+                                                C.c_void_p(stream), C.c_void_p(med.data_ptr()),
+                                                C.c_void_p(mad.data_ptr()), C.c_void_p(nz.data_ptr()))
+    _lib.check(rc, "bpmf_row_median_mad_dev")
+    return med, mad, nz
 
 
 def saturated_envelopes(traces, anomaly_threshold=1.0e-11, max_dynamic_range=1.0e5, device=None):
     """Device version of BPMF/template_search.py:1525-1572.  Returns (features (S, C, N) float32
-    device tensor, data_availability (S,) int32 NumPy array)."""
+    device tensor, data_availability (S,) int32 NumPy array).  The median and MAD of the valid
+    samples of all channels come from ONE launch (radix select, csrc/stats.hip); the decisions per
+    channel (more than half missing, MAD below the anomaly threshold) are taken on the device, and
+    the only transfer to the host is the (S,) availability vector at the end."""
     torch, dev = _torch_device(device)
     wf = envelope(traces, device=device)
     n_stations, n_components, n_samples = wf.shape
-    availability = np.zeros(n_stations, dtype=np.int32)
+    rows = wf.reshape(n_stations * n_components, n_samples)
+    median, mad, n_missing = row_median_mad(rows, skip_zeros=True, device=dev.index)
+    # channels the reference zeroes: more than half of the samples missing, or MAD < threshold (a NaN
+    # MAD -- no valid sample -- only occurs together with the first condition)
+    dead = (n_missing.to(torch.float64) > n_samples / 2) | ~(mad.to(torch.float64) >= anomaly_threshold)
+    missing = rows == 0.0
+    std = (rows - median[:, None]) / mad[:, None]            # float32, NumPy's operations
+    std = torch.where(missing, torch.zeros((), dtype=torch.float32, device=dev), std)
     cap = torch.tensor(max_dynamic_range, dtype=torch.float32, device=dev)
-    for s in range(n_stations):
-        for c in range(n_components):
-            row = wf[s, c]
-            missing = row == 0.0
-            if int(missing.sum()) > n_samples / 2:
-                row.zero_()
-                continue
-            valid = row[~missing]
-            median = _numpy_median_f32(torch.sort(valid).values)
-            mad = _numpy_median_f32(torch.sort((valid - median).abs()).values)
-            if float(mad) < anomaly_threshold:
-                row.zero_()
-                continue
-            std = (row - median) / mad
-            std[missing] = 0.0
-            wf[s, c] = torch.minimum(std, cap)
-            availability[s] += 1
-    return wf, availability
+    out = torch.where(dead[:, None], torch.zeros((), dtype=torch.float32, device=dev), torch.minimum(std, cap))
+    availability = (~dead).reshape(n_stations, n_components).sum(dim=1).to(torch.int32).cpu().numpy()
+    return out.reshape(n_stations, n_components, n_samples), availability
 
 
 def kurtosis(signal, W, device=None):

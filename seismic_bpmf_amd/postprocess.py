@@ -514,3 +514,22 @@ def bp_time_dependent_threshold(network_response, window, n_dev, overlap=0.75):
         mad[q] = np.median(np.abs(seg - m))
     centre, nodes = bp_threshold_nodes(n, window, overlap, med, mad, n_dev)
     return interp_threshold(np.arange(n, dtype=np.float64), centre, nodes)
+
+
+def excess_kurtosis_f32(a):
+    """scipy.stats.kurtosis(a) (Fisher, biased) of a 1-D float32 series exactly as SciPy evaluates it
+    on a float32 array -- the `sanity_check` of MatchedFilter._find_detections_t
+    (BPMF/similarity_search.py:633-642): float32 mean (NumPy's pairwise sum / count), float32
+    powers of the zero-mean series, float32 means of those, m4 / m2**2 - 3; NaN when
+    m2 <= (eps * mean)**2.  Restated without SciPy so that the device kernel
+    (csrc/stats.hip, bpmf_row_kurtosis_dev) has a host mirror; tests compare both with SciPy."""
+    a = np.asarray(a, dtype=np.float32).reshape(-1)
+    mean = np.mean(a, keepdims=True)
+    d = a - mean
+    s2 = d ** 2
+    m2 = np.mean(s2)
+    m4 = np.mean(s2 ** 2)
+    with np.errstate(all="ignore"):
+        if m2 <= (np.finfo(np.float32).eps * mean[0]) ** 2:
+            return np.float32(np.nan)
+        return np.float32(m4 / m2 ** 2.0) - np.float32(3)

@@ -67,56 +67,50 @@ class ThresholdGPU:
         self._keep = (cc, g)
         return thr_win, full
 
-    def time_dependent_threshold_mad(self, cc_row, sliding_window_samp, num_dev, overlap=0.66,
-                                     white_noise=None):
-        """MAD variant of the detection threshold (BPMF/similarity_search.py:1079-1113) for one CC
-        time series that lives on the device: the global and per-window medians / MADs come from
-        device sorts, every float32 operation in NumPy's order, so the result equals
-        postprocess.time_dependent_threshold_mad bit for bit.  Returns the (n,) float32 threshold
-        as a device tensor (compare with `cc_row > thr` on the device)."""
+    def time_dependent_threshold_mad(self, cc, sliding_window_samp, num_dev, overlap=0.66,
+                                     white_noise=None, expand=True):
+        """MAD variant of the detection threshold (BPMF/similarity_search.py:1079-1113) for every row
+        of a CC matrix that lives on the device, in one call (csrc/stats.hip: radix-select medians,
+        every float32 operation in NumPy's order -- equal to postprocess.time_dependent_threshold_mad
+        bit for bit).  `white_noise`: standard-normal values; row r fills its zeros with
+        white_noise[:n_zeros(r)] (drawn here when None).
+
+        cc (n,) -> the (n,) float32 threshold as a device tensor (the reference's return value);
+        cc (rows, n) -> (thr_windows (rows, n_windows), full (rows, n) or None if not `expand`)."""
         t = self.torch
-        x = cc_row.reshape(-1).to(device=self.device, dtype=t.float32)
-        n = x.numel()
+        single = cc.dim() == 1
+        x = cc.reshape(1, -1) if single else cc
+        x = x.to(device=self.device, dtype=t.float32).contiguous()
+        rows, n = x.shape
         W = int(sliding_window_samp)
-        half = W // 2
         shift = int((1.0 - overlap) * W)
-
-        def median_last(rows):                  # np.median along the last axis, float32
-            srt = t.sort(rows, dim=-1).values
-            m = rows.shape[-1]
-            return srt[..., m // 2] if m % 2 else (srt[..., m // 2 - 1] + srt[..., m // 2]) / 2
-
-        zeros = x == 0.0
-        n_zeros = int(zeros.sum())
+        n_win = self.lib.bpmf_tdt_mad_num_windows(n, W, shift)
+        if n_win == 0:
+            raise ValueError("series shorter than the sliding window")
         if white_noise is None:
-            white_noise = np.random.normal(size=n_zeros).astype("float32")
-        nz = x[~zeros]
-        centre0 = median_last(nz)
-        dev0 = median_last((nz - centre0).abs())
-        ts = x.clone()
-        if n_zeros:
-            wn = t.as_tensor(np.ascontiguousarray(white_noise[:n_zeros], dtype=np.float32), device=self.device)
-            ts[zeros] = wn * dev0 + centre0
-        wins = ts.unfold(0, W, shift)           # sliding_window_view(ts, W)[::shift]
-        centre = t.empty(wins.shape[0], dtype=t.float32, device=self.device)
-        dev = t.empty_like(centre)
-        rows_per_batch = max(1, (1 << 27) // W)  # bounds the sort work space (~0.5 GB of keys)
-        for i in range(0, wins.shape[0], rows_per_batch):
-            w_ = wins[i:i + rows_per_batch]
-            c_ = median_last(w_)
-            centre[i:i + rows_per_batch] = c_
-            dev[i:i + rows_per_batch] = median_last((w_ - c_[:, None]).abs())
-        thr = centre + num_dev * dev
-        thr[1:] = t.maximum(thr[:-1], thr[1:]).clone()
-        thr[:-1] = t.maximum(thr[:-1], thr[1:]).clone()
-        where = t.arange(half, n - (W - half), device=self.device) // shift
-        where = t.clamp(where, max=thr.numel() - 1)
-        mid = thr[where]   # the reference pads with the ends of the INDEXED array
-        return t.cat((mid[0].expand(half), mid, mid[-1].expand(W - half)))
+            white_noise = np.random.normal(size=n).astype("float32")
+        wn = t.as_tensor(np.ascontiguousarray(white_noise, dtype=np.float32), device=self.device)
+        nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(rows, n, W, shift)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        thr_win = t.empty((rows, n_win), dtype=t.float32, device=self.device)
+        full = t.empty((rows, n), dtype=t.float32, device=self.device) if (expand or single) else None
+        with t.cuda.device(self.device):
+            rc = self.lib.bpmf_tdt_mad_dev(x.data_ptr(), wn.data_ptr() if wn.numel() else None, wn.numel(),
+                                           float(num_dev), rows, n, W, shift, self._ws.data_ptr(),
+                                           self._ws.numel(), self._stream(), thr_win.data_ptr(),
+                                           full.data_ptr() if full is not None else None, None)
+        _lib.check(rc, "bpmf_tdt_mad_dev")
+        self._keep = (x, wn)
+        return full[0] if single else (thr_win, full)
 
     def extract_candidates(self, cc, thr_windows, sliding_window_samp, overlap=0.66, row_cap=None,
-                           capacity=1 << 20):
-        """Records (row, index, cc, threshold) of every sample above min(threshold, row_cap)."""
+                           capacity=1 << 20, kind="rms"):
+        """Records (row, index, cc, threshold) of every sample above min(threshold, row_cap).
+        `thr_windows` are the window values of time_dependent_threshold (kind "rms") or of
+        time_dependent_threshold_mad (kind "mad").  The record buffer grows and the extraction is
+        repeated when it overflows."""
         t = self.torch
         cc = cc.contiguous()
         if cc.dim() == 1:
@@ -126,16 +120,27 @@ class ThresholdGPU:
         cap = None
         if row_cap is not None:
             cap = t.as_tensor(np.ascontiguousarray(row_cap, dtype=np.float32), device=self.device)
-        count = t.zeros(1, dtype=t.int32, device=self.device)
-        rec = t.empty((capacity, 4), dtype=t.int32, device=self.device)
-        with t.cuda.device(self.device):
-            rc = self.lib.bpmf_extract_candidates_dev(
-                cc.data_ptr(), thr_windows.contiguous().data_ptr(), cap.data_ptr() if cap is not None else None,
-                rows, n, half, shift, capacity, self._stream(), count.data_ptr(), rec.data_ptr())
-        _lib.check(rc, "bpmf_extract_candidates_dev")
-        n_found = int(count.item())
-        if n_found > capacity:
-            raise _lib.BpmfHipError(f"{n_found} candidates exceed the capacity {capacity}")
+        thr_windows = thr_windows.contiguous()
+        while True:
+            count = t.zeros(1, dtype=t.int32, device=self.device)
+            rec = t.empty((capacity, 4), dtype=t.int32, device=self.device)
+            with t.cuda.device(self.device):
+                if kind == "rms":
+                    rc = self.lib.bpmf_extract_candidates_dev(
+                        cc.data_ptr(), thr_windows.data_ptr(), cap.data_ptr() if cap is not None else None,
+                        rows, n, half, shift, capacity, self._stream(), count.data_ptr(), rec.data_ptr())
+                elif kind == "mad":
+                    rc = self.lib.bpmf_extract_candidates_mad_dev(
+                        cc.data_ptr(), thr_windows.data_ptr(), cap.data_ptr() if cap is not None else None,
+                        rows, n, int(sliding_window_samp), shift, capacity, self._stream(), count.data_ptr(),
+                        rec.data_ptr())
+                else:
+                    raise ValueError("kind must be 'rms' or 'mad'")
+            _lib.check(rc, "bpmf_extract_candidates_dev")
+            n_found = int(count.item())
+            if n_found <= capacity:
+                break
+            capacity = n_found
         out = rec[:n_found].cpu().numpy().view(candidate_dtype).reshape(-1)
         return out[np.lexsort((out["index"], out["row"]))]
 

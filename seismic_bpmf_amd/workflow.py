@@ -42,38 +42,53 @@ def merge_candidates(index, cc, search_win):
     return np.asarray(idx, dtype=np.int64)
 
 
-def row_excess_kurtosis(cc, rows_per_pass=8):
-    """scipy.stats.kurtosis (Fisher, biased: m4 / m2**2 - 3) of every row of a (T, n) device tensor, in
-    float64, a few rows at a time (a cfg2 CC matrix is 17 GB: no full-size temporaries).  Returns a
-    NumPy array; NaN for a constant row, like SciPy."""
+def row_excess_kurtosis(cc):
+    """scipy.stats.kurtosis (Fisher, biased: m4 / m2**2 - 3) of every row of a (T, n) float32 device
+    tensor, evaluated as SciPy evaluates it on the reference's float32 CC series
+    (BPMF/similarity_search.py:633-642): float32 moments in NumPy's summation order
+    (csrc/stats.hip, bpmf_row_kurtosis_dev; host mirror postprocess.excess_kurtosis_f32).  Returns a
+    float32 NumPy array; NaN for a constant row, like SciPy."""
+    import ctypes as C
     import torch
-    out = []
-    for r0 in range(0, cc.shape[0], rows_per_pass):
-        x = cc[r0:r0 + rows_per_pass].to(torch.float64)
-        d = x - x.mean(dim=1, keepdim=True)
-        d2 = d * d
-        m2 = d2.mean(dim=1)
-        m4 = (d2 * d2).mean(dim=1)
-        out.append((m4 / (m2 * m2) - 3.0).cpu().numpy())
-    return np.concatenate(out) if out else np.zeros(0)
+    from . import _lib
+    x = cc if cc.dim() == 2 else cc.reshape(1, -1)
+    x = x.to(dtype=torch.float32).contiguous()
+    rows, n = x.shape
+    if rows == 0:
+        return np.zeros(0, dtype=np.float32)
+    lib = _lib.lib()
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.bpmf_row_kurtosis_workspace_bytes(rows, n), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.bpmf_row_kurtosis_dev(C.c_void_p(x.data_ptr()), rows, n, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
+                                       C.c_void_p(out.data_ptr()))
+    _lib.check(rc, "bpmf_row_kurtosis_dev")
+    return out.cpu().numpy()
 
 
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                               threshold_window_dur, minimum_interevent_time, n_dev=8.0,
                               overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
                               remove_edges=True, data_buffer_sec=None, data_duration_sec=None,
-                              sanity_check=True, max_kurto=100.0):
+                              sanity_check=True, max_kurto=100.0, threshold_type="rms"):
     """Matched-filter search of one day: returns ({template: cc indices}, cc device tensor).
 
     `remove_edges` (the reference's default, BPMF/similarity_search.py:274-285) drops detections
     inside the `data_buffer_sec` margins the day was loaded with (`cfg.DATA_BUFFER_SEC`) and past
-    `data_duration_sec + data_buffer_sec`; it needs both durations and is skipped when
-    `data_buffer_sec` is None (a day loaded without margins).  The optional anomalous-CDF
+    `data_duration_sec + data_buffer_sec`; it needs `data_buffer_sec` (pass remove_edges=False for a
+    day loaded without margins).  The optional anomalous-CDF
     validation of :253-272 is available through postprocess.select_cc_indexes on a downloaded
     row; it is off in this device pipeline.  `sanity_check` (the reference's default, :633-642): a
     template whose CC series has an excess kurtosis above `max_kurto` -- most of the day missing --
-    yields no detection (the reference zeroes its CCs before the peak selection); the kurtosis is
-    scipy.stats.kurtosis' definition, evaluated on the device in float64."""
+    yields no detection (the reference zeroes its CCs before the peak selection); `threshold_type`:
+    the RMS threshold of libc.c (default) or the MAD threshold of similarity_search.py:1079-1113; the kurtosis is
+    scipy.stats.kurtosis of the float32 row, evaluated on the device in SciPy's own float32 order.
+    `remove_edges=True` without `data_buffer_sec` raises: the reference always trims
+    cfg.DATA_BUFFER_SEC, there is no silent default here."""
+    if remove_edges and data_buffer_sec is None:
+        raise ValueError("remove_edges=True needs data_buffer_sec (the reference trims cfg.DATA_BUFFER_SEC); "
+                         "pass remove_edges=False for a day without margins")
     weights = np.asarray(weights, dtype=np.float32)
     mf = MatchedFilterGPU(device=device)
     mf.set_data(data)
@@ -81,10 +96,17 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     cc.nan_to_num_(nan=0.0)                                    # similarity_search.py:540
     th = ThresholdGPU(device=device)
     window = int(pp.sec_to_samp(threshold_window_dur, sr))
-    thr_win, _ = th.time_dependent_threshold(cc, window, n_dev, overlap=overlap,
-                                             white_noise=white_noise)
+    threshold_type = threshold_type.lower()
+    if threshold_type == "rms":
+        thr_win, _ = th.time_dependent_threshold(cc, window, n_dev, overlap=overlap,
+                                                 white_noise=white_noise)
+    elif threshold_type == "mad":                                               # :1079-1113
+        thr_win, _ = th.time_dependent_threshold_mad(cc, window, n_dev, overlap=overlap,
+                                                     white_noise=white_noise, expand=False)
+    else:
+        raise ValueError("threshold_type must be 'rms' or 'mad'")
     cap = max_cc_threshold * weights.reshape(weights.shape[0], -1).sum(axis=1)   # :629
-    cand = th.extract_candidates(cc, thr_win, window, overlap=overlap, row_cap=cap)
+    cand = th.extract_candidates(cc, thr_win, window, overlap=overlap, row_cap=cap, kind=threshold_type)
     min_iet = int(pp.sec_to_samp(minimum_interevent_time, sr))
     mv = np.asarray(moveouts)
     rejected = row_excess_kurtosis(cc) > max_kurto if sanity_check else np.zeros(weights.shape[0], bool)
@@ -104,48 +126,6 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                 idx = idx[samples < pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr)]
         out[t] = idx
     return out, cc
-
-
-def bp_time_dependent_threshold_device(beam, window, n_dev, overlap=0.75):
-    """postprocess.bp_time_dependent_threshold (BPMF/template_search.py:1418-1487) with the
-    per-window medians and MADs computed on the device: `beam` is the (N,) float32 device tensor
-    the beamformer returned; all windows are sorted in one batched call.  Same float32 arithmetic
-    (median of an even count = float32 mean of the two middle values), so the result is
-    bit-identical to the host version; only the n_windows + 2 window values come back, and the
-    float64 interpolation to N samples runs on the host like the reference's interp1d."""
-    import torch
-    x = beam.reshape(-1)
-    n = x.numel()
-    shift = int((1.0 - overlap) * window)
-    n_windows = int((n - window) // shift) + 1
-
-    def median_rows(rows):                     # np.median along the last axis, float32
-        srt = torch.sort(rows, dim=-1).values
-        m = rows.shape[-1]
-        return srt[..., m // 2] if m % 2 else (srt[..., m // 2 - 1] + srt[..., m // 2]) / 2
-
-    med = torch.zeros(n_windows + 2, dtype=torch.float32, device=x.device)
-    mad = torch.zeros_like(med)
-    centre = np.zeros(n_windows + 2, dtype=np.float32)
-    # windows q = 1 .. n_windows start at q * shift; those that fit entirely are rows of one view
-    n_full = min(n_windows, (n - window) // shift)          # q with q*shift + window <= n
-    if n_full >= 1:
-        rows = x.unfold(0, window, shift)[1:n_full + 1]
-        m = median_rows(rows)
-        med[1:n_full + 1] = m
-        mad[1:n_full + 1] = median_rows((rows - m[:, None]).abs())
-    for q in range(n_full + 1, n_windows + 1):              # shorter windows at the end of the day
-        seg = x[q * shift:min(n, q * shift + window)]
-        m = median_rows(seg)
-        med[q] = m
-        mad[q] = median_rows((seg - m).abs())
-    for q in range(1, n_windows + 1):
-        i1 = q * shift
-        centre[q] = (i1 + min(n, i1 + window)) / 2.0
-    med[0], mad[0], centre[0] = med[1], mad[1], 0.0
-    med[-1], mad[-1], centre[-1] = med[-2], mad[-2], n
-    thr = (med + n_dev * mad).cpu().numpy()
-    return pp.interp_threshold(np.arange(n, dtype=np.float64), centre, thr)   # SciPy's operation order
 
 
 def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev=15.0, overlap=0.75,

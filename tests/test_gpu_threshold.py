@@ -88,8 +88,9 @@ def test_end_to_end_planted_events_are_detected_at_exact_samples(oracle_lib):
 
 
 def test_mad_threshold_on_device_equals_the_host_mirror_and_the_reference_golden():
-    """threshold_type="mad" (BPMF/similarity_search.py:1079-1113): device sorts vs the host mirror
-    (pinned to tests/golden/tdt_mad.npz, the reference's own output), bit for bit."""
+    """threshold_type="mad" (BPMF/similarity_search.py:1079-1113): the device pipeline of
+    csrc/stats.hip vs the host mirror (pinned to tests/golden/tdt_mad.npz, the reference's own output),
+    bit for bit."""
     import os
     import torch
     from seismic_bpmf_amd import postprocess as pp
@@ -109,3 +110,73 @@ def test_mad_threshold_on_device_equals_the_host_mirror_and_the_reference_golden
         got = th.time_dependent_threshold_mad(torch.as_tensor(x, device="cuda"), W, 8.0, overlap=ov,
                                               white_noise=wn).cpu().numpy()
         assert np.array_equal(got, want), (n, W, ov)
+
+
+def test_mad_threshold_batched_rows_and_candidates():
+    """All rows of a CC matrix in one call: window values, expanded threshold and the candidates above
+    it (bpmf_extract_candidates_mad_dev) equal the host mirror row by row -- rows with different
+    numbers of zeros sharing one white-noise vector, a row without zeros, a row of zeros only at the
+    ends (the shape of a real CC series), even and odd windows, a row cap."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    th = ThresholdGPU()
+    rng = np.random.default_rng(17)
+    for n, W, ov in [(40_000, 3000, 0.66), (25_001, 1001, 0.25), (9_000, 4500, 0.5)]:
+        rows = 6
+        x = (rng.standard_normal((rows, n)) * 0.05).astype(np.float32)
+        x[0, rng.random(n) < 0.05] = 0.0
+        x[1, :700] = 0.0
+        x[1, -900:] = 0.0
+        x[3, 5000:5600] = 0.0
+        x[4] = np.round(x[4] * 50) / 50                              # ties
+        x[:, ::977] += 0.6                                           # peaks above the threshold
+        wn = rng.standard_normal(n).astype(np.float32)
+        thr_win, full = th.time_dependent_threshold_mad(torch.as_tensor(x, device="cuda"), W, 8.0, overlap=ov,
+                                                        white_noise=wn)
+        full = full.cpu().numpy()
+        for r in range(rows):
+            want = pp.time_dependent_threshold_mad(x[r], W, 8.0, overlap=ov, white_noise=wn)
+            assert np.array_equal(full[r], want), (n, W, ov, r)
+        cap = np.array([10.0, 10.0, 0.3, 10.0, 10.0, 10.0], np.float32)
+        cand = th.extract_candidates(torch.as_tensor(x, device="cuda"), thr_win, W, overlap=ov, row_cap=cap, kind="mad",
+                                     capacity=64)
+        for r in range(rows):
+            t_r = np.minimum(full[r], cap[r])
+            idx = np.flatnonzero(x[r] > t_r)
+            mine = cand[cand["row"] == r]
+            assert np.array_equal(mine["index"], idx), (n, W, ov, r)
+            assert np.array_equal(mine["threshold"], t_r[idx]) and np.array_equal(mine["cc"], x[r, idx])
+    short = torch.zeros(10, device="cuda")
+    with pytest.raises(ValueError):
+        th.time_dependent_threshold_mad(short, 100, 8.0)
+    few = torch.zeros((1, 5000), device="cuda")
+    with pytest.raises(Exception, match="white-noise"):
+        th.time_dependent_threshold_mad(few, 1000, 8.0, white_noise=np.zeros(10, np.float32))
+
+
+def test_row_median_mad_over_non_zero_samples():
+    """bpmf_row_median_mad_dev: np.median / MAD of the rows, over all samples and over the non-zero
+    ones (the statistics of saturated_envelopes, BPMF/template_search.py:1547-1561)."""
+    import torch
+    from seismic_bpmf_amd import features
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 3, 1000, 1001, 70_000):
+        x = np.abs(rng.standard_normal((7, n))).astype(np.float32)
+        x[1, rng.random(n) < 0.4] = 0.0
+        x[2] = 0.0
+        x[3] = np.round(x[3] * 4) / 4
+        if n > 2:
+            x[4, 1] = -0.0
+            x[5, 0] = np.nan
+        for skip in (False, True):
+            med, mad, nz = (t.cpu().numpy() for t in features.row_median_mad(torch.as_tensor(x, device="cuda"), skip))
+            for r in range(7):
+                v = x[r][x[r] != 0] if skip else x[r]
+                with np.errstate(all="ignore"), __import__("warnings").catch_warnings():
+                    __import__("warnings").simplefilter("ignore")
+                    m = np.median(v) if v.size else np.float32(np.nan)
+                    d = np.median(np.abs(v - m)) if v.size else np.float32(np.nan)
+                assert np.array_equal(med[r], np.float32(m), equal_nan=True), (n, skip, r)
+                assert np.array_equal(mad[r], np.float32(d), equal_nan=True), (n, skip, r)
+                assert nz[r] == (x[r] == 0).sum()

@@ -11,7 +11,18 @@ def test_matched_filter_detections_recover_planted_events():
     inp = syn.make_mf_inputs(T=4, S=6, C=3, L=64, N=150_000, seed=3, max_moveout=200, n_events=4)
     det, cc = matched_filter_detections(inp["templates"], inp["moveouts"], inp["weights"], inp["data"],
                                         sr=100.0, threshold_window_dur=300.0, minimum_interevent_time=5.0,
+                                        remove_edges=False,
                                         white_noise=np.random.default_rng(0).standard_normal(500).astype(np.float32))
+    with pytest.raises(ValueError, match="data_buffer_sec"):      # the reference always trims its buffer: no silent skip
+        matched_filter_detections(inp["templates"], inp["moveouts"], inp["weights"], inp["data"], sr=100.0,
+                                  threshold_window_dur=300.0, minimum_interevent_time=5.0)
+    # the MAD threshold finds the same planted events
+    det_mad, _ = matched_filter_detections(inp["templates"], inp["moveouts"], inp["weights"], inp["data"],
+                                           sr=100.0, threshold_window_dur=300.0, minimum_interevent_time=5.0,
+                                           remove_edges=False, threshold_type="mad",
+                                           white_noise=np.random.default_rng(0).standard_normal(5000).astype(np.float32))
+    for t in range(4):
+        assert set(i0 for tt, i0 in inp["planted"] if tt == t) <= set(det_mad[t].tolist()), t
     for t in range(4):
         planted = sorted(i0 for tt, i0 in inp["planted"] if tt == t)
         assert list(det[t]) == planted, (t, det[t], planted)
@@ -59,25 +70,29 @@ def test_intertemplate_cc_against_oracle(oracle_lib):
 
 
 def test_bp_threshold_on_device_equals_the_host_mirror():
-    """Sliding median/MAD threshold of the max beam: device sorts vs the host mirror that is pinned
-    to the reference's golden (tests/golden/bp_threshold.npz), bit for bit, including windows cut
-    short at the end of the trace and even/odd window lengths."""
+    """Sliding median/MAD threshold of the max beam: window statistics by radix select on the device
+    (BeamDetectorGPU.window_stats) + the node / interpolation logic of the host mirror, against the
+    reference's golden (tests/golden/bp_threshold.npz), bit for bit, including windows cut short at the
+    end of the trace and even/odd window lengths."""
     import torch
     from seismic_bpmf_amd import postprocess as pp
-    from seismic_bpmf_amd.workflow import bp_time_dependent_threshold_device
+    from seismic_bpmf_amd.threshold import BeamDetectorGPU
     import os
+    det = BeamDetectorGPU()
+
+    def device_threshold(x, window, n_dev, overlap):
+        med, mad = det.window_stats(torch.as_tensor(x, device="cuda"), window, overlap)
+        centre, thr = pp.bp_threshold_nodes(len(x), window, overlap, med, mad, n_dev)
+        return pp.interp_threshold(np.arange(len(x), dtype=np.float64), centre, thr)
+
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bp_threshold.npz"))
-    got = bp_time_dependent_threshold_device(torch.as_tensor(g["maxbeam"], device="cuda"), int(g["window"]),
-                                             float(g["n_dev"]), overlap=float(g["overlap"]))
+    got = device_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]), float(g["overlap"]))
     assert np.array_equal(got, g["thr"])          # interpolation in SciPy's own operation order: the golden itself
-    assert np.array_equal(got, pp.bp_time_dependent_threshold(g["maxbeam"], int(g["window"]), float(g["n_dev"]),
-                                                              float(g["overlap"])))
     rng = np.random.default_rng(8)
     for n, window, overlap in [(50_001, 3001, 0.75), (40_000, 3000, 0.5), (12_345, 1000, 0.9), (9_000, 9_000, 0.75)]:
         x = (np.abs(rng.standard_normal(n)) * (1 + 5 * (rng.random(n) > 0.999))).astype(np.float32)
         want = pp.bp_time_dependent_threshold(x, window, 15.0, overlap=overlap)
-        got = bp_time_dependent_threshold_device(torch.as_tensor(x, device="cuda"), window, 15.0, overlap=overlap)
-        assert np.array_equal(got, want), (n, window, overlap)
+        assert np.array_equal(device_threshold(x, window, 15.0, overlap), want), (n, window, overlap)
 
 
 # ------------------------------------------------------- BP detection stage on the device ---
@@ -276,7 +291,8 @@ def test_matched_filter_detections_sanity_check_rejects_gappy_days(oracle_lib):
     full, cc = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], m["data"], **kw)
     cc_ref = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1)
     k = workflow.row_excess_kurtosis(cc)
-    assert np.allclose(k, kurtosis(cc_ref.astype(np.float64), axis=1), rtol=1e-9) and (k < 100).all()
+    # the reference hands SciPy the float32 series: bit-identical to that
+    assert k.dtype == np.float32 and np.array_equal(k, kurtosis(cc_ref, axis=1)) and (k < 100).all()
     assert all(len(full[t]) >= 1 for t in range(3))
     gappy = m["data"].copy()
     gappy[:, :, 1_500:] = 0.0                                   # 97 % of the day missing: CC exactly 0 there
@@ -287,3 +303,25 @@ def test_matched_filter_detections_sanity_check_rejects_gappy_days(oracle_lib):
     off, _ = workflow.matched_filter_detections(m["templates"], m["moveouts"], m["weights"], gappy, sanity_check=False, **kw)
     for t in range(3):
         assert (len(on[t]) == 0) if want_reject[t] else np.array_equal(on[t], off[t])
+
+
+def test_row_kurtosis_is_scipy_on_float32_bit_for_bit():
+    """bpmf_row_kurtosis_dev == scipy.stats.kurtosis of the float32 rows (NumPy's pairwise sums over
+    8192-element chunks, float32 powers, the float64 division by the count): lengths around every
+    boundary of the summation tree, a constant row (NaN), a mostly-zero row, a day-sized row."""
+    import torch
+    from scipy.stats import kurtosis
+    from seismic_bpmf_amd import postprocess as pp, workflow
+    rng = np.random.default_rng(11)
+    for n in (1, 5, 7, 8, 9, 127, 128, 129, 143, 255, 257, 1000, 8191, 8192, 8193, 16385, 100_003, 2_000_001):
+        rows = 3 if n > 100_000 else 5
+        x = (rng.standard_normal((rows, n)) * rng.uniform(0.01, 2.0, (rows, 1)) + rng.uniform(-1, 1, (rows, 1))).astype(np.float32)
+        if n > 4:
+            x[1, : n // 2] = 0.0
+            x[2] = x[2, 0]
+        with np.errstate(all="ignore"):
+            want = np.array([pp.excess_kurtosis_f32(r) for r in x], dtype=np.float32)
+            ref = np.asarray(kurtosis(x, axis=1), dtype=np.float32)
+        got = workflow.row_excess_kurtosis(torch.as_tensor(x, device="cuda"))
+        assert np.array_equal(want, ref, equal_nan=True), n
+        assert np.array_equal(got, want, equal_nan=True), (n, got, want)
