@@ -19,51 +19,77 @@ constexpr int GAUSSIAN_LEN = 500;
 
 // dword-aligned 16-byte load: rows and windows start at arbitrary sample offsets
 typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));   // 16-byte aligned (LDS tile)
 
-// Stream one window through f(value, index) in strictly ascending order.  The adds of a window
-// form one dependent chain, so the only parallelism inside a thread is in the LOADS: a batch is
-// 8 x 16 B = one 128-byte line per lane, and the next batch is in flight while the current one is
-// accumulated (without this the chain waits for a memory round trip every 4 samples).
+// Stream one window per LANE through f(value, index) in strictly ascending order.  The adds of a
+// window form one dependent chain, so a thread owns a whole window and a wave walks 64 windows
+// side by side -- 64 different cache lines per step.  Rounds 1-2 let every lane load its own line
+// 16 bytes at a time: 8 load instructions per line, each of them touching 64 lines, and the stage
+// ran at what the texture addresser makes of that (2.1-2.7 TB/s of the matrix, whatever the depth
+// of the load pipeline).  Now the wave reads every line ONCE: load k of a step has lanes 8j .. 8j+7
+// fetch the eight 16-byte pieces of the line of window 8k + j -- 8 lines per instruction instead
+// of 64 -- and a transposition through a 9 KB LDS tile hands each lane its own 32 samples.  The
+// next step's loads are in flight while the current 32 samples are accumulated.
+// Call with all 64 lanes of a one-wave workgroup (`p` of an idle lane: any readable window).
+constexpr int TDT_STEP = 32;                 // samples per lane and step = one 128-byte line
+constexpr int TDT_ROW = TDT_STEP + 4;        // tile row stride in floats (16-byte aligned, spreads the banks)
 template <typename F>
-__device__ __forceinline__ void tdt_stream(const float* __restrict__ p, size_t window, F f)
+__device__ __forceinline__ void tdt_stream(const float* __restrict__ p, size_t window, float* tile, F f)
 {
-    constexpr int NB = 8;
-    const size_t nbatch = window / (4 * NB);
-    f32x4a cur[NB], nxt[NB];
-    if (nbatch) {
+    const int lane = threadIdx.x & 63;
+    const int piece = lane & 7, sub = lane >> 3;
+    const size_t nstep = window / TDT_STEP;
+    // the windows whose pieces this lane fetches: 8k + sub, k = 0 .. 7
+    const float* src[8];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) cur[i] = *(const f32x4a*)(p + 4 * i);
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long q = __shfl((unsigned long long)(size_t)p, 8 * k + sub, 64);
+        src[k] = (const float*)(size_t)q + 4 * piece;
     }
-    for (size_t b = 0; b < nbatch; ++b) {
-        const float* pn = p + (b + 1) * (4 * NB);
-        if (b + 1 < nbatch) {
+    f32x4a reg[8];
+    if (nstep) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) nxt[i] = *(const f32x4a*)(pn + 4 * i);
+        for (int k = 0; k < 8; ++k) reg[k] = *(const f32x4a*)(src[k]);
+    }
+    for (size_t b = 0; b < nstep; ++b) {
+        // (LDS operations of one wave execute in order: the reads of the previous step are done)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) *(f32x4v*)(tile + (8 * k + sub) * TDT_ROW + 4 * piece) = (f32x4v)reg[k];
+        if (b + 1 < nstep) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) reg[k] = *(const f32x4a*)(src[k] + (b + 1) * TDT_STEP);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        f32x4v mine[8];
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < 8; ++i) mine[i] = *(const f32x4v*)(tile + lane * TDT_ROW + 4 * i);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f(cur[i][e], b * (4 * NB) + 4 * i + e);
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) cur[i] = nxt[i];
+            for (int e = 0; e < 4; ++e) f(mine[i][e], b * TDT_STEP + 4 * i + e);
     }
-    for (size_t j = nbatch * (4 * NB); j < window; ++j) f(p[j], j);
+    for (size_t j = nstep * TDT_STEP; j < window; ++j) f(p[j], j);
 }
 
 // (1) per (row, global window): sum and count of the non-zero samples.       libc.c:553-571
-__global__ void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, size_t n,
+__global__ __launch_bounds__(64) void tdt_glob_sum_kernel(const float* __restrict__ x, size_t n_rows, size_t n,
                                     size_t window, size_t n_glob, float* __restrict__ part,
                                     unsigned long long* __restrict__ cnt)
 {
+    __shared__ __attribute__((aligned(16))) float tile[64 * TDT_ROW];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rows * n_glob) return;
-    size_t row = idx / n_glob, q = idx % n_glob;
+    const bool live = idx < n_rows * n_glob;      // idle lanes of the last wave walk window 0 and store nothing
+    size_t row = live ? idx / n_glob : 0, q = live ? idx % n_glob : 0;
     const float* p = x + row * n + q * window;
     float acc = 0.0f;
     unsigned long long c = 0;
-    tdt_stream(p, window, [&](float v, size_t) {  // strictly sequential adds
+    tdt_stream(p, window, tile, [&](float v, size_t) {  // strictly sequential adds
         if (v != 0.0f) { acc += v; ++c; }
     });
+    if (!live) return;
     part[idx] = acc;
     cnt[idx] = c;
 }
@@ -85,23 +111,24 @@ __global__ void tdt_glob_centre_kernel(const float* __restrict__ part,
 
 // (3) per (row, global window): sum of squared deviations of the non-zero samples (float
 //     accumulator, squares in double).                                       libc.c:574-586
-__global__ void tdt_glob_dev_kernel(const float* __restrict__ x, const float* __restrict__ centre,
+__global__ __launch_bounds__(64) void tdt_glob_dev_kernel(const float* __restrict__ x, const float* __restrict__ centre,
                                     size_t n_rows, size_t n, size_t window, size_t n_glob,
                                     float* __restrict__ part)
 {
+    __shared__ __attribute__((aligned(16))) float tile[64 * TDT_ROW];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rows * n_glob) return;
-    size_t row = idx / n_glob, q = idx % n_glob;
+    const bool live = idx < n_rows * n_glob;
+    size_t row = live ? idx / n_glob : 0, q = live ? idx % n_glob : 0;
     const float* p = x + row * n + q * window;
     const float c = centre[row];
     float acc = 0.0f;
-    tdt_stream(p, window, [&](float v, size_t) {
+    tdt_stream(p, window, tile, [&](float v, size_t) {
         if (v != 0.0f) {
             double d = (double)(v - c);
             acc = (float)((double)acc + d * d);
         }
     });
-    part[idx] = acc;
+    if (live) part[idx] = acc;
 }
 
 // (4) per row: dev = sqrtf(sum / count).                                      libc.c:584-587
@@ -121,31 +148,32 @@ __global__ void tdt_glob_std_kernel(const float* __restrict__ part,
 //     below: the reference is compiled with -std=c99, an ISO mode in which gcc contracts nothing (its
 //     binary holds no FMA; round 1 had assumed fused operations here, oracle/adjacent_oracle.c).
 //                                                                            libc.c:606-627
-__global__ void tdt_window_kernel(const float* __restrict__ x, const float* __restrict__ gauss,
+__global__ __launch_bounds__(64) void tdt_window_kernel(const float* __restrict__ x, const float* __restrict__ gauss,
                                   const float* __restrict__ centre, const float* __restrict__ dev,
                                   float num_dev, size_t n_rows, size_t n, size_t window,
                                   size_t shift, size_t n_win, float* __restrict__ thr_win)
 {
+    __shared__ __attribute__((aligned(16))) float tile[64 * TDT_ROW];
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_rows * n_win) return;
-    size_t row = idx / n_win, q = idx % n_win;
+    const bool live = idx < n_rows * n_win;
+    size_t row = live ? idx / n_win : 0, q = live ? idx % n_win : 0;
     const size_t i0 = q * shift;
     const float* p = x + row * n + i0;
     const float c = centre[row], dv = dev[row];
     float acc = 0.0f;
     unsigned g0 = (unsigned)(i0 % GAUSSIAN_LEN);  // gauss index of sample j: (g0 + j) mod 500
-    tdt_stream(p, window, [&](float v, size_t j) {
+    tdt_stream(p, window, tile, [&](float v, size_t j) {
         if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
         acc += v;
     });
     const float mean = acc / (float)window;
     float ss = 0.0f;
-    tdt_stream(p, window, [&](float v, size_t j) {
+    tdt_stream(p, window, tile, [&](float v, size_t j) {
         if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
         double d = (double)(v - mean);
         ss = (float)((double)ss + d * d);
     });
-    thr_win[idx] = __fadd_rn(mean, __fmul_rn(num_dev, sqrtf(ss / (float)window)));
+    if (live) thr_win[idx] = __fadd_rn(mean, __fmul_rn(num_dev, sqrtf(ss / (float)window)));
 }
 
 // (6) per row: "delay the jump" -- a drop is postponed by one window, a rise anticipated by
