@@ -110,6 +110,13 @@ int bpmf_mf_run_multi(const float *templates, const int32_t *moveouts, const flo
                       size_t C, size_t n_corr, int network_sum, int flags, int n_devices,
                       const int *devices, float *cc_out);
 
+/* The template ranges of that split: block r computes templates [bounds_out[r], bounds_out[r+1]),
+ * balanced by the number of channels with a non-zero weight (the kernels skip the others) -- the
+ * same rule as seismic_bpmf_amd.parallel.shard_bounds_weighted, which the torch.distributed path
+ * uses.  Pure host function (no device needed); bounds_out has n_blocks + 1 entries. */
+int bpmf_mf_shard_bounds(const float *weights, size_t T, size_t S, size_t C, size_t n_blocks,
+                         size_t *bounds_out);
+
 /* ------------------------------------------------------------ backprojection --- */
 /*
  * Serves beampower.beampower.beamform(waveform_features, moveouts, weights_phases,

@@ -42,6 +42,7 @@ SIGNATURES = {
                               C.c_int, _f]),
     "bpmf_mf_run_multi": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int,
                                     C.c_int, C.POINTER(C.c_int), _f]),
+    "bpmf_mf_shard_bounds": (C.c_int, [_f, _sz, _sz, _sz, _sz, C.POINTER(_sz)]),
     "bpmf_bp_run_multi": (C.c_int, [_f, _i, _f, _f, _sz, _sz, _sz, _sz, _sz, C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_int), _f, _i]),
     "bpmf_bp_plan_create": (C.c_int, [_i, _f, _sz, _sz, _sz, C.c_int, C.c_int32, C.POINTER(_vp)]),

@@ -1998,6 +1998,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         hi_s = std::max(lo_s, std::min(hi_s, (long long)N));
         float* pbeam = rows > 1 ? (float*)part : beam_final;
         int32_t* parg = rows > 1 ? (int32_t*)(part + (size_t)rows * N * sizeof(float)) : arg_final;
+        std::lock_guard<std::mutex> enqueue_lock(pl->enqueue_mutex);
         profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
         int rc = 0;
         const bool have_edge = lo_s > 0 || hi_s < (long long)N;

@@ -4,6 +4,8 @@
 #include "common.h"
 #include "../../include/bpmf_hip.h"
 
+#include <mutex>
+
 namespace bpmf {
 
 constexpr int BP_THREADS = 256;
@@ -94,6 +96,10 @@ struct bpmf_bp_plan {
     // full duration of one tile (5 ms at cfg3) to every call.  A plan serves one call at a time.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Two host threads may run the same resident plan on different streams: the fork / join
+    // sequence on the shared side stream is enqueued under this mutex, so that the sequences of
+    // two calls never interleave (each call's edge tiles stay ordered behind ITS prestack kernel).
+    mutable std::mutex enqueue_mutex;
 };
 
 namespace bpmf {

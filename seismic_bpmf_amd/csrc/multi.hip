@@ -50,6 +50,36 @@ int resolve_devices(int n_devices, const int* devices, size_t n_items, std::vect
     return 0;
 }
 
+// Contiguous partition of the templates into `parts` blocks of balanced COST: a template costs its
+// number of channels with a non-zero weight (the kernels skip the others), and block r ends at the
+// first template where the running cost reaches (r + 1) / parts of the total -- the rule of
+// seismic_bpmf_amd.parallel.shard_bounds_weighted (np.searchsorted(cumsum, total * r / parts,
+// side="left") on float64 sums), so that the library's own multi-device split and the
+// one-process-per-GPU split of torch.distributed agree on who computes which template.
+std::vector<size_t> weighted_bounds(const float* weights, size_t T, size_t n_ch, size_t parts)
+{
+    std::vector<double> cum(T + 1, 0.0);
+    for (size_t t = 0; t < T; ++t) {
+        size_t used = 0;
+        for (size_t c = 0; c < n_ch; ++c) used += weights[t * n_ch + c] != 0.0f;
+        cum[t + 1] = cum[t] + (double)used;
+    }
+    std::vector<size_t> b(parts + 1, 0);
+    const double total = cum[T];
+    if (total <= 0.0) {          // no weighted channel anywhere: plain balanced blocks
+        const size_t base = T / parts, rem = T % parts;
+        for (size_t i = 0; i < parts; ++i) b[i + 1] = b[i] + base + (i < rem ? 1 : 0);
+        return b;
+    }
+    for (size_t r = 1; r < parts; ++r) {
+        const double target = total * (double)r / (double)parts;
+        size_t k = (size_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin());
+        b[r] = std::min(std::max(k, b[r - 1]), T);
+    }
+    b[parts] = T;
+    return b;
+}
+
 // balanced contiguous partition of range(n) into `parts` blocks
 std::vector<size_t> block_bounds(size_t n, size_t parts)
 {
@@ -99,8 +129,8 @@ extern "C" int bpmf_mf_run_multi(const float* templates, const int32_t* moveouts
     }
     std::vector<int> dev;
     if (int rc = resolve_devices(n_devices, devices, T, dev, "bpmf_mf_run_multi")) return rc;
-    const std::vector<size_t> b = block_bounds(T, dev.size());
     const size_t n_ch = S * C;
+    const std::vector<size_t> b = weighted_bounds(weights, T, n_ch, dev.size());
     const size_t row = n_corr * (network_sum ? 1 : n_ch);   // floats of output per template
     return run_blocks(dev.size(), [&](size_t i) -> int {
         const size_t t0 = b[i], nt = b[i + 1] - b[i];
@@ -109,6 +139,19 @@ extern "C" int bpmf_mf_run_multi(const float* templates, const int32_t* moveouts
                            step, L, N, nt, S, C, n_corr, network_sum, flags, dev[i],
                            cc_out + t0 * row);
     });
+}
+
+// The split bpmf_mf_run_multi applies, for callers and tests: bounds_out[0 .. n_blocks] (no device needed).
+extern "C" int bpmf_mf_shard_bounds(const float* weights, size_t T, size_t S, size_t C, size_t n_blocks,
+                                    size_t* bounds_out)
+{
+    if (!weights || !bounds_out || T == 0 || n_blocks == 0) {
+        set_error("bpmf_mf_shard_bounds: bad argument");
+        return -1;
+    }
+    const std::vector<size_t> b = weighted_bounds(weights, T, S * C, n_blocks);
+    for (size_t i = 0; i <= n_blocks; ++i) bounds_out[i] = b[i];
+    return 0;
 }
 
 extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,

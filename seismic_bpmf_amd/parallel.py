@@ -128,13 +128,17 @@ class ShardedBeamformer:
 class ShardedMatchedFilter:
     """Matched filter with the templates block-partitioned across the ranks of a group."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, local=None):
+        """`local`: the per-rank engine (set_data / run like MatchedFilterGPU); None = a
+        MatchedFilterGPU on `device`.  (The CPU tests of the exchange logic pass a stand-in.)"""
         import torch.distributed as dist
-        from .matched_filter import MatchedFilterGPU
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.local = MatchedFilterGPU(device=device)
+        if local is None:
+            from .matched_filter import MatchedFilterGPU
+            local = MatchedFilterGPU(device=device)
+        self.local = local
 
     def set_data(self, data):
         self.local.set_data(data)

@@ -200,11 +200,17 @@ def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev
                 cache[int(c)] = wrow
     flat = beam.reshape(-1)
 
+    centres = np.array(sorted(cache), dtype=np.int64)     # a busy day has thousands of candidates: bisect
+
     def beam_slice(i0, i1):
-        for c, wrow in cache.items():            # a handful of entries: linear search is fine
+        # a gathered window [c - half, c + half] that covers [i0, i1): c in [i1 - 1 - half, i0 + half]
+        j = int(np.searchsorted(centres, i1 - 1 - half, side="left"))
+        while j < centres.size and centres[j] <= i0 + half:
+            c = int(centres[j])
             lo = c - half
-            if i0 >= max(lo, 0) and i1 <= min(c + half + 1, n) and lo >= 0 and c + half < n:
-                return wrow[i0 - lo:i1 - lo]
+            if lo >= 0 and c + half < n:         # windows clamped at the ends of the trace are not contiguous
+                return cache[c][i0 - lo:i1 - lo]
+            j += 1
         return flat[i0:i1].cpu().numpy()         # rare: a window no candidate's gather covers
 
     peaks = pp.find_beam_detections_from_candidates(idx_all, rec["beam"], threshold_at, mpd, n, beam_slice)
@@ -233,12 +239,13 @@ def relocation_focus(beamformer, features, weights_phases, uncertainty_method="s
     if uncertainty_method == "spatial":
         vol = beamformer.run(features, weights_phases, "none", out_of_bounds)        # (K, N) on the device
         flat = vol.reshape(-1)
-        first = int(torch.nonzero(flat == flat.max())[0, 0])                         # first maximum, as np.argmax
+        first = int(torch.argmax(flat))      # the first maximum (the first NaN if there is one), as np.argmax;
+                                             # a reduction: no K x N temporaries
         src_idx, time_idx = divmod(first, vol.shape[1])
         return src_idx, time_idx, vol[:, time_idx].cpu().numpy()
     if uncertainty_method == "temporal":
         beam, arg = beamformer.run(features, weights_phases, "max", out_of_bounds)
-        time_idx = int(torch.nonzero(beam == beam.max())[0, 0])
+        time_idx = int(torch.argmax(beam))
         return int(arg[time_idx]), time_idx, beam.cpu().numpy()
     raise ValueError("uncertainty_method should be 'spatial' or 'temporal'")
 

@@ -124,3 +124,111 @@ def test_weighted_template_sharding_balances_active_channels():
         loads = [costs[lo:hi].sum() for lo, hi in b]
         assert max(loads) <= costs.sum() / world + costs.max() + 1e-9
     assert parallel.shard_bounds_weighted(np.zeros(10), 3) == parallel.shard_bounds(10, 3)
+
+
+def test_c_abi_and_python_shard_the_templates_identically():
+    """bpmf_mf_run_multi (one process, host thread per GPU) and ShardedMatchedFilter (one process per
+    GPU) must agree on who computes which template: bpmf_mf_shard_bounds == shard_bounds_weighted on
+    the weighted-channel counts, for ragged weights, empty templates, more blocks than templates."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from seismic_bpmf_amd import _lib, parallel
+    lib = _lib.lib()
+    rng = np.random.default_rng(9)
+    for T, S, Cc, world in [(5000, 40, 3, 8), (500, 20, 3, 8), (17, 5, 3, 4), (3, 2, 1, 8), (64, 7, 3, 1), (9, 3, 3, 2)]:
+        for trial in range(4):
+            w = rng.random((T, S, Cc)).astype(np.float32)
+            w[rng.random((T, S, Cc)) < (0.0, 0.3, 0.7, 1.0)[trial]] = 0.0
+            if trial == 2:
+                w[: T // 2] = 0.0
+            costs = (w.reshape(T, -1) != 0).sum(axis=1)
+            want = parallel.shard_bounds_weighted(costs, world)
+            got = (C.c_size_t * (world + 1))()
+            rc = lib.bpmf_mf_shard_bounds(w.ctypes.data_as(_lib._f), T, S, Cc, world, got)
+            assert rc == 0
+            assert [(got[r], got[r + 1]) for r in range(world)] == [tuple(map(int, b)) for b in want], (T, world, trial)
+
+
+class _OracleMF:
+    """Stand-in for MatchedFilterGPU on a CPU-only box: the per-rank engine of ShardedMatchedFilter
+    backed by the CPU oracle (test infrastructure standing in for the kernels)."""
+
+    def set_data(self, data):
+        self.data = np.ascontiguousarray(data, dtype=np.float32)
+
+    def run(self, templates, moveouts, weights, step=1, network_sum=True):
+        from oracle import oracle
+        return torch.from_numpy(oracle.matched_filter(np.asarray(templates), np.asarray(moveouts), np.asarray(weights),
+                                                      self.data, step, network_sum, num_threads=1))
+
+
+def _mf_case():
+    sys.path.insert(0, ROOT)
+    from seismic_bpmf_amd import synthetic as syn
+    m = syn.make_mf_inputs(T=7, S=4, C=3, L=32, N=6000, seed=12, max_moveout=60, n_events=3)
+    w = m["weights"].copy()
+    w[:3, 1:] = 0.0                 # ragged costs: the weighted split (0,5),(5,7) differs from the equal-count one
+    w[5] = 0.0                      # a template without any weighted channel
+    m["weights"] = w
+    return m
+
+
+def _mf_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seismic_bpmf_amd import parallel, workflow
+    m = _mf_case()
+    smf = parallel.ShardedMatchedFilter(local=_OracleMF())
+    smf.set_data(m["data"])
+    t0, t1, cc = smf.run(m["templates"], m["moveouts"], m["weights"], 1)
+    # this rank's detections as fixed-capacity records (global template id, CC index, CC)
+    rec = torch.zeros((64, 3), dtype=torch.float64)
+    n = 0
+    if cc is not None:
+        cc = cc.numpy()
+        for t in range(t0, t1):
+            row = cc[t - t0]
+            above = np.flatnonzero(row > 0.5)
+            idx = workflow.merge_candidates(above, row[above], 40)
+            for i in idx:
+                rec[n] = torch.tensor([t, int(i), float(row[i])], dtype=torch.float64)
+                n += 1
+    parts = parallel.allgather_records(rec, n)
+    q.put((rank, (t0, t1), [p.numpy() for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_matched_filter_gathers_the_single_process_detections(oracle_lib):
+    """ShardedMatchedFilter over gloo, world size 2: weighted template ranges (not the equal-count
+    ones), every rank's detections all-gathered as records; their union equals the detections of one
+    process over all templates, and every rank receives the same records."""
+    sys.path.insert(0, ROOT)
+    from seismic_bpmf_amd import parallel, workflow
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mf_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = _mf_case()
+    costs = (m["weights"].reshape(7, -1) != 0).sum(axis=1)
+    bounds = parallel.shard_bounds_weighted(costs, world)
+    assert [r[1] for r in results] == [tuple(b) for b in bounds]
+    assert bounds != parallel.shard_bounds(7, world)            # the case does exercise the weighting
+    cc = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1)
+    want = []
+    for t in range(7):
+        above = np.flatnonzero(cc[t] > 0.5)
+        want += [(t, int(i), float(cc[t, i])) for i in workflow.merge_candidates(above, cc[t][above], 40)]
+    assert len(want) >= 3
+    for rank, _, parts in results:
+        got = [tuple(r) for p in parts for r in p.tolist()]
+        assert [(int(a), int(b), c) for a, b, c in got] == want, rank
