@@ -57,6 +57,15 @@ void bpmf_oracle_last_phase_seconds(double *out4)
     for (int i = 0; i < 4; i++) out4[i] = g_phase_seconds[i];
 }
 
+/* Upstream-compatibility variants (mirrors of the library's options mf.compat_exclusive_last_lag,
+ * mf.compat_sqrt_norm, bp.compat_first_computed; all off by default): bit 0 -- the last valid data
+ * offset is exclusive (i * step < N - L - mv_max); bit 1 -- cc = num / sqrtf(E_t * E_d) where
+ * E_t * E_d > 1e-6, else 0; bit 2 -- the running maximum over the sources starts from the first
+ * computed beam (any sign), samples without a computed beam return (0, 0). */
+static int g_compat = 0;
+void bpmf_oracle_set_compat(int flags) { g_compat = flags; }
+int bpmf_oracle_get_compat(void) { return g_compat; }
+
 static void set_threads(int num_threads)
 {
 #ifdef _OPENMP
@@ -193,6 +202,7 @@ static int mf_valid_range(const int32_t *mv, const float *w, size_t n_ch, size_t
     int64_t first = 0;
     if (mv_min < 0) first = (-mv_min + (int64_t)step - 1) / (int64_t)step;
     int64_t room = (int64_t)N - (int64_t)L - mv_max;
+    if (g_compat & 1) room -= 1;           /* exclusive bound: i * step < N - L - mv_max */
     if (room < 0) return 0;
     int64_t last = room / (int64_t)step;
     if (last > (int64_t)n_corr - 1) last = (int64_t)n_corr - 1;
@@ -236,8 +246,11 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
     mf_data_csum(data, n_ch, N, csum);
     mf_window_energy(csum, n_ch, N, L, e_d);
     free(csum);
-    mf_reciprocal_norm(e_t, T * n_ch, e_t);   /* in place: e_t, e_d now hold r_t, r_d */
-    mf_reciprocal_norm(e_d, n_ch * nwin, e_d);
+    const int sqrt_norm = (g_compat & 2) != 0;
+    if (!sqrt_norm) {
+        mf_reciprocal_norm(e_t, T * n_ch, e_t);   /* in place: e_t, e_d now hold r_t, r_d */
+        mf_reciprocal_norm(e_d, n_ch * nwin, e_d);
+    }
 
     const size_t out_per_t = network_sum ? n_corr : n_corr * n_ch;
     memset(out, 0, T * out_per_t * sizeof(float));
@@ -312,9 +325,10 @@ int mf_cpu(const float *templates, const int32_t *moveouts, const float *weights
                 }
                 for (size_t v = 0; v < nv; v++) {
                     const size_t off = (size_t)((int64_t)((b0 + v) * step) + mv[ch]);
-                    float nrm = et * ed[off];
+                    float nrm = et * ed[off];   /* r_t * r_d, or E_t * E_d in the sqrt-norm variant */
                     float cc = 0.0f;
-                    if (nrm < BPMF_MAX_NORM) cc = num[v] * nrm;
+                    if (sqrt_norm) { if (nrm > 1.0e-6f) cc = num[v] / sqrtf(nrm); }
+                    else if (nrm < BPMF_MAX_NORM) cc = num[v] * nrm;
                     if (network_sum)
                         cc_sum[v] = fmaf(w[ch], cc, cc_sum[v]);
                     else
@@ -409,9 +423,10 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
     for (size_t tb = 0; tb < n_tb; tb++) {
         const size_t t0 = tb * TB;
         const size_t t1 = t0 + TB < N ? t0 + TB : N;
+        const int first_computed = (g_compat & 4) != 0;
         float best[512];
         int32_t arg[512];
-        for (size_t j = 0; j < t1 - t0; j++) { best[j] = 0.0f; arg[j] = 0; }
+        for (size_t j = 0; j < t1 - t0; j++) { best[j] = first_computed ? -INFINITY : 0.0f; arg[j] = 0; }
         for (size_t k = 0; k < K; k++) {
             const float *beta = w_sources + k * S;
             const int32_t *tau = moveouts + k * S * P;
@@ -439,7 +454,11 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
             }
         }
         if (reduce == 0)
-            for (size_t t = t0; t < t1; t++) { out_beam[t] = best[t - t0]; out_arg[t] = arg[t - t0]; }
+            for (size_t t = t0; t < t1; t++) {
+                const int none = first_computed && best[t - t0] == -INFINITY;   /* no beam computed at t */
+                out_beam[t] = none ? 0.0f : best[t - t0];
+                out_arg[t] = none ? 0 : arg[t - t0];
+            }
     }
     free(U); free(tmin); free(tmax); free(active);
     return 0;

@@ -49,6 +49,8 @@ def load(path=None):
     lib.bp_cpu.restype = C.c_int
     lib.bp_prestack.argtypes = [_f, _f, sz, sz, sz, sz, _f]
     lib.bpmf_oracle_max_threads.restype = C.c_int
+    lib.bpmf_oracle_set_compat.argtypes = [C.c_int]
+    lib.bpmf_oracle_last_phase_seconds.argtypes = [C.POINTER(C.c_double)]
     lib.tdt_rms_cpu.argtypes = [_f, _f, C.c_float, sz, sz, sz, _f, _f]
     lib.tdt_rms_cpu.restype = C.c_long
     lib.select_cc_indexes_cpu.argtypes = [_f, _f, sz, sz, _i]
@@ -165,3 +167,23 @@ def find_similar_sources(moveouts, lon, lat, cell_lon, cell_lat, threshold, n_di
                              float(threshold), K, S, cl.size - 1, ca.size - 1, int(n_diff), mode,
                              _p(red, _i))
     return red.astype(bool)
+
+
+COMPAT_EXCLUSIVE_LAST_LAG, COMPAT_SQRT_NORM, COMPAT_FIRST_COMPUTED = 1, 2, 4
+
+
+class compat:
+    """with oracle.compat(flags): ... -- the upstream-compatibility variants of bpmf_oracle.c (mirrors
+    of the library's *.compat_* options); back to the build's conventions on exit."""
+
+    def __init__(self, flags, lib=None):
+        self.flags, self.lib = int(flags), lib or load()
+
+    def __enter__(self):
+        self.old = self.lib.bpmf_oracle_get_compat()
+        self.lib.bpmf_oracle_set_compat(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.bpmf_oracle_set_compat(self.old)
+        return False

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int* __restrict__ srcs,
     const int* __restrict__ term_off, const float* __restrict__ term_beta, int NT,
-    int id_offset, float* __restrict__ out_beam, int* __restrict__ out_arg, long long tile_base)
+    int id_offset, float* __restrict__ out_beam, int* __restrict__ out_arg, long long tile_base, float best0)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
     int arg[TPT];
 #pragma unroll
     for (int j = 0; j < TPT; ++j) {
-        best[j] = 0.0f;
+        best[j] = best0;
         arg[j] = id_offset;
         lds[tid + j * BP_THREADS] = 0.0f;  // the zero slab (never overwritten)
     }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, long long tile_base)
+    int* __restrict__ out_arg, long long tile_base, float best0)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_uvgpr_kernel(
     int arg[TPT];
 #pragma unroll
     for (int j = 0; j < TPT; ++j) {
-        best[j] = 0.0f;
+        best[j] = best0;
         arg[j] = id_offset;
         lds[tid + j * BP_THREADS] = 0.0f;  // the zero slab (never overwritten)
     }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ terms, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, long long tile_base)
+    int* __restrict__ out_arg, long long tile_base, float best0)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_wps_kernel(
     float best[TPW];
     int arg[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
+    for (int j = 0; j < TPW; ++j) { best[j] = best0; arg[j] = id_offset; }
     for (int x = tid; x < TILE; x += BP_THREADS) lds[x] = 0.0f;  // the zero slab
 
     for (int g = 0; g < n_groups; ++g) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
     const int4* __restrict__ chunks, const int4* __restrict__ srcs4,
     const int4* __restrict__ recs, int id_offset, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, long long tile_base, long long n_tiles, long long split_stride)
+    int* __restrict__ out_arg, long long tile_base, long long n_tiles, long long split_stride, float best0)
 {
     extern __shared__ float lds[];
     constexpr int TPW = 8;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64 * WPB, WPB >= 16 ? WPB / 4 : (WPB * 2 + 3) / 4) 
     float best[TPW];
     int arg[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
+    for (int j = 0; j < TPW; ++j) { best[j] = best0; arg[j] = id_offset; }
     for (int x = tid; x < TILE; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
 
     for (int g = g_lo; g < g_hi; ++g) {
@@ -966,6 +966,15 @@ __global__ void bp_merge_splits_kernel(const float* __restrict__ pbeam, const in
     }
     beam[i] = b;
     arg[i] = a;
+}
+
+// option bp.compat_first_computed: samples on which no beam was computed still hold the start value
+__global__ void bp_finish_first_computed_kernel(float* __restrict__ beam, int* __restrict__ arg, size_t N,
+                                                int id_offset)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (beam[i] == -INFINITY) { beam[i] = 0.0f; arg[i] = id_offset; }
 }
 
 __global__ void bp_pack_kernel(const float* __restrict__ beam, const int* __restrict__ arg, size_t N,
@@ -1714,6 +1723,10 @@ namespace {
 thread_local long long t_samp_lo = 0, t_samp_hi = -1;
 thread_local int t_n_split = 1;                  // group ranges per tile (short series, see bp_split_count)
 thread_local long long t_split_stride = 0;       // elements between the partial outputs of reduce="max"
+// start value of the running maximum: 0 (the build's convention: a beam that is not > 0 never
+// becomes the maximum) or -inf (option bp.compat_first_computed: the maximum over the computed
+// beams whatever their sign; samples without any computed beam are set to (0, first id) at the end)
+thread_local float t_best0 = 0.0f;
 
 // tiles [base, base + count) of a kernel with `tile` samples per workgroup
 inline void tile_range(size_t N, size_t tile, long long& base, long long& count)
@@ -1743,7 +1756,7 @@ int launch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t st
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int*)pl->d_srcs, pl->d_off, pl->d_beta, pl->NT, pl->id_offset, beam, arg, tile_base);
+        (const int*)pl->d_srcs, pl->d_off, pl->d_beta, pl->NT, pl->id_offset, beam, arg, tile_base, t_best0);
     BPMF_LAUNCH_CHECK();
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
@@ -1787,7 +1800,7 @@ int launch_beam_uv(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_t
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), pl->lds_bytes, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base);
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base, t_best0);
     BPMF_LAUNCH_CHECK();
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
@@ -1824,7 +1837,7 @@ int launch_beam_wps(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream_
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
     kern<<<grid, dim3(BP_THREADS), lds, stream>>>(
         U, (long long)N, pl->d_groups, pl->n_groups, (const int4*)pl->d_chunks,
-        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base);
+        (const int4*)pl->d_srcs, (const int4*)pl->d_termsv, pl->id_offset, beam, arg, tile_base, t_best0);
     BPMF_LAUNCH_CHECK();
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
@@ -1861,7 +1874,7 @@ int launch_beam_wps2(const bpmf_bp_plan* pl, const float* U, size_t N, hipStream
     kern<<<grid, dim3(64 * WPB), lds, stream>>>(U, (long long)N, pl->d_groups, pl->n_groups,
                                                 (const int4*)pl->d_chunks, pl->d_hdr2, pl->d_recs,
                                                 pl->id_offset, beam, arg, tile_base, n_tiles,
-                                                t_split_stride);
+                                                t_split_stride, t_best0);
     BPMF_LAUNCH_CHECK();
     if (t_samp_hi < 0) profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
     return 0;
@@ -1978,6 +1991,19 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         SplitScope(int n, long long stride) { t_n_split = n; t_split_stride = stride; }
         ~SplitScope() { t_n_split = 1; t_split_stride = 0; t_samp_hi = -1; t_samp_lo = 0; }
     };
+    const bool first_computed = reduce == BPMF_BP_REDUCE_MAX && option(OPT_BP_COMPAT_FIRST_COMPUTED) != 0;
+    struct Best0Scope {
+        explicit Best0Scope(float v) { t_best0 = v; }
+        ~Best0Scope() { t_best0 = 0.0f; }
+    } best0_scope(first_computed ? -INFINITY : 0.0f);
+    auto finish = [&](float* beam, int32_t* arg) -> int {
+        if (first_computed) {
+            bp_finish_first_computed_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
+                beam, arg, N, pl->id_offset);
+            BPMF_LAUNCH_CHECK();
+        }
+        return 0;
+    };
     float* const beam_final = d_beam_out;
     int32_t* const arg_final = d_arg_out;
     char* const part = (char*)d_workspace + align_up((size_t)S * P * N * sizeof(float), 256);
@@ -2028,7 +2054,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
             const BpFastClass& fc = pl->cls[c];
             rc = launch_beam_fast(fc, pl->id_offset, U, N, lo_s / fc.tile, hi_s / fc.tile, stream,
                                   pbeam + (size_t)c * n_split * N, parg + (size_t)c * n_split * N, n_split,
-                                  rows > 1 ? (long long)N : 0);
+                                  rows > 1 ? (long long)N : 0, t_best0);
         }
         if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
         if (!rc && rows > 1) {
@@ -2036,6 +2062,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
                 pbeam, parg, rows, n_split_edge, lo_s, hi_s, N, beam_final, arg_final);
             BPMF_LAUNCH_CHECK();
         }
+        if (!rc) rc = finish(beam_final, arg_final);
         profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
         return rc;
     }
@@ -2062,6 +2089,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         default: rc = dispatch_beam<4>(pl, U, N, out_of_bounds, reduce, stream, d_beam_out, d_arg_out); break;
     }
     if (!rc) rc = merge_splits();
+    if (!rc && reduce == BPMF_BP_REDUCE_MAX) rc = finish(beam_final, arg_final);
     return rc;
 }
 

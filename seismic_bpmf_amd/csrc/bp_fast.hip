@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves, long long split_stride)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0)
 {
     // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
     // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     float best[TPW];
     int arg[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) { best[j] = 0.0f; arg[j] = id_offset; }
+    for (int j = 0; j < TPW; ++j) { best[j] = best0; arg[j] = id_offset; }   // 0, or -inf (bp.compat_first_computed)
     for (int x = tid; x < BPF_ZERO_SLAB; x += NTHREADS) lds[x] = 0.0f;  // the zero slab
     const long long rec_stride = (long long)rec_dw * 4 * WPB;   // bytes between a wave's consecutive parts
 
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 
 int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_t N, long long tile_lo,
                      long long tile_hi, hipStream_t stream, float* beam, int32_t* arg, int n_split,
-                     long long split_stride)
+                     long long split_stride, float best0)
 {
     if (tile_hi <= tile_lo) return 0;
     const long long n_tiles = tile_hi - tile_lo;
@@ -467,7 +467,7 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
-            fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride);         \
+            fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0);  \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
     else if (fc.tile == 256) { if (fc.uniform) BPF_LAUNCH(true, 4); else BPF_LAUNCH(false, 4); }

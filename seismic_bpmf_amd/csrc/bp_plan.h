@@ -108,5 +108,5 @@ namespace bpmf {
 // test per source).
 int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_t N, long long tile_lo,
                      long long tile_hi, hipStream_t stream, float* beam, int32_t* arg,
-                     int n_split = 1, long long split_stride = 0);
+                     int n_split = 1, long long split_stride = 0, float best0 = 0.0f);
 }

@@ -22,13 +22,17 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Execution options (util.hip, C ABI: bpmf_set_option / bpmf_get_option).  Every option selects
 // among code paths and sizes that produce IDENTICAL results -- kernel family, LDS budget, staging
 // batch sizes, group ranges per tile; none of them can change an output bit, and the library reads
-// nothing from the environment.  The defaults are the tuned production values; the GPU tests use
+// nothing from the environment.  The exception are the three `*.compat_*` switches at the end (off
+// by default): each replaces one convention of this build that rests on recollection only by the
+// alternative the upstream packages may implement.  The defaults are the tuned production values; the GPU tests use
 // the options to force every kernel family through the same parity cases.
 enum Option {
     OPT_BP_LDS_KB, OPT_BP_MAX_GROUP, OPT_BP_TPT, OPT_BP_REORDER, OPT_BP_DUAL, OPT_BP_PACKED,
     OPT_BP_WPS, OPT_BP_UVGPR, OPT_BP_FAST, OPT_BP_FAST_UNIFORM, OPT_BP_SPLIT, OPT_BP_WPB,
     OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_BP_FAST_TILE, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
-    OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_COUNT
+    OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE,
+    // upstream-compatibility switches: the ONLY options that change results (off by default)
+    OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG, OPT_MF_COMPAT_SQRT_NORM, OPT_BP_COMPAT_FIRST_COMPUTED, OPT_COUNT
 };
 long option(Option which);
 

@@ -45,7 +45,7 @@ __global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t
 // chasing weights / moveouts / norms through dependent loads.
 __global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restrict__ w,
                                 const float* __restrict__ r_t, int T, int n_ch, long long step,
-                                long long L, long long N, long long n_corr,
+                                long long L, long long N, long long n_corr, int exclusive_last,
                                 int2* __restrict__ range, int4* __restrict__ chan_rec)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,6 +69,9 @@ __global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restr
     if (any && N >= L) {
         long long first = mv_min < 0 ? (-mv_min + step - 1) / step : 0;
         long long room = N - L - mv_max;
+        // compat (option mf.compat_exclusive_last_lag): data offsets i * step < room only -- the loop
+        // bound `i < stop_i`, stop_i = N - L - max_moveout, that upstream is recollected to use
+        if (exclusive_last) room -= 1;
         if (room >= 0) {
             long long last = room / step;
             if (last > n_corr - 1) last = n_corr - 1;
@@ -756,12 +759,17 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 // ------------------------------------------------------ generic (any step) kernel ---
 // One thread per (template, lag); plain fmaf chain.  Used when step != 1 or when the
 // template is too long for the LDS tile, and as an independent on-device cross-check.
-template <bool NETWORK_SUM>
+// SQRT_NORM (option mf.compat_sqrt_norm, a diffing aid, not a production path): the textbook
+// normalisation upstream is recollected to use -- cc = num / sqrtf(E_t * E_d) where E_t * E_d exceeds
+// 1e-6, else 0 -- instead of num * (r_t * r_d); E_t is the fmaf chain of the template, E_d the
+// float difference of the double prefix sums, both as the oracle defines them.
+template <bool NETWORK_SUM, bool SQRT_NORM = false>
 __global__ __launch_bounds__(256) void mf_direct_kernel(
     const float* __restrict__ tmpl, const int* __restrict__ mv, const float* __restrict__ wgt,
     const float* __restrict__ data, const float* __restrict__ e_t,
     const float* __restrict__ e_d, const int2* __restrict__ range, long long step, int L,
-    long long N, int n_ch, long long n_corr, float* __restrict__ out)
+    long long N, int n_ch, long long n_corr, float* __restrict__ out,
+    const double* __restrict__ cs_local = nullptr, const double* __restrict__ cs_off = nullptr, long long nq = 0)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.y;
@@ -779,9 +787,21 @@ __global__ __launch_bounds__(256) void mf_direct_kernel(
             const float* d = data + (size_t)ch * (size_t)N + j;
             float num = 0.0f;
             for (int l = 0; l < L; ++l) num = __fmaf_rn(tp[l], d[l], num);
-            const float nrm = e_t[(size_t)t * n_ch + ch] * e_d[(size_t)ch * nwin + j];  // r_t * r_d
             float cc = 0.0f;
-            if (nrm < MAX_NORM) cc = num * nrm;
+            if constexpr (SQRT_NORM) {
+                float et = 0.0f;
+                for (int l = 0; l < L; ++l) et = __fmaf_rn(tp[l], tp[l], et);
+                const double* lo = cs_local + (size_t)ch * (size_t)N;
+                const double* of = cs_off + (size_t)ch * (size_t)nq;
+                const long long nh = j + L - 1;
+                const double hi = of[nh / CSUM_CHUNK] + lo[nh];
+                const double low = j > 0 ? of[(j - 1) / CSUM_CHUNK] + lo[j - 1] : 0.0;
+                const float den2 = et * (float)(hi - low);
+                if (den2 > 1.0e-6f) cc = num / sqrtf(den2);
+            } else {
+                const float nrm = e_t[(size_t)t * n_ch + ch] * e_d[(size_t)ch * nwin + j];  // r_t * r_d
+                if (nrm < MAX_NORM) cc = num * nrm;
+            }
             if (NETWORK_SUM)
                 sum = __fmaf_rn(w, cc, sum);
             else
@@ -917,7 +937,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         BPMF_LAUNCH_CHECK();
         mf_range_kernel<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, stream>>>(
             d_moveouts, d_weights, ws.e_t, (int)T, (int)n_ch, (long long)step, (long long)L,
-            (long long)N, (long long)n_corr, ws.range, ws.chan_rec);
+            (long long)N, (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0, ws.range,
+            ws.chan_rec);
         BPMF_LAUNCH_CHECK();
     }
     if (!network_sum)
@@ -934,7 +955,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);  // beyond this (64) the direct kernel wins
     // (the MFMA kernels address the data through buffer descriptors with 32-bit byte offsets:
     // traces of 2^30 samples or more take the generic kernel)
-    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
+    const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;     // generic kernel only
+    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !sqrt_norm && need_r <= 24 &&
                           need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
                           N < ((size_t)1 << 30) - 8192;
     if (use_mfma) {
@@ -982,14 +1004,14 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             set_error("bpmf_mf_run_dev: generic kernel supports at most 65535 templates per call");
             return -1;
         }
-        if (network_sum)
-            mf_direct_kernel<true><<<grid, dim3(256), 0, stream>>>(
-                d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range,
-                (long long)step, (int)L, (long long)N, (int)n_ch, (long long)n_corr, d_cc_out);
-        else
-            mf_direct_kernel<false><<<grid, dim3(256), 0, stream>>>(
-                d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range,
-                (long long)step, (int)L, (long long)N, (int)n_ch, (long long)n_corr, d_cc_out);
+        const long long nq = (long long)((N + CSUM_CHUNK - 1) / CSUM_CHUNK);
+#define BPMF_MF_DIRECT(NS, SQ)                                                                     \
+    mf_direct_kernel<NS, SQ><<<grid, dim3(256), 0, stream>>>(                                      \
+        d_templates, d_moveouts, d_weights, d_data, ws.e_t, ws.e_d, ws.range, (long long)step,     \
+        (int)L, (long long)N, (int)n_ch, (long long)n_corr, d_cc_out, ws.local, ws.off, nq)
+        if (network_sum) { if (sqrt_norm) BPMF_MF_DIRECT(true, true); else BPMF_MF_DIRECT(true, false); }
+        else { if (sqrt_norm) BPMF_MF_DIRECT(false, true); else BPMF_MF_DIRECT(false, false); }
+#undef BPMF_MF_DIRECT
     }
     BPMF_LAUNCH_CHECK();
     profile_mark(BPMF_KERNEL_MF_MAIN, 1, stream);

@@ -179,6 +179,9 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
                                C, P, out_of_bounds, reduce, dev[i], beam_out + k0 * N, nullptr);
         });
     }
+    // (option bp.compat_first_computed: a device's result carries (0, first id) where it computed no
+    // beam, which the host merge cannot tell from a real 0 -- the switch runs on one device)
+    if (bpmf::option(bpmf::OPT_BP_COMPAT_FIRST_COMPUTED) != 0 && dev.size() > 1) dev.resize(1);
     if (dev.size() == 1)
         return bpmf_bp_run(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds,
                            reduce, dev[0], beam_out, arg_out);
