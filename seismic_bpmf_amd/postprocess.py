@@ -533,3 +533,30 @@ def excess_kurtosis_f32(a):
         if m2 <= (np.finfo(np.float32).eps * mean[0]) ** 2:
             return np.float32(np.nan)
         return np.float32(m4 / m2 ** 2.0) - np.float32(3)
+
+
+# ---------------------------------------------------------------- event relocation ---
+def likelihood(beam_column):
+    """Beamformer._likelihood (BPMF/template_search.py:498-506): the beam over the grid at the time of
+    maximum focusing, rescaled to [0, 1] -- (x - min) / (max - min), clipped."""
+    x = np.asarray(beam_column)
+    like = (x - x.min()) / (x.max() - x.min())
+    return np.clip(like, a_min=0.0, a_max=1.0)
+
+
+def gibbs_weights(maxbeam, effective_kT=0.33):
+    """Likelihood of the "temporal" uncertainty method of Event.relocate_beam
+    (BPMF/dataset.py:2224-2231): exp(-(max - maxbeam) / effective_kT)."""
+    mb = np.asarray(maxbeam)
+    return np.exp(-(mb.max() - mb) / effective_kT)
+
+
+def location_uncertainty(likelihood_domain, distances_km, depth_diff_km):
+    """Beamformer._compute_location_uncertainty (BPMF/template_search.py:1269-1333) behind its geodesic
+    call: likelihood-weighted mean epicentral distance and mean absolute depth difference of the
+    sources of the domain.  `distances_km`: distance of every source of the domain to the event (the
+    reference takes cartopy's Geodesic().inverse(...)[:, 0] / 1000); returns (hunc, vunc) in km."""
+    like = np.asarray(likelihood_domain)
+    hunc = np.sum(like * np.asarray(distances_km)) / np.sum(like)
+    vunc = np.sum(like * np.asarray(depth_diff_km)) / np.sum(like)
+    return hunc, vunc

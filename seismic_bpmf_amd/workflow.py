@@ -250,6 +250,28 @@ def relocation_focus(beamformer, features, weights_phases, uncertainty_method="s
     raise ValueError("uncertainty_method should be 'spatial' or 'temporal'")
 
 
+def relocation_likelihood(beamformer, features, weights_phases, out_of_bounds="flexible", domain=None):
+    """The spatial branch of ``Event.relocate_beam`` (BPMF/dataset.py:2186-2245) up to the likelihood,
+    on the device: backprojection of the event's short feature array over the whole grid
+    (``reduce="none"``, the (K, N) volume stays in HBM), the point of maximum focusing, and
+    ``Beamformer._likelihood`` of the beam column at that time (BPMF/template_search.py:498-506) --
+    float32 subtract / divide / clip, the operations NumPy performs, evaluated on the column where it
+    lies.  Only `likelihood[domain]` (or the whole (K,) vector when `domain` is None) comes back.
+
+    Returns (src_idx, time_idx, likelihood): feed `likelihood` with the domain's geodesic distances
+    to postprocess.location_uncertainty for (hunc, vunc)."""
+    import torch
+    vol = beamformer.run(features, weights_phases, "none", out_of_bounds)
+    first = int(torch.argmax(vol.reshape(-1)))
+    src_idx, time_idx = divmod(first, vol.shape[1])
+    col = vol[:, time_idx]
+    lo, hi = col.min(), col.max()
+    like = ((col - lo) / (hi - lo)).clamp_(0.0, 1.0)
+    if domain is not None:
+        like = like[torch.as_tensor(np.asarray(domain, dtype=np.int64), device=like.device)]
+    return src_idx, time_idx, like.cpu().numpy()
+
+
 def backprojection_detections(features, moveouts, weights_phases, weights_sources, *, sr,
                               minimum_interevent_time, threshold_window_dur=None, n_dev=15.0,
                               overlap=0.75, threshold=None, out_of_bounds="strict", device=None,

@@ -72,8 +72,60 @@ def cc_like_series(rng, n, gaps=True):
     return x
 
 
+def relocation_goldens(BPMF):
+    """Beamformer._likelihood and Beamformer._compute_location_uncertainty (BPMF/template_search.py:
+    498-506, 1269-1333) and the Gibbs weights of Event.relocate_beam (BPMF/dataset.py:2224-2231) on
+    seeded beam columns.  cartopy (the geodesic distances of :1311-1321) is absent here: its
+    Geodesic.inverse is replaced by a deterministic plane approximation, and the distances it returned
+    are stored with the vectors -- what the golden pins is the reference's arithmetic around them."""
+    import types
+    import pandas as pd
+    from BPMF import template_search
+    rng = np.random.default_rng(20260929)
+
+    class _Geodesic:
+        def inverse(self, point, endpoints):
+            point, endpoints = np.asarray(point, float), np.asarray(endpoints, float)
+            dx = (endpoints[:, 0] - point[0]) * 111_194.9 * np.cos(np.deg2rad(point[1]))
+            dy = (endpoints[:, 1] - point[1]) * 111_194.9
+            return np.stack([np.hypot(dx, dy), np.zeros(len(dx)), np.zeros(len(dx))], axis=1)
+
+    sys.modules["cartopy"] = types.ModuleType("cartopy")
+    sys.modules["cartopy.geodesic"] = types.ModuleType("cartopy.geodesic")
+    sys.modules["cartopy.geodesic"].Geodesic = _Geodesic
+    out = {}
+    n_cases = 4
+    for j in range(n_cases):
+        K = (500, 5000, 37, 1200)[j]
+        col = np.abs(rng.standard_normal(K)).astype(np.float32) * np.float32((1.0, 30.0, 1e-3, 5.0)[j])
+        if j == 3:
+            col[::7] = col.max()                     # ties at the maximum
+        like = template_search.Beamformer._likelihood(col)
+        coords = pd.DataFrame({"longitude": rng.uniform(30.0, 31.0, K), "latitude": rng.uniform(40.0, 41.0, K),
+                               "depth": rng.uniform(0.0, 30.0, K)})
+        fake = types.SimpleNamespace(source_coordinates=coords)
+        k0 = int(col.argmax())
+        domain = np.sort(rng.choice(K, size=max(3, K // 3), replace=False))
+        ev = (coords["longitude"].iloc[k0], coords["latitude"].iloc[k0], coords["depth"].iloc[k0])
+        hunc, vunc = template_search.Beamformer._compute_location_uncertainty(fake, *ev, like[domain], domain)
+        dist = _Geodesic().inverse(np.array(ev[:2]), np.hstack((coords["longitude"].values[domain, None],
+                                                                coords["latitude"].values[domain, None])))[:, 0] / 1000.0
+        # temporal method: Gibbs weights of the max-beam (dataset.py:2224-2231)
+        maxbeam = np.abs(rng.standard_normal(3000)).astype(np.float32) * np.float32(2.0)
+        gibbs = np.exp(-(maxbeam.max() - maxbeam) / 0.33)
+        out.update({f"column_{j}": col, f"likelihood_{j}": like, f"domain_{j}": domain,
+                    f"distances_km_{j}": dist, f"depth_diff_{j}": np.abs(ev[2] - coords["depth"].values[domain]),
+                    f"hunc_{j}": np.float64(hunc), f"vunc_{j}": np.float64(vunc),
+                    f"maxbeam_{j}": maxbeam, f"gibbs_{j}": gibbs})
+    np.savez_compressed(os.path.join(HERE, "relocation.npz"), n_cases=n_cases, effective_kT=0.33, **out)
+
+
 def main():
     BPMF, clib = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "relocation":      # only this file (the others stay untouched)
+        relocation_goldens(BPMF)
+        print("relocation.npz written")
+        return
     from BPMF import similarity_search, template_search, utils
     rng = np.random.default_rng(20260928)
     out = {}
@@ -380,6 +432,7 @@ def main():
         tg.normalize(method=method)
         wts[f"tg_norm_{method}"] = np.asarray(tg._waveforms_arr)
     np.savez_compressed(os.path.join(HERE, "weights.npz"), **wts)
+    relocation_goldens(BPMF)
 
     print("goldens written to", HERE)
     for fn in sorted(os.listdir(HERE)):

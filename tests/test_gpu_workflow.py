@@ -325,3 +325,24 @@ def test_row_kurtosis_is_scipy_on_float32_bit_for_bit():
         got = workflow.row_excess_kurtosis(torch.as_tensor(x, device="cuda"))
         assert np.array_equal(want, ref, equal_nan=True), n
         assert np.array_equal(got, want, equal_nan=True), (n, got, want)
+
+
+def test_relocation_likelihood_on_device_equals_the_host_mirror(oracle_lib):
+    """workflow.relocation_likelihood: focus point and likelihood of the beam column computed where the
+    (K, N) volume lies, against the oracle's volume + the host mirror pinned to the reference."""
+    from seismic_bpmf_amd import BeamformerGPU, postprocess as pp, synthetic as syn, workflow
+    geo = syn.make_bp_geometry((12, 12, 6), 9, 2, 50.0, n_closest=9)
+    feat, planted = syn.make_bp_features(geo["moveouts"], 9, 3, 2500, sr=50.0, n_events=1)
+    wp = syn.phase_weights(9, 3, 2)
+    bf = BeamformerGPU(geo["moveouts"], geo["weights_sources"])
+    try:
+        dom = np.arange(0, geo["moveouts"].shape[0], 3)
+        src, t_idx, like = workflow.relocation_likelihood(bf, feat, wp, "flexible", domain=dom)
+        _, _, like_all = workflow.relocation_likelihood(bf, feat, wp, "flexible")
+    finally:
+        bf.close()
+    vol = oracle_lib.beamform(feat, geo["moveouts"], wp, geo["weights_sources"], "flexible", "none")
+    k_ref, t_ref = np.unravel_index(vol.argmax(), vol.shape)
+    assert (src, t_idx) == (int(k_ref), int(t_ref)) and src == planted[0][0]
+    want = pp.likelihood(vol[:, t_ref])
+    assert like_all.dtype == np.float32 and np.array_equal(like_all, want) and np.array_equal(like, want[dom])

@@ -277,3 +277,16 @@ def test_has_close_ties():
     assert not pp.has_close_ties(idx, np.array([2.0, 5.0, 2.0, 2.0]), 300)      # equal, but far apart
     assert pp.has_close_ties(idx, np.array([2.0, 5.0, 2.0, 2.0]), 500)
     assert not pp.has_close_ties(idx[:1], np.array([2.0]), 500)
+
+
+def test_relocation_likelihood_and_uncertainty_match_reference():
+    """Beamformer._likelihood, the weighted means of _compute_location_uncertainty and the Gibbs weights
+    of relocate_beam (BPMF/template_search.py:498-506, 1269-1333; dataset.py:2224-2231) against vectors
+    produced by the reference's own methods (tests/golden/make_goldens.py: relocation_goldens)."""
+    g = load("relocation.npz")
+    for j in range(int(g["n_cases"])):
+        like = pp.likelihood(g[f"column_{j}"])
+        assert like.dtype == g[f"likelihood_{j}"].dtype and np.array_equal(like, g[f"likelihood_{j}"]), j
+        hunc, vunc = pp.location_uncertainty(like[g[f"domain_{j}"]], g[f"distances_km_{j}"], g[f"depth_diff_{j}"])
+        assert hunc == g[f"hunc_{j}"] and vunc == g[f"vunc_{j}"], j
+        assert np.array_equal(pp.gibbs_weights(g[f"maxbeam_{j}"], float(g["effective_kT"])), g[f"gibbs_{j}"]), j
