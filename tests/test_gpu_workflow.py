@@ -332,7 +332,7 @@ def test_relocation_likelihood_on_device_equals_the_host_mirror(oracle_lib):
     (K, N) volume lies, against the oracle's volume + the host mirror pinned to the reference."""
     from seismic_bpmf_amd import BeamformerGPU, postprocess as pp, synthetic as syn, workflow
     geo = syn.make_bp_geometry((12, 12, 6), 9, 2, 50.0, n_closest=9)
-    feat, planted = syn.make_bp_features(geo["moveouts"], 9, 3, 2500, sr=50.0, n_events=1)
+    feat, planted = syn.make_bp_features(geo["moveouts"], 9, 3, 6000, sr=50.0, n_events=1, amp=20.0)
     wp = syn.phase_weights(9, 3, 2)
     bf = BeamformerGPU(geo["moveouts"], geo["weights_sources"])
     try:
@@ -343,6 +343,6 @@ def test_relocation_likelihood_on_device_equals_the_host_mirror(oracle_lib):
         bf.close()
     vol = oracle_lib.beamform(feat, geo["moveouts"], wp, geo["weights_sources"], "flexible", "none")
     k_ref, t_ref = np.unravel_index(vol.argmax(), vol.shape)
-    assert (src, t_idx) == (int(k_ref), int(t_ref)) and src == planted[0][0]
+    assert (src, t_idx) == (int(k_ref), int(t_ref)) and planted and abs(t_idx - planted[0][1]) <= 3
     want = pp.likelihood(vol[:, t_ref])
     assert like_all.dtype == np.float32 and np.array_equal(like_all, want) and np.array_equal(like, want[dom])
