@@ -154,3 +154,56 @@ def test_bp_random_shapes_signed_moveouts(oracle_lib, seed):
         for oob in ("strict", "flexible"):
             _same(beamform(f, tau, wp, ws, device="gpu", reduce="none", out_of_bounds=oob),
                   oracle_lib.beamform(f, tau, wp, ws, oob, "none"), f"seed {seed} full beam {oob}")
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(30))
+def test_bp_random_dense_and_mixed_station_counts(oracle_lib, seed, hip_opts):
+    """Round 3: sources with 1..70 weighted stations in one grid (station-count classes of the
+    interior kernel on tiles of 512 / 256 / 128 samples, multi-part records, the class merge; above 64
+    stations the general kernels alone), random forced tiles and group ranges, moveouts of both signs,
+    uniform and per-station weights, ties."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(9100 + seed)
+    S = int(rng.choice([18, 21, 24, 33, 40, 48, 64, 70]))
+    K = int(rng.integers(20, 400))
+    C = int(rng.integers(1, 4))
+    N = int(rng.choice([700, 1024, 3000, 5000, 9001]))
+    lo = -int(rng.choice([0, 0, 5, 60, 300]))
+    hi = int(rng.choice([0, 9, 100, 400]))
+    f = np.abs(rng.standard_normal((S, C, N))).astype(np.float32)
+    if seed % 3 == 0:
+        f = np.round(f * 2)
+    tau = rng.integers(lo, hi + 1, (K, S, 2)).astype(np.int32)
+    if seed % 2:                                     # smooth moveouts: groups of many sources
+        base = rng.integers(lo, hi + 1, (1, S, 2))
+        tau = (base + rng.integers(-4, 5, (K, S, 2))).astype(np.int32)
+    wp = rng.random((S, C, 2)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    mode = seed % 4
+    for k in range(K):
+        if mode == 0:
+            n = S                                     # dense
+        elif mode == 1:
+            n = int(rng.integers(1, S + 1))           # anything
+        elif mode == 2:
+            n = int(rng.choice([3, 10, 16, 17, min(S, 40)]))
+        else:
+            n = int(rng.integers(max(1, S - 6), S + 1))
+        sel = rng.choice(S, n, replace=False)
+        ws[k, sel] = 0.25 if seed % 5 else rng.uniform(0.1, 1.0, n).astype(np.float32)
+    if K > 30:
+        ws[7] = 0.0
+        tau[11], ws[11] = tau[29], ws[29]             # identical sources: the lower id must win
+    if seed % 6 == 0:
+        hip_opts("bp.fast_tile", int(rng.choice([256, 128])))
+    if seed % 7 == 0:
+        hip_opts("bp.split", int(rng.integers(2, 6)))
+    bf = BeamformerGPU(tau, ws)
+    try:
+        for oob in ("strict", "flexible"):
+            mb, ma = bf.run(f, wp, "max", oob)
+            ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+            _same(mb.cpu().numpy(), ob, f"seed {seed} {oob} maxbeam (K={K} S={S} N={N} mode={mode} tau in [{lo},{hi}]) {bf.plan_info()}")
+            _same(ma.cpu().numpy(), oa, f"seed {seed} {oob} argmax {bf.plan_info()}")
+    finally:
+        bf.close()
