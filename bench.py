@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--bp-config", default=None,
                     help="default: cfg3 (configs[2]) on one GPU, cfg5_per_gpu (configs[4]'s share) on N > 1")
     ap.add_argument("--skip-dense", action="store_true", help="skip the dense-station-weight BP extras")
+    ap.add_argument("--skip-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (rocprofv3 --pmc child passes, ~2 min); "
+                         "the committed figures of profiles/ are quoted instead")
     ap.add_argument("--skip-e2e", action="store_true", help="skip the host-pointer end-to-end extra")
     ap.add_argument("--skip-bp", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
@@ -154,6 +157,49 @@ def bp_detection_stage(beam, arg, geo, bcfg):
             "full_length_d2h": False, "detections": int(peaks.size),
             "planted": len(geo["planted"]), "planted_found_within_5_samples": found,
             "planted_located_at_planted_source": same_source}
+
+
+# ------------------------------------------------------------------ HBM traffic (PMC) ---
+def measure_traffic(target, kernels, extra_args=(), timeout=240):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: two separate
+    `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE -- the two do not fit one pass, counters
+    only, no other trace domain: MI355X_MICROARCH.md, HBM / rocprofv3 sections) over a small script that
+    launches the same kernel on the same workload (tools/prof_mf.py 500 / tools/prof_bp.py), as child
+    processes after the timed region.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at
+    64 bytes), WRITE_SIZE is taken as is (it equals the output size: the calibration).  Returns a
+    dict or None when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bpmf_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(ROOT, "tools", target)] + list(extra_args)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    for k in kernels:
+                        if k in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            vals.setdefault(k, []).append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            # per launch of the workload = the sum over the kernels that make it up (interior + edge)
+            out[counter] = sum(sum(v) / len(v) for v in vals.values()) * 1024.0
+            out[counter + "_launches"] = max(len(v) for v in vals.values())
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["hbm_bytes_per_launch"] = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+    return out
 
 
 # ----------------------------------------------------------------------- CPU baseline ---
@@ -498,6 +544,43 @@ def main():
                "row0_peak_cc": round(float(h_cc[0].max()), 4)}
         del h_cc, h_t, h_mv, h_w, h_d
 
+    # untimed extras: the matched filter off its headline shape -- BASELINE
+    # configs[0] (the reference's own CPU-runnable case: one hour, 4 templates, L = 128) and a day with
+    # 128-sample templates; kernel time from the library's events, the whole call from the host clock
+    mf_shapes = None
+    if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
+        mf_shapes = {}
+        for name, (T2, S2, C2, L2, N2) in (("configs0", (4, 8, 3, 128, 180_000)), ("day_L128", (50, 20, 3, 128, 8_640_000))):
+            g2 = torch.Generator(device=device)
+            g2.manual_seed(77)
+            d2 = torch.randn((S2, C2, N2), device=device, generator=g2)
+            t2 = torch.randn((T2, S2, C2, L2), device=device, generator=g2)
+            m2 = torch.randint(0, 1500, (T2, S2, C2), device=device, dtype=torch.int32, generator=g2)
+            w2 = torch.full((T2, S2, C2), 1.0 / (S2 * C2), device=device)
+            mf2 = sb.MatchedFilterGPU(device=local_rank)
+            mf2.set_data(d2)
+            o2 = mf2.run(t2, m2, w2, 1)
+            torch.cuda.synchronize()
+            reps = 20 if N2 < 1_000_000 else 3
+            _lib.profile_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                mf2.run(t2, m2, w2, 1, out=o2)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / reps
+            _lib.profile_enable(False)
+            kms = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_MF_MAIN)))
+            flop = 2.0 * L2 * S2 * C2 * T2 * (N2 - L2 + 1)
+            mf_shapes[name] = {"workload": f"{T2} templates x {S2} stations x {C2} comp, L={L2}, N={N2}, step 1 (data resident and prepared)",
+                               "ms_per_call": round(wall * 1e3, 4), "kernel_ms": round(kms, 4),
+                               "value": round(T2 * (N2 - L2 + 1) / wall / 1e6, 1), "unit": "M CC-samples/s",
+                               "roofline": {"kernel": "mf_mfma_wave_kernel", "bound": "mfma",
+                                            "achieved": round(flop / (kms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": round(flop / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                            "frac_whole_call": round(flop / wall / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+            del d2, t2, m2, w2, o2, mf2
+        torch.cuda.empty_cache()
+
     # ---------------------------------------------------------------- backprojection
     bp_obj = None
     if not args.skip_bp:
@@ -641,6 +724,31 @@ def main():
     if rank == 0 and world == 1 and not args.skip_cpu:
         cpu = cpu_baseline(cfg, args.cpu_seconds)
 
+    # roofline.traffic measured in this run (separate PMC passes in child processes, after everything
+    # else, with this process's device memory released); headline workloads only
+    if rank == 0 and world == 1 and dist is None and not args.skip_traffic:
+        try:
+            del data, tmpl, mv, w
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        if args.mf_config == "cfg2" and roofline is not None:
+            tr = measure_traffic("prof_mf.py", ["mf_mfma"], ["500"])
+            if tr:
+                roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = ("measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                                              "tools/prof_mf.py 500 (the same kernel on cfg2's shape), FETCH_SIZE x 2 (gfx950), "
+                                              f"{tr['FETCH_SIZE_launches']} launches; fetched {tr['FETCH_SIZE'] * 2 / 1e9:.1f} GB, "
+                                              f"written {tr['WRITE_SIZE'] / 1e9:.2f} GB")
+        if bp_obj is not None and args.bp_config == "cfg3" and not args.skip_bp:
+            tr = measure_traffic("prof_bp.py", ["bp_beam_fast", "bp_beam_wps2"])
+            if tr:
+                bp_obj["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                bp_obj["roofline"]["traffic_source"] = (
+                    "measured in this run: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/prof_bp.py "
+                    "(interior + edge kernels of cfg3), FETCH_SIZE x 2 (gfx950); "
+                    f"fetched {tr['FETCH_SIZE'] * 2 / 1e9:.2f} GB, written {tr['WRITE_SIZE'] / 1e6:.1f} MB")
+
     line = None
     if rank == 0:
         line = {
@@ -656,7 +764,8 @@ def main():
                                        "data replicated, no data-path collective; all-gather of merged peak records"
                                        if world > 1 else "single GPU"),
                        "row0_peak_cc": round(peak, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "bp": bp_obj, "detection": detect,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "mf_shapes": mf_shapes, "bp": bp_obj,
+            "detection": detect,
         }
     if dist is not None:
         dist.destroy_process_group()

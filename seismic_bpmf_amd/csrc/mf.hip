@@ -534,7 +534,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // execute in order): single-buffered, 6.6 KB per wave instead of 9.9 KB.  The price is the
 // 256-float overlap between neighbouring waves' windows (25 % more staging traffic from L2).
 // Used for L <= 257 (window 1280 floats = 20 staging registers per lane).
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
+// NTILE: 16x16 tiles (of 256 lags) per wave -- 4 for a day-long search (the A operand of a k-step
+// feeds 4 MFMAs); 2 or 1 when the whole problem has too few waves to fill the chip otherwise (an
+// hour-long series with a handful of templates, BASELINE configs[0]: 704 waves of 1024 lags on 1024
+// SIMDs, each wave alone with its serial work; at 256 lags per wave 2816 waves share the matrix pipes
+// three to a SIMD).  The hand-placed operand reads and their counted waits follow NTILE.
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
@@ -544,7 +549,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
     const int tp_len = mf_band_len(L);
-    const int Ww = MF_LAGS_PER_WAVE - 16 + Kpad;          // this wave's window
+    static_assert(NTILE == 4 || NTILE == 2 || NTILE == 1, "tiles per wave");
+    constexpr int LAGS_W = 256 * NTILE, LAGS_WG = 4 * LAGS_W;
+    const int Ww = LAGS_W - 16 + Kpad;          // this wave's window
     const int wave_floats = tp_len + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64;
 
     const int tid = threadIdx.x;
@@ -562,16 +569,16 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     // the loop also cost 7 spilled registers.  One block per workgroup.)
     if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
     const int2 rgi = range[t];
-    const long long lag0 = lag_block * MF_LAGS_PER_WG + (long long)wv * MF_LAGS_PER_WAVE;
+    const long long lag0 = lag_block * LAGS_WG + (long long)wv * LAGS_W;
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
 
-    f32x4 sum[4];
+    f32x4 sum[NTILE];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int u = 0; u < NTILE; ++u) sum[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    const bool wave_valid = rg.x <= rg.y && !(lag0 > rg.y || lag0 + MF_LAGS_PER_WAVE - 1 < rg.x);   // empty range: first > last
-    const bool wave_inside = lag0 >= rg.x && lag0 + MF_LAGS_PER_WAVE - 1 <= rg.y;
+    const bool wave_valid = rg.x <= rg.y && !(lag0 > rg.y || lag0 + LAGS_W - 1 < rg.x);   // empty range: first > last
+    const bool wave_inside = lag0 >= rg.x && lag0 + LAGS_W - 1 <= rg.y;
     const long long lag_w = lag0 + 16 * a + 4 * kq;
 
     if (wave_valid) {
@@ -624,9 +631,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             const float et = __int_as_float(rec.w);
             const int4 rec2 = recs[ri + 2];
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
-            f32x4 ed[4];
+            f32x4 ed[NTILE];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NTILE; ++u) {
                 const long long lag = lag_w + 256 * u;
                 // One 16-byte load per group of 4 lags.  A group that straddles an end of the
                 // valid range reads up to 3 floats outside this channel's row of norms -- the
@@ -640,12 +647,12 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
             if (rec1.x >= 0) issue_stage(rec1.x, rec1.y);
 
-            f32x4 acc[4];
+            f32x4 acc[NTILE];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int u = 0; u < NTILE; ++u) acc[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             const int nq = Kpad >> 4;
             unsigned ap = (unsigned)(size_t)(tp + a_base), bp = (unsigned)(size_t)(dw + b_base);
-            float sa[4], sb[4][4];
+            float sa[4], sb[4][NTILE];
             // counted waits as in mf_mfma_kernel; the ds_writes above are older than every read
             // and complete first (one wave's LDS ops are ordered), so they can only make the
             // count stricter
@@ -653,36 +660,31 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define MF_MFMA(slot, u) \
     acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[slot], sb[slot][u], acc[u], 0, 0, 0)
-#define MF_REQ(slot, aoff, boff)                                    \
-    MF_LDS_READ(sa[slot], ap, (aoff));                               \
-    MF_LDS_READ(sb[slot][0], bp, (boff));                            \
-    MF_LDS_READ(sb[slot][1], bp, (boff) + 1152);                     \
-    MF_LDS_READ(sb[slot][2], bp, (boff) + 2304);                     \
-    MF_LDS_READ(sb[slot][3], bp, (boff) + 3456)
-// One k-step: the 4 MFMAs of slot `cur` with the 5 operand reads of slot `req` (two k-steps
-// ahead) issued BETWEEN them.  A wave issues in order and waits ~32 cycles at every MFMA for the
-// matrix pipe; a read placed there issues for free, a block of reads after the MFMAs would add
+#define MF_REQ(slot, aoff, boff)                                                    \
+    MF_LDS_READ(sa[slot], ap, (aoff));                                               \
+    MF_LDS_READ(sb[slot][0], bp, (boff));                                            \
+    if constexpr (NTILE > 1) MF_LDS_READ(sb[slot][1 % NTILE], bp, (boff) + 1152);    \
+    if constexpr (NTILE > 2) MF_LDS_READ(sb[slot][2 % NTILE], bp, (boff) + 2304);    \
+    if constexpr (NTILE > 2) MF_LDS_READ(sb[slot][3 % NTILE], bp, (boff) + 3456)
+// One k-step: the NTILE MFMAs of slot `cur` with the NTILE + 1 operand reads of slot `req` (two
+// k-steps ahead) issued BETWEEN them.  A wave issues in order and waits ~32 cycles at every MFMA for
+// the matrix pipe; a read placed there issues for free, a block of reads after the MFMAs would add
 // its issue time to every k-step.  On entry the reads of `cur` and of the k-step after it are
-// outstanding (10), LDS returns in order, so lgkmcnt(5) = "cur has landed".
-#define MF_STEP(cur, req, aoff, boff)                                \
-    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");               \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA(cur, 0);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sa[req], ap, (aoff));                                \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA(cur, 1);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][0], bp, (boff));                             \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA(cur, 2);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][1], bp, (boff) + 1152);                      \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_MFMA(cur, 3);                                                 \
-    __builtin_amdgcn_sched_barrier(0);                               \
-    MF_LDS_READ(sb[req][2], bp, (boff) + 2304);                      \
-    MF_LDS_READ(sb[req][3], bp, (boff) + 3456);                      \
+// outstanding (2 (NTILE + 1)), LDS returns in order, so lgkmcnt(NTILE + 1) = "cur has landed".
+#define MF_STEP(cur, req, aoff, boff)                                                \
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NTILE + 1) : "memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    MF_MFMA(cur, 0);                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    MF_LDS_READ(sa[req], ap, (aoff));                                                \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    if constexpr (NTILE > 1) { MF_MFMA(cur, 1 % NTILE); __builtin_amdgcn_sched_barrier(0); } \
+    MF_LDS_READ(sb[req][0], bp, (boff));                                             \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    if constexpr (NTILE > 2) { MF_MFMA(cur, 2 % NTILE); __builtin_amdgcn_sched_barrier(0); } \
+    if constexpr (NTILE > 1) { MF_LDS_READ(sb[req][1 % NTILE], bp, (boff) + 1152); __builtin_amdgcn_sched_barrier(0); } \
+    if constexpr (NTILE > 2) { MF_MFMA(cur, 3 % NTILE); __builtin_amdgcn_sched_barrier(0); } \
+    if constexpr (NTILE > 2) { MF_LDS_READ(sb[req][2 % NTILE], bp, (boff) + 2304); MF_LDS_READ(sb[req][3 % NTILE], bp, (boff) + 3456); } \
     __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
             MF_REQ(0, 0, 0);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
                 // but the first and last tiles of a day): no per-lag range tests
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NTILE; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float nrm = et * ed[u][r];  // r_t * r_d
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 }
             } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NTILE; ++u) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long lag = lag_w + 256 * u + r;
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     }
     if (NETWORK_SUM) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NTILE; ++u) {
             const long long lag = lag_w + 256 * u;
             float* dst = out + (size_t)t * n_corr + lag;
             if (STEP1 && lag + 3 < n_corr) {
@@ -977,18 +979,37 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
         const bool wave_kernel = option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
-            const int Kp = mf_kpad((int)L), Ww = MF_LAGS_PER_WAVE - 16 + Kp;
-            dim3 grid_w = grid;
+            // tiles (of 256 lags) per wave: 4 unless the problem is too small to give every SIMD ~4 waves
+            // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
+            const size_t waves4 = T * ((n_offsets + 4095) / 4096) * 4;
+            int ntile = waves4 >= 4096 ? 4 : (2 * waves4 >= 4096 ? 2 : 1);
+            const long forced = option(OPT_MF_TILES_PER_WAVE);
+            if (forced == 1 || forced == 2 || forced == 4) ntile = (int)forced;
+            const int Kp = mf_kpad((int)L), Ww = 256 * ntile - 16 + Kp;
+            const size_t lags_wg = (size_t)4 * 256 * ntile;
+            const size_t n_blocks_w = (n_offsets + lags_wg - 1) / lags_wg;
+            if (T * (n_blocks_w + 8) >= 0x7fffffffull) {
+                set_error("bpmf_mf_run_dev: grid too large");
+                return -1;
+            }
+            dim3 grid_w((unsigned)(T * 8 * ((n_blocks_w + 7) / 8)));
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
-#define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                           \
-    mf_mfma_wave_kernel<NS, 20, 5, S1><<<grid_w, dim3(MF_THREADS), wl, stream>>>(                \
+#define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT)                                                     \
+    mf_mfma_wave_kernel<NS, R, 5, S1, NT><<<grid_w, dim3(MF_THREADS), wl, stream>>>(            \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks)
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w)
+#define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
+    do {                                                                                         \
+        if (ntile == 4) BPMF_MF_WAVE_LAUNCH3(NS, S1, 20, 4);                                     \
+        else if (ntile == 2) BPMF_MF_WAVE_LAUNCH3(NS, S1, 12, 2);                                \
+        else BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1);                                                 \
+    } while (0)
             if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
             else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);
             else BPMF_MF_WAVE_LAUNCH(false, false);
 #undef BPMF_MF_WAVE_LAUNCH
+#undef BPMF_MF_WAVE_LAUNCH3
         } else if (need_r <= 17 && need_t <= 2) {   // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041

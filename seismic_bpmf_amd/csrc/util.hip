@@ -49,6 +49,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.host_batch_kb", 0, 0, 1L << 30},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
     {"mf.host_piece_kb", 0, 0, 1L << 30},  // host-pointer call: pinned piece (0 = 64 MB)
     {"mf.verbose", 0, 0, 1},
+    {"mf.tiles_per_wave", 0, 0, 4},     // 16x16 tiles per wave of the L <= 257 kernel: 0 = by problem size, 1 / 2 / 4
     {"mf.compat_exclusive_last_lag", 0, 0, 1},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (generic kernel; default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1},      // running max starts from the first computed beam (default: from (0, source 0))

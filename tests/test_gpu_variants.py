@@ -50,6 +50,40 @@ def test_mf_both_mfma_kernels(oracle_lib, wave_kernel, hip_opts):
               oracle_lib.matched_filter(tp, mv, w, d, 1, ns), f"wave_kernel={wave_kernel} ns={ns}")
 
 
+@pytest.mark.parametrize("ntile", [1, 2, 4])
+@pytest.mark.parametrize("L", [1, 17, 128, 241, 257])
+def test_mf_tiles_per_wave(oracle_lib, ntile, L, hip_opts):
+    """mf.tiles_per_wave: the per-wave kernel with 1, 2 or 4 tiles of 256 lags per wave (small problems
+    take fewer lags per wave so that every SIMD gets several waves: BASELINE configs[0]); the same bits
+    whatever the split -- negative moveouts, zero-weight channels, steps 1 and 3, both layouts, series
+    shorter than one workgroup's lags and series that end inside a tile."""
+    from seismic_bpmf_amd import matched_filter
+    hip_opts("mf.tiles_per_wave", ntile)
+    rng = np.random.default_rng(50 * ntile + L)
+    for N in (L + 5, 700, 1024 + L, 9000):
+        if N < L:
+            continue
+        T, S, C = 3, 3, 2
+        tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+        mv = rng.integers(-70, 400, (T, S, C)).astype(np.int32)
+        w = rng.random((T, S, C)).astype(np.float32)
+        w[1, 2] = 0.0
+        d = rng.standard_normal((S, C, N)).astype(np.float32)
+        for step in (1, 3):
+            for ns in (True, False):
+                _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
+                      oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"ntile={ntile} L={L} N={N} step={step} ns={ns}")
+
+
+def test_mf_small_problems_pick_fewer_lags_per_wave(oracle_lib):
+    """BASELINE configs[0]'s shape (4 templates, one hour at 50 Hz) takes the one-tile kernel by itself
+    and still equals the oracle; a day does not change kernels."""
+    from seismic_bpmf_amd import matched_filter, synthetic as syn
+    m = syn.make_mf_inputs(T=4, S=8, C=3, L=128, N=60_000, seed=2, max_moveout=300, n_events=2)
+    got = matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1, check_zeros=False)
+    _same(got, oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1), "configs[0]-shaped")
+
+
 @pytest.mark.parametrize("L", [48, 130, 256, 257])
 @pytest.mark.parametrize("step", [1, 3])
 def test_mf_negative_moveouts_zero_weights_steps(oracle_lib, L, step):
