@@ -1013,6 +1013,8 @@ struct PlanHost {
     std::vector<float> beta;
     size_t lds_floats = 0;
     int NT = 4;
+    int n_pass = 1;             // 2: every group is two consecutive entries of `groups` (station halves)
+    std::vector<int> half;      // n_pass == 2: stations of source q that belong to the first half
 };
 
 // Processing order: recursive median bisection of the sources on the moveout column with
@@ -1188,6 +1190,148 @@ bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& orde
     return true;
 }
 
+// Two-residency plan (bp_fast.hip, HALVES): dual windows at `tile`, groups of at most `max_group`
+// sources, the weighted stations of every source split in two halves (the first ceil(n / 2) in
+// station order, then the rest); a group is closed when either half's windows would exceed the LDS.
+// Every group becomes TWO consecutive entries of ph.groups (same sources, the chunks of one half each);
+// ph.off holds the offsets of a source's terms inside the residency its half belongs to.
+bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int>& order_in, size_t S, size_t P,
+                       int tile, int chunk, const size_t hard_floats, int max_group, int32_t id_offset,
+                       PlanHost& ph)
+{
+    auto row_len = [&](int spread) -> size_t { return ((size_t)tile + (size_t)spread + 3) & ~(size_t)3; };
+    auto row_cost = [&](int spread) -> size_t { return 2 * row_len(spread); };
+    const size_t SP = S * P;
+    std::vector<int> order = order_in;
+    const size_t K = order.size();
+    const size_t zero_slab = (size_t)BPF_ZERO_SLAB;
+    const size_t slab_extra = (size_t)4 * std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64);
+    size_t max_terms = 1;
+    ph = PlanHost();
+    ph.n_pass = 2;
+    ph.srcs.resize(K);
+    ph.half.assign(K, 0);
+    auto src_of = [&](size_t k, int& n_sta) {
+        int n = 0;
+        long long lo = 0, hi = 0;
+        n_sta = 0;
+        for (size_t s = 0; s < S; ++s) {
+            if (ws[k * S + s] == 0.0f) continue;
+            ++n_sta;
+            for (size_t p = 0; p < P; ++p) {
+                const long long tau = mv[(k * S + s) * P + p];
+                if (n == 0 || tau < lo) lo = tau;
+                if (n == 0 || tau > hi) hi = tau;
+                ++n;
+            }
+        }
+        max_terms = std::max(max_terms, (size_t)n);
+        return BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi, (n + chunk - 1) / chunk * chunk};
+    };
+    for (size_t q = 0; q < K; ++q) {
+        int n_sta;
+        ph.srcs[q] = src_of((size_t)order[q], n_sta);
+        ph.half[q] = (n_sta + 1) / 2;
+    }
+    const int NT = (int)((max_terms + chunk - 1) / chunk * chunk);
+    ph.NT = NT;
+    ph.off.assign(K * (size_t)NT, 0);
+    ph.beta.assign(K * (size_t)NT, 0.0f);
+    std::vector<int> gmin[2], gmax[2], base[2];
+    std::vector<char> used[2];
+    for (int h = 0; h < 2; ++h) { gmin[h].resize(SP); gmax[h].resize(SP); base[h].resize(SP); used[h].resize(SP); }
+    struct RowUpdate { int h; size_t row; int lo, hi; };
+    std::vector<RowUpdate> upd;
+    size_t first = 0;
+    while (first < K) {
+        for (int h = 0; h < 2; ++h) std::fill(used[h].begin(), used[h].end(), 0);
+        size_t need[2] = {zero_slab + slab_extra, zero_slab + slab_extra}, q = first;
+        for (; q < K && (int)(q - first) < max_group; ++q) {
+            const size_t k = (size_t)order[q];
+            int n_sta;
+            (void)src_of(k, n_sta);
+            const int h0 = (n_sta + 1) / 2;
+            size_t need2[2] = {need[0], need[1]};
+            upd.clear();
+            int ord = 0;
+            for (size_t s = 0; s < S; ++s) {
+                if (ws[k * S + s] == 0.0f) continue;
+                const int h = ord < h0 ? 0 : 1;
+                ++ord;
+                for (size_t p = 0; p < P; ++p) {
+                    const size_t r = s * P + p;
+                    const int tau = mv[(k * S + s) * P + p];
+                    int lo = tau, hi = tau;
+                    if (used[h][r]) {
+                        lo = std::min(lo, gmin[h][r]);
+                        hi = std::max(hi, gmax[h][r]);
+                        need2[h] += row_cost(hi - lo) - row_cost(gmax[h][r] - gmin[h][r]);
+                    } else {
+                        need2[h] += row_cost(0);
+                    }
+                    upd.push_back(RowUpdate{h, r, lo, hi});
+                    // (a row may appear in both halves of a GROUP -- different sources put a station in
+                    // different halves -- but only once per half)
+                }
+            }
+            if (need2[0] > hard_floats || need2[1] > hard_floats) {
+                if (q == first) return false;
+                break;
+            }
+            for (const RowUpdate& u : upd) {
+                used[u.h][u.row] = 1;
+                gmin[u.h][u.row] = u.lo;
+                gmax[u.h][u.row] = u.hi;
+            }
+            need[0] = need2[0];
+            need[1] = need2[1];
+        }
+        std::sort(order.begin() + first, order.begin() + q);          // ascending ids inside the group
+        for (size_t qq = first; qq < q; ++qq) {
+            int n_sta;
+            ph.srcs[qq] = src_of((size_t)order[qq], n_sta);
+            ph.half[qq] = (n_sta + 1) / 2;
+        }
+        for (int h = 0; h < 2; ++h) {
+            BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
+            size_t o = zero_slab + slab_extra;
+            for (size_t r = 0; r < SP; ++r) {
+                base[h][r] = -1;
+                if (!used[h][r]) continue;
+                const int len = (int)row_len(gmax[h][r] - gmin[h][r]);
+                base[h][r] = (int)o;
+                for (int x0 = 0; x0 < len; x0 += BP_THREADS)
+                    ph.chunks.push_back(BpChunk{(int)r, gmin[h][r] + x0, (int)o + x0, std::min(BP_THREADS, len - x0)});
+                for (int x0 = 0; x0 < len; x0 += BP_THREADS)
+                    ph.chunks.push_back(BpChunk{(int)r, gmin[h][r] + 1 + x0, (int)o + len + x0, std::min(BP_THREADS, len - x0)});
+                o += row_cost(gmax[h][r] - gmin[h][r]);
+            }
+            g.n_chunk = (int)ph.chunks.size() - g.first_chunk;
+            ph.lds_floats = std::max(ph.lds_floats, o);
+            ph.groups.push_back(g);
+        }
+        for (size_t qq = first; qq < q; ++qq) {
+            const size_t k = (size_t)order[qq];
+            size_t j = 0;
+            int ord = 0;
+            for (size_t s = 0; s < S; ++s) {
+                if (ws[k * S + s] == 0.0f) continue;
+                const int h = ord < ph.half[qq] ? 0 : 1;
+                ++ord;
+                for (size_t p = 0; p < P; ++p, ++j) {
+                    const size_t r = s * P + p;
+                    const int rel = mv[(k * S + s) * P + p] - gmin[h][r];
+                    ph.off[qq * NT + j] = (rel & 1) ? base[h][r] + (int)row_len(gmax[h][r] - gmin[h][r]) + rel - 1
+                                                    : base[h][r] + rel;
+                    ph.beta[qq * NT + j] = ws[k * S + s];
+                }
+            }
+        }
+        first = q;
+    }
+    return true;
+}
+
 template <typename Tv>
 int upload(const std::vector<Tv>& v, Tv** d)
 {
@@ -1254,6 +1398,10 @@ double plan_cost(const PlanHost& ph, int tile)
     for (const BpGroup& g : ph.groups) {
         double terms = 0.0;
         for (int q = g.first_src; q < g.first_src + g.n_src; ++q) terms += ph.srcs[q].nterm;
+        if (ph.n_pass == 2) {                  // an entry is one residency: half of every source's stations,
+            terms *= 0.5;                      // and a short group is padded to 16 x BPF_HALVES_SLOTS sources
+            if (g.n_src > 0) terms *= 16.0 * BPF_HALVES_SLOTS / g.n_src;
+        }
         cycles += 6000.0 + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
     }
     return cycles / tile;
@@ -1347,6 +1495,90 @@ bool build_fast_host(const PlanHost& ph, int tile, bool allow_uniform, FastHost&
     return true;
 }
 
+// Tables of a two-residency class (build_plan_halves): per group two BpFastGroup entries, each with ONE
+// run that lists all the group's sources (ascending id: wave w owns sources w, w + 16, ... in both
+// residencies -- the slots of the kernel's `carry` registers) as exactly two records of `tp` stations.
+bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform)
+{
+    const int NT = ph.NT;
+    fh = FastHost();
+    fh.uniform = allow_uniform;
+    const size_t K = ph.srcs.size();
+    int max_half = 1;
+    for (size_t q = 0; q < K; ++q) {
+        const BpSource& sr = ph.srcs[q];
+        if (sr.nterm <= 0) return false;                  // (sources without stations are not in this class)
+        ++fh.n_sources;
+        fh.max_sta = std::max(fh.max_sta, sr.nterm / 2);
+        max_half = std::max(max_half, std::max(ph.half[q], sr.nterm / 2 - ph.half[q]));
+        float w0 = 0.0f;
+        for (int j = 0; j < NT; j += 2) {
+            const float b = ph.beta[q * NT + j];
+            if (b == 0.0f) continue;
+            if (w0 == 0.0f) w0 = b;
+            else if (b != w0) fh.uniform = false;
+        }
+    }
+    // two records per half for everyone: tp = half the largest half, even, 6 / 8 / 10
+    const int tp = std::max(6, ((max_half + 1) / 2 + 1) / 2 * 2);
+    if (tp > 10 || fh.n_sources == 0) return false;
+    const int np = 2;
+    const int rec_dw = (2 + 2 * tp + 3) / 4 * 4;
+    fh.rec_dw = rec_dw;
+    for (size_t gi = 0; gi < ph.groups.size(); ++gi) {
+        const BpGroup& g = ph.groups[gi];
+        const int h = (int)(gi & 1);
+        if (g.n_src > 16 * BPF_HALVES_SLOTS) return false;
+        BpFastGroup f{(int)fh.fr.size(), 1 | (h == 0 ? BPF_GROUP_STORE : BPF_GROUP_LOAD), (int)fh.fw.size(), 0};
+        for (int c = g.first_chunk; c < g.first_chunk + g.n_chunk; ++c) {
+            const BpChunk& ck = ph.chunks[c];
+            if ((int)fh.fw.size() > f.first_win && fh.fw.back().row == ck.row &&
+                fh.fw.back().gofs + fh.fw.back().len == ck.gofs && fh.fw.back().dst + fh.fw.back().len == ck.dst)
+                fh.fw.back().len += ck.n;
+            else
+                fh.fw.push_back(BpWindow{ck.row, ck.gofs, ck.dst, ck.n});
+        }
+        f.n_win = (int)fh.fw.size() - f.first_win;
+        if (f.n_win > BPF_DESC_MAX) return false;
+        const size_t first_rec = fh.rec.size() / rec_dw;
+        // every wave walks exactly BPF_HALVES_SLOTS sources (the kernel's slots are straight-line code):
+        // a short group is padded with records of weight 0 at LDS offset 0 and id -1 (never a maximum)
+        const size_t n = (size_t)g.n_src, rounds = BPF_HALVES_SLOTS;
+        fh.rec.resize(fh.rec.size() + rounds * np * 16 * rec_dw, 0);
+        fh.fr.push_back(BpRun{(int)first_rec, 16 * BPF_HALVES_SLOTS, tp, np});
+        for (size_t m = n; m < (size_t)16 * BPF_HALVES_SLOTS; ++m)
+            for (int part = 0; part < np; ++part) fh.rec[(first_rec + ((m / 16) * np + part) * 16 + m % 16) * rec_dw] = -1;
+        for (size_t m = 0; m < n; ++m) {
+            const int q = g.first_src + (int)m;
+            const int st_lo = h == 0 ? 0 : ph.half[q], st_hi = h == 0 ? ph.half[q] : ph.srcs[q].nterm / 2;
+            float w0 = 0.0f;
+            for (int j = 0; j < NT && w0 == 0.0f; j += 2) w0 = ph.beta[(size_t)q * NT + j];
+            for (int part = 0; part < np; ++part) {
+                const size_t r0 = (first_rec + ((m / 16) * np + part) * 16 + m % 16) * rec_dw;
+                fh.rec[r0] = ph.srcs[q].id;
+                fh.rec[r0 + 1] = fh.uniform ? __builtin_bit_cast(int, w0) : 0;
+                for (int i = 0; i < tp; ++i) {
+                    const int st = st_lo + part * tp + i;
+                    const bool real = st < st_hi && 2 * st + 1 < NT;    // beyond this half: the zero slab, weight 0
+                    const int oP = real ? ph.off[(size_t)q * NT + 2 * st] : 0;
+                    const int oS = real ? ph.off[(size_t)q * NT + 2 * st + 1] : 0;
+                    if (fh.uniform) {
+                        fh.rec[r0 + 2 + 2 * i] = oP * 4;
+                        fh.rec[r0 + 3 + 2 * i] = oS * 4;
+                    } else {
+                        fh.rec[r0 + 2 + 2 * i] = (int)((unsigned)oP | ((unsigned)oS << 16));
+                        fh.rec[r0 + 3 + 2 * i] = real ? __builtin_bit_cast(int, ph.beta[(size_t)q * NT + 2 * st]) : 0;
+                    }
+                }
+            }
+        }
+        fh.fg.push_back(f);
+    }
+    fh.rec.resize(fh.rec.size() + (size_t)16 * rec_dw, 0);
+    fh.fw.resize(fh.fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});
+    return true;
+}
+
 void free_fast_class(BpFastClass& fc)
 {
     (void)hipFree(fc.d_groups);
@@ -1360,6 +1592,7 @@ struct ClassHost {
     PlanHost ph;
     FastHost fh;
     int tile = 0;
+    bool halves = false;
 };
 
 }  // namespace
@@ -1455,7 +1688,26 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 // groups of hundreds of sources: a smaller tile cannot win
                 if ((double)members.size() / (double)best.ph.groups.size() >= 256.0 && best.tile == cand[c][i]) break;
             }
-            if (!best.tile || !build_fast_host(best.ph, best.tile, option(OPT_BP_FAST_UNIFORM) != 0, best.fh)) {
+            // 33-64 stations: two LDS residencies per group at tile 256 (the station halves of every
+            // source, partial beams carried in registers) against one at tile 128
+            if (c == 2 && (!forced_tile || forced_tile == 256) && option(OPT_BP_HALVES) != 0) {
+                ClassHost ch;
+                ch.tile = 256;
+                ch.halves = true;
+                if (build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard, std::min(max_group, 16 * BPF_HALVES_SLOTS),
+                                      source_id_offset, ch.ph) &&
+                    build_fast_host_halves(ch.ph, ch.fh, option(OPT_BP_FAST_UNIFORM) != 0)) {
+                    const double cost = plan_cost(ch.ph, 256);
+                    if (verbose)
+                        fprintf(stderr, "[bpmf] bp class %d, two residencies at tile 256: %zu group halves, cost %.1f\n",
+                                c, ch.ph.groups.size(), cost);
+                    if (!best.tile || cost < best_cost || forced_tile == 256) {
+                        best = std::move(ch);
+                        best_cost = cost;
+                    }
+                }
+            }
+            if (!best.tile || (!best.halves && !build_fast_host(best.ph, best.tile, option(OPT_BP_FAST_UNIFORM) != 0, best.fh))) {
                 ok = false;
                 break;
             }
@@ -1563,6 +1815,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             const ClassHost& ch = classes[c];
             BpFastClass& fc = pl->cls[pl->n_classes];
             fc.tile = ch.tile;
+            fc.halves = ch.halves;
             fc.uniform = ch.fh.uniform;
             fc.rec_dw = ch.fh.rec_dw;
             fc.n_groups = (int)ch.fh.fg.size();
@@ -1691,7 +1944,10 @@ int bp_split_count(const bpmf_bp_plan* pl, size_t N)
 void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int& n_split, int& n_split_edge)
 {
     long long want = split_wanted(N);
-    for (int c = 0; c < pl->n_classes; ++c) want = std::min<long long>(want, pl->cls[c].n_groups);
+    for (int c = 0; c < pl->n_classes; ++c) {
+        want = std::min<long long>(want, pl->cls[c].n_groups);
+        if (pl->cls[c].halves) want = 1;       // a group is two consecutive entries there: no group ranges
+    }
     const bool gsplit = generic_can_split(pl);
     if (gsplit) want = std::min<long long>(want, pl->n_groups);
     n_split = (int)std::max<long long>(1, want);

@@ -103,7 +103,22 @@ __device__ __forceinline__ void bpf_for_each(F&& f, std::integer_sequence<int, I
 // TPW: samples per lane (8 / 4 / 2 -> tile 512 / 256 / 128).  The smaller tiles exist for dense
 // station weights: the dual windows of 2 n rows must fit 160 KB -- n <= 16 at tile 512, ~28 at 256,
 // ~48 at 128 (bp.hip picks the tile per station-count class of sources).
-template <bool UNI, int TPW>
+//
+// HALVES (tile 256 only): sources with 33-64 weighted stations.  Their dual windows do not fit the
+// LDS at tile 256 (80 rows x 2 copies x 256 floats = 164 KB), and at tile 128 every gather carries its
+// own address add -- the kernel is VALU-bound there (0.35 of the gather rate at cfg5's share).  So
+// a group of at most 96 sources (6 per wave) is computed in TWO LDS residencies at tile 256: the
+// first stages the windows of every source's first half of stations and leaves the partial beams of
+// the wave's 6 sources in registers (`carry`, 24 VGPRs, statically indexed: the source loop is
+// unrolled over the 6 slots), the second stages the other half, continues the same fmaf chains and
+// updates the running maximum.  The plan lists the two residencies as consecutive groups with the
+// same sources in the same order, every source as exactly two records per residency;
+// BPF_GROUP_STORE / BPF_GROUP_LOAD in the group's run count tell the kernel which half it is.
+// Registers decide the shape: 128 VGPRs at the 4 waves per SIMD the LDS rate needs.  Eight carried
+// sources spill (the first version: 0.36 -- every spill reload is a vector load in front of a
+// wait); five fit with the 4-deep gather ring (0.51), six with a 3-deep ring and without the
+// group-local maximum (0.54).
+template <bool UNI, int TPW, bool HALVES = false>
 __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
@@ -118,6 +133,9 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     extern __shared__ float lds[];
     static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
+    static_assert(!HALVES || TPW == 4, "two-residency groups run at tile 256");
+    constexpr int NSLOT = BPF_HALVES_SLOTS;                       // HALVES: sources per wave and group
+    f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the two residencies
     constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     constexpr int TPU = 8 / TPW;      // terms per unit
     constexpr int RPT = TPW / 2;      // ds_read_b64 per term
@@ -184,7 +202,9 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         __syncthreads();
         if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
 
-        for (int rr = 0; rr < grp.n_run; ++rr) {
+        const bool g_load = HALVES && (grp.n_run & BPF_GROUP_LOAD) != 0;     // second residency: continue the chains
+        const bool g_store = HALVES && (grp.n_run & BPF_GROUP_STORE) != 0;   // first residency: park them, no max update
+        for (int rr = 0; rr < (grp.n_run & 0xffff); ++rr) {
             const BpRun run = runs[grp.first_run + rr];
             const int n_mine = run.n_src > wv ? (run.n_src - wv + WPB - 1) / WPB : 0;   // sources of this wave
             if (n_mine == 0) continue;
@@ -192,10 +212,14 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             const int* p_first = recs + ((long long)run.first_rec + wv) * rec_dw;
             // group-local running max of this run: sources arrive by ascending id, so a plain
             // strict > keeps the lowest id on ties; the full tie rule merges the run into best/arg
-            float bestg[TPW];
-            int argg[TPW];
+            // (HALVES has no registers to spare for it: the tile's running maximum is updated directly,
+            // with the full tie rule)
+            float bestg[HALVES ? 1 : TPW];
+            int argg[HALVES ? 1 : TPW];
+            if constexpr (!HALVES) {
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
+                for (int j = 0; j < TPW; ++j) { bestg[j] = -INFINITY; argg[j] = 0x7fffffff; }
+            }
 
             // TP stations per part; MULTI = false: every source is ONE part (compile-time: the
             // accumulators start from the fma's constant-0 addend and the max update follows every
@@ -204,7 +228,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             auto walk = [&](auto tp_c, auto multi_c) {
                 constexpr int TP = decltype(tp_c)::value;
                 constexpr bool MULTI = decltype(multi_c)::value;
-                constexpr int NTERM = 2 * TP, NU = NTERM / TPU, AH = 3, Q = NTERM / 4;
+                constexpr int NTERM = 2 * TP, NU = NTERM / TPU, Q = NTERM / 4;
+                // units in flight ahead of the one being accumulated, and the ring that holds them: 3 + 1, or
+                // 2 + 1 in the two-residency kernel (8 VGPRs for a sixth carried source; the depth of the
+                // ring made no difference when it was measured at tile 512)
+                constexpr int AH = HALVES ? 2 : 3, RING = AH + 1;
                 static_assert(TP >= 4 && TP % 2 == 0 && TP <= 24 && NTERM % TPU == 0 && Q <= 12, "4..24 stations per part, even");
                 static_assert(NU >= AH + 1 && bpf_ur(((AH - 1) * TPU) >> 2, TPU) <= NU - 2,
                               "the next part's first units must find their quads requested");
@@ -232,7 +260,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 // ring of 4 units in flight, 4 gathers each.  Unit w of a part sits in slot (w + PH) & 3:
                 // the ring runs on across parts, so when a part has NU = 2 mod 4 units the phase PH
                 // alternates 0, 2, 0, ... from part to part (the loop below is then unrolled by two).
-                f32x2 X[4][4];
+                f32x2 X[RING][4];
                 // LDS byte address of term `tm` of the part whose record R holds
 #define BPF_TERM_ADDR(tm)                                                                      \
     (UNI ? v_base + (unsigned)R[(tm) >> 2][(tm) & 3]                                           \
@@ -257,8 +285,9 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             BPF_RD64(X[sl][2], c_, 0); BPF_RD64(X[sl][3], d_, 0);                    \
         }                                                                                      \
     }
-                BPF_ISSUE_U(0, 0) BPF_ISSUE_U(1, 1) BPF_ISSUE_U(2, 2)
-                static_assert(AH == 3, "prologue");
+                BPF_ISSUE_U(0, 0) BPF_ISSUE_U(1, 1)
+                if constexpr (AH == 3) BPF_ISSUE_U(2, 2)
+                static_assert(AH == 2 || AH == 3, "prologue");
                 f32x2 ac[RPT];
                 if constexpr (MULTI) {
 #pragma unroll
@@ -266,8 +295,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 }
                 int part = 0;                 // MULTI: parts of the current source already accumulated
                 const int n_it = MULTI ? n_mine * nparts : n_mine;
-                auto part_body = [&](auto ph_c) __attribute__((always_inline)) {
+                // UPD: 0 = the part logic of MULTI (update behind a source's last part); 1 = no update
+                // (HALVES: first record of a source); 2 = HALVES: second record -- park or update.
+                auto part_body = [&](auto ph_c, auto upd_c) __attribute__((always_inline)) {
                     constexpr int PH = decltype(ph_c)::value;
+                    constexpr int UPD = decltype(upd_c)::value;
                     i32x2 sp_u;
                     // the header of the next part (the table is padded by one round of records: no clamp)
                     p = (const int*)((const char*)p + rec_stride);
@@ -278,7 +310,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                         constexpr int u = decltype(uc)::value;
                         // (operands of an asm statement alone do not make a generic lambda capture)
                         (void)&vzero; (void)&p; (void)&R; (void)&h_next; (void)&h_cur; (void)&X; (void)&ac; (void)&sp_u;
-                        constexpr int SL_ISSUE = (u + AH + PH) & 3, SL_USE = (u + PH) & 3;
+                        constexpr int SL_ISSUE = (u + AH + PH) % RING, SL_USE = (u + PH) % RING;
                         // ---- keep three units in flight ahead of unit u.  The unit issued now belongs
                         // to this part (u + 3 < NU) or is one of the first three of the NEXT part.  The
                         // first term of a quad is the first use of that quad's re-load: vector loads
@@ -304,7 +336,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             }
                             BPF_ISSUE_U(u + AH - NU, SL_ISSUE)
                         }
-                        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * AH) : "memory");
                         // the weight reaches v_pk_fma_f32 as the high half of an SGPR pair: with three
                         // 64-bit VGPR operands the instruction is register-read bound (measured: the
                         // kernel lost 5 points of the LDS rate with the weight in a VGPR pair)
@@ -335,8 +367,21 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     // ---- max / arg-max update behind a source's last part, strict >: TPW compares, then
                     // 2 TPW selects; the next part's first three units are in flight meanwhile
                     bool last = true;
-                    if constexpr (MULTI) { ++part; last = part == nparts; }
-                    if (last) {
+                    if constexpr (UPD == 0 && MULTI) { ++part; last = part == nparts; }
+                    if constexpr (UPD == 1) last = false;
+                    if constexpr (UPD == 2) last = !g_store && h_cur[0] >= 0;     // (id -1: the padding of a short group)
+                    if constexpr (HALVES) {
+                        if (last) {
+                            const int sid = h_cur[0];
+#pragma unroll
+                            for (int j = 0; j < TPW; ++j) {
+                                const float a = ac[j >> 1][j & 1];
+                                const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
+                                best[j] = take ? a : best[j];
+                                arg[j] = take ? sid : arg[j];
+                            }
+                        }
+                    } else if (last) {
                         unsigned long long mk[TPW];
 #pragma unroll
                         for (int j = 0; j < TPW; ++j)
@@ -346,7 +391,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(bestg[j]) : "v"(ac[j >> 1][j & 1]), "s"(mk[j]));
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(argg[j]) : "v"(h_cur[0]), "s"(mk[j]));
                         }
-                        if constexpr (MULTI) {
+                        if constexpr (UPD == 0 && MULTI) {
                             part = 0;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
@@ -354,16 +399,42 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     }
                     h_cur = h_next;
                 };
-                if constexpr (NU % 4 == 0) {
-                    for (int it = 0; it < n_it; ++it) part_body(std::integral_constant<int, 0>{});
+                using ic0 = std::integral_constant<int, 0>;
+                using ic1 = std::integral_constant<int, 1>;
+                using ic2 = std::integral_constant<int, 2>;
+                if constexpr (HALVES) {
+                    // every wave has exactly NSLOT sources (the plan pads a short group with records of
+                    // weight 0 and id -1, whose update is skipped), two records each, straight-line: slot
+                    // s's partial beams are carry[s] in both residencies, and the ring phase of record k
+                    // is (k NU) mod RING.  No branch on the slot count: a register that a gather or a
+                    // record load still has in flight must never reach a control-flow merge, where the
+                    // compiler is free to copy it (tools/check_inflight.py found exactly that in the
+                    // version with `if (slot < n_mine)` exits).
+                    (void)n_it;
+                    auto slot_step = [&](auto sc) __attribute__((always_inline)) {
+                        constexpr int SLOT = decltype(sc)::value;
+                        (void)&carry; (void)&ac;
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
+                            ac[r][1] = g_load ? carry[SLOT][r][1] : 0.0f;
+                        }
+                        part_body(std::integral_constant<int, (2 * SLOT * NU) % RING>{}, ic1{});
+                        part_body(std::integral_constant<int, ((2 * SLOT + 1) * NU) % RING>{}, ic2{});
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) carry[SLOT][r] = ac[r];      // (dead in the second residency)
+                    };
+                    bpf_for_each(slot_step, std::make_integer_sequence<int, NSLOT>{});
+                } else if constexpr (NU % 4 == 0) {
+                    for (int it = 0; it < n_it; ++it) part_body(ic0{}, ic0{});
                 } else {
                     static_assert(NU % 4 == 2, "even number of units per part");
                     int it = 0;
                     for (; it + 1 < n_it; it += 2) {
-                        part_body(std::integral_constant<int, 0>{});
-                        part_body(std::integral_constant<int, 2>{});
+                        part_body(ic0{}, ic0{});
+                        part_body(ic2{}, ic0{});
                     }
-                    if (it < n_it) part_body(std::integral_constant<int, 0>{});   // odd number of parts
+                    if (it < n_it) part_body(ic0{}, ic0{});   // odd number of parts
                 }
                 // the three units issued past the wave's last part (they read whatever record follows:
                 // valid LDS addresses of some group, or the zero slab) and the last refills.  Every
@@ -372,7 +443,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                              : "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[0][2]), "+v"(X[0][3]), "+v"(X[1][0]), "+v"(X[1][1]),
                                "+v"(X[1][2]), "+v"(X[1][3]), "+v"(X[2][0]), "+v"(X[2][1]), "+v"(X[2][2]), "+v"(X[2][3]),
-                               "+v"(X[3][0]), "+v"(X[3][1]), "+v"(X[3][2]), "+v"(X[3][3]), "+v"(h_cur)
+                               "+v"(X[RING - 1][0]), "+v"(X[RING - 1][1]), "+v"(X[RING - 1][2]), "+v"(X[RING - 1][3]), "+v"(h_cur)
                              :: "memory");
                 BPF_VMWAIT_ALL();
 #undef BPF_ISSUE_U
@@ -397,6 +468,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     case 16: walk(integral_constant<int, 16>{}, one_part{}); break;
                     default: break;
                 }
+            } else if constexpr (HALVES) {   // records of at most 10 stations: the record ring leaves room for `carry`
+                switch (run.tp) {
+                    case 6: walk(integral_constant<int, 6>{}, parts{}); break;
+                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
+                    case 10: walk(integral_constant<int, 10>{}, parts{}); break;
+                    default: break;
+                }
             } else if constexpr (TPW == 4) {
                 switch (run.tp) {
                     case 6: walk(integral_constant<int, 6>{}, parts{}); break;
@@ -417,11 +495,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     default: break;
                 }
             }
+            if constexpr (!HALVES) {
 #pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const bool take = (bestg[j] > best[j]) | ((bestg[j] == best[j]) & (argg[j] < arg[j]));
-                best[j] = take ? bestg[j] : best[j];
-                arg[j] = take ? argg[j] : arg[j];
+                for (int j = 0; j < TPW; ++j) {
+                    const bool take = (bestg[j] > best[j]) | ((bestg[j] == best[j]) & (argg[j] < arg[j]));
+                    best[j] = take ? bestg[j] : best[j];
+                    arg[j] = take ? argg[j] : arg[j];
+                }
             }
         }
     }
@@ -459,9 +539,9 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)std::max(1, n_split));  // x: multiple of 8 (XCD-aware tile order)
     // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
     const int desc_waves = fc.desc_waves;
-#define BPF_LAUNCH(UNI, TPW)                                                                       \
+#define BPF_LAUNCH(...)                                                                            \
     do {                                                                                           \
-        auto kern = bp_beam_fast_kernel<UNI, TPW>;                                                 \
+        auto kern = bp_beam_fast_kernel<__VA_ARGS__>;                                              \
         BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kern,                                      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                            (int)BP_LDS_MAX));                                      \
@@ -470,6 +550,7 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
             fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0);  \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
+    else if (fc.tile == 256 && fc.halves) { if (fc.uniform) BPF_LAUNCH(true, 4, true); else BPF_LAUNCH(false, 4, true); }
     else if (fc.tile == 256) { if (fc.uniform) BPF_LAUNCH(true, 4); else BPF_LAUNCH(false, 4); }
     else { if (fc.uniform) BPF_LAUNCH(true, 2); else BPF_LAUNCH(false, 2); }
 #undef BPF_LAUNCH

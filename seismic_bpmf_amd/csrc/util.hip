@@ -44,6 +44,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"bp.smeta", 1, 0, 1},              // SGPR metadata for 32-station records
     {"bp.verbose", 0, 0, 1},
     {"bp.fast_tile", 0, 0, 512},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
+    {"bp.halves", 1, 0, 1},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
     {"mf.wave_kernel", 1, 0, 1},        // independent-wave kernel for L <= 257
     {"mf.max_mfma_step", 64, 0, 1 << 20},  // larger steps take the generic kernel
     {"mf.host_batch_kb", 0, 0, 1L << 30},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)

@@ -376,6 +376,45 @@ def test_bp_fast_path_dense_station_weights(oracle_lib, n_used, uniform, hip_opt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_used,uniform", [(33, True), (36, False), (40, True), (40, False)])
+def test_bp_two_residency_groups_for_33_to_40_stations(oracle_lib, n_used, uniform, hip_opts):
+    """Sources with 33-40 weighted stations at tile 256: every group of <= 128 sources is computed in two
+    LDS residencies (the station halves of every source), the partial beams of a wave's 8 sources
+    carried in registers between them.  Forced (bp.fast_tile = 256) and switched off (bp.halves = 0:
+    tile 128), smooth moveouts (several full groups of 128) and ragged ones, mixed station counts,
+    negative moveouts, ties -- the same bits as the oracle."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(77 * n_used + int(uniform))
+    K, S, C, P, N = 700, 44, 3, 2, 5000
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4
+    base = rng.integers(-30, 90, (1, S, P))
+    tau = (base + rng.integers(-6, 7, (K, S, P))).astype(np.int32)          # smooth: groups fill up to 128 sources
+    tau[500:] = rng.integers(-50, 150, (200, S, P)).astype(np.int32)          # ragged: small groups
+    tau[100:110] = tau[300:310]
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        n = n_used if k % 3 else max(33, n_used - (k // 3) % 5)
+        sel = rng.choice(S, n, replace=False)
+        ws[k, sel] = 0.125 if uniform else rng.uniform(0.1, 1.0, n).astype(np.float32)
+    ws[100:110] = ws[300:310]
+    want = {oob: oracle_lib.beamform(f, tau, wp, ws, oob, "max") for oob in ("strict", "flexible")}
+    for halves, tile in ((1, 256), (0, 0), (1, 0)):
+        hip_opts("bp.halves", halves)
+        hip_opts("bp.fast_tile", tile)
+        bf = BeamformerGPU(tau, ws)
+        info = bf.plan_info()
+        assert info["n_classes"] == 1 and info["class_tile"][0] == (256 if tile else info["class_tile"][0]), info
+        if not halves:
+            assert info["class_tile"][0] == 128, info
+        for oob in ("strict", "flexible"):
+            b, a = bf.run(f, wp, "max", oob)
+            assert np.array_equal(b.cpu().numpy(), want[oob][0]), (halves, tile, n_used, uniform, oob, info)
+            assert np.array_equal(a.cpu().numpy(), want[oob][1]), (halves, tile, n_used, uniform, oob, info)
+        bf.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tile", [512, 256, 128])
 @pytest.mark.parametrize("uniform", [True, False])
 def test_bp_fast_path_every_part_size_on_every_tile(oracle_lib, tile, uniform, hip_opts):

@@ -116,11 +116,15 @@ def test_fast_beam_kernels_touch_no_register_in_flight(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     kernels = check_inflight.split_kernels(out.read_text())
     names = [n for n in kernels if "bp_beam_fast_kernel" in n]
-    assert len(names) == 6
+    assert len(names) == 8
     for n in names:
         body = kernels[n]
         assert sum(t.startswith("ds_read_b64") for t in body) > 100       # the unrolled gathers are there
-        assert not any("scratch_" in t for t in body)                      # no spills
+        # no spills -- except in the two-residency kernels (..., 4, true>), where the compiler keeps part
+        # of the carried partial beams in scratch: a reload per source at the boundary of its records,
+        # none between the gathers (the checker counts those loads in the in-order vector-memory queue)
+        if "ELi4ELb1E" not in n:
+            assert not any("scratch_" in t for t in body)
         bad = check_inflight.check_kernel(body)
         assert not bad, f"{n}: {bad[:4]}"
 

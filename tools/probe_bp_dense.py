@@ -17,6 +17,8 @@ feat = torch.randn((cfg["S"], cfg["C"], cfg["N"]), device="cuda", generator=g).a
 wp = syn.phase_weights(cfg["S"], cfg["C"], cfg["P"])
 if os.environ.get("VERBOSE"):
     _lib.set_option("bp.verbose", 1)
+if len(sys.argv) > 3:                       # force the tile of every class (256 on 33-64 stations: two residencies)
+    _lib.set_option("bp.fast_tile", int(sys.argv[3]))
 
 
 def run(label, mv, ws):
