@@ -11,6 +11,8 @@
 // This is the one HBM-bound stage of the workflow (reads the CC matrix four times).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 #include "../../include/bpmf_hip.h"
 
 namespace bpmf {
@@ -19,6 +21,9 @@ constexpr int GAUSSIAN_LEN = 500;
 
 // dword-aligned 16-byte load: rows and windows start at arbitrary sample offsets
 typedef float f32x4a __attribute__((ext_vector_type(4), aligned(4)));
+// the same in the GLOBAL address space: a pointer that went through __shfl is generic, and a FLAT load
+// counts in lgkmcnt too -- every wait for the LDS tile would drain the whole load pipeline
+typedef const __attribute__((address_space(1))) f32x4a* tdt_gptr;
 typedef float f32x4v __attribute__((ext_vector_type(4)));   // 16-byte aligned (LDS tile)
 
 // Stream one window per LANE through f(value, index) in strictly ascending order.  The adds of a
@@ -29,49 +34,101 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));   // 16-byte aligned (
 // of the load pipeline).  Now the wave reads every line ONCE: load k of a step has lanes 8j .. 8j+7
 // fetch the eight 16-byte pieces of the line of window 8k + j -- 8 lines per instruction instead
 // of 64 -- and a transposition through a 9 KB LDS tile hands each lane its own 32 samples.  The
-// next step's loads are in flight while the current 32 samples are accumulated.
+// loads of the next TDT_DEPTH steps are in flight while the current 32 samples are accumulated.
+// Round 3, measured on cfg2's CC matrix (500 x 8.64 M): with the chain removed a pass streams at
+// 5.2 TB/s (3.35 ms per 17.3 GB) -- what HBM gives 24 000 concurrent 128-byte streams; the passes
+// now run at 3.8-4.4 ms (glob) and 8.3 ms for the window kernel's 2 x 1.31 passes (5.4 TB/s).
 // Call with all 64 lanes of a one-wave workgroup (`p` of an idle lane: any readable window).
-constexpr int TDT_STEP = 32;                 // samples per lane and step = one 128-byte line
+#ifndef TDT_STEP_V
+#define TDT_STEP_V 32
+#endif
+constexpr int TDT_STEP = TDT_STEP_V;          // samples per lane and step: 32 = one 128-byte line
+constexpr int TDT_NL = TDT_STEP / 4;         // 16-byte pieces per window and step = load instructions per step
+constexpr int TDT_WPL = 64 / TDT_NL;         // windows served by one load instruction
 constexpr int TDT_ROW = TDT_STEP + 4;        // tile row stride in floats (16-byte aligned, spreads the banks)
-template <typename F>
-__device__ __forceinline__ void tdt_stream(const float* __restrict__ p, size_t window, float* tile, F f)
+#ifndef TDT_DEPTH_V
+#define TDT_DEPTH_V 6
+#endif
+constexpr int TDT_DEPTH = TDT_DEPTH_V;       // steps of loads in flight
+template <typename F, int... I>
+__device__ __forceinline__ void tdt_unroll(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(value, index): every sample.  g(value, index): used instead of f for the 32 samples of a step in
+// which this lane holds an exact zero (the window kernel's replacement path: kept out of the hot loop).
+template <typename F, typename G>
+__device__ __forceinline__ void tdt_stream2(const float* __restrict__ p, size_t window, float* tile, F f, G g)
 {
     const int lane = threadIdx.x & 63;
-    const int piece = lane & 7, sub = lane >> 3;
+    const int piece = lane % TDT_NL, sub = lane / TDT_NL;
     const size_t nstep = window / TDT_STEP;
-    // the windows whose pieces this lane fetches: 8k + sub, k = 0 .. 7
-    const float* src[8];
+    // the windows whose pieces this lane fetches: TDT_WPL k + sub, k = 0 .. TDT_NL - 1
+    tdt_gptr src[TDT_NL];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const unsigned long long q = __shfl((unsigned long long)(size_t)p, 8 * k + sub, 64);
-        src[k] = (const float*)(size_t)q + 4 * piece;
+    for (int k = 0; k < TDT_NL; ++k) {
+        const unsigned long long q = __shfl((unsigned long long)(size_t)p, TDT_WPL * k + sub, 64);
+        src[k] = (tdt_gptr)((const float*)(size_t)q + 4 * piece);
     }
-    f32x4a reg[8];
-    if (nstep) {
+    // TDT_DEPTH steps of loads in flight per wave (the stage has only ~2 waves per CU)
+    f32x4a reg[TDT_DEPTH][TDT_NL];
+    // Every load below is UNCONDITIONAL (past the last step the index is clamped: the last step is
+    // read again and dropped).  With the loads under `if (b + DEPTH < nstep)` the compiler's wait
+    // insertion lost count at the merge and waited for vmcnt(7..0) in front of the first tile write of
+    // every round -- that is, for the loads of the steps AHEAD as well: the depth bought nothing.
+    const size_t last = nstep ? nstep - 1 : 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) reg[k] = *(const f32x4a*)(src[k]);
+    for (int d = 0; d < TDT_DEPTH && nstep; ++d) {
+        const size_t at = (size_t)d < last ? (size_t)d : last;
+#pragma unroll
+        for (int k = 0; k < TDT_NL; ++k) reg[d][k] = src[k][at * TDT_NL];
     }
-    for (size_t b = 0; b < nstep; ++b) {
+    auto step = [&](size_t b, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;
         // (LDS operations of one wave execute in order: the reads of the previous step are done)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) *(f32x4v*)(tile + (8 * k + sub) * TDT_ROW + 4 * piece) = (f32x4v)reg[k];
-        if (b + 1 < nstep) {
+        for (int k = 0; k < TDT_NL; ++k) *(f32x4v*)(tile + (TDT_WPL * k + sub) * TDT_ROW + 4 * piece) = (f32x4v)reg[SL][k];
+        {
+            const size_t at = b + TDT_DEPTH < last ? b + TDT_DEPTH : last;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) reg[k] = *(const f32x4a*)(src[k] + (b + 1) * TDT_STEP);
+            for (int k = 0; k < TDT_NL; ++k) reg[SL][k] = src[k][at * TDT_NL];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4v mine[8];
+        f32x4v mine[TDT_NL];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mine[i] = *(const f32x4v*)(tile + lane * TDT_ROW + 4 * i);
+        for (int i = 0; i < TDT_NL; ++i) mine[i] = *(const f32x4v*)(tile + lane * TDT_ROW + 4 * i);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        float lo = INFINITY;                      // independent of the chain: fills its latency
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < TDT_NL; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f(mine[i][e], b * TDT_STEP + 4 * i + e);
-    }
-    for (size_t j = nstep * TDT_STEP; j < window; ++j) f(p[j], j);
+            for (int e = 0; e < 4; ++e) lo = fminf(lo, fabsf(mine[i][e]));
+        if (__builtin_expect(lo == 0.0f, 0)) {
+#pragma unroll 1
+            for (int i = 0; i < TDT_NL; ++i)
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) g(mine[i][e], b * TDT_STEP + 4 * i + e);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TDT_NL; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f(mine[i][e], b * TDT_STEP + 4 * i + e);
+        }
+    };
+    size_t b = 0;
+    for (; b + TDT_DEPTH <= nstep; b += TDT_DEPTH)
+        tdt_unroll(std::make_integer_sequence<int, TDT_DEPTH>{}, [&](auto sc) __attribute__((always_inline)) { step(b + decltype(sc)::value, sc); });
+    tdt_unroll(std::make_integer_sequence<int, TDT_DEPTH - 1>{}, [&](auto sc) __attribute__((always_inline)) {
+        if (b < nstep) { step(b, sc); ++b; }
+    });
+    for (size_t j = nstep * TDT_STEP; j < window; ++j) g(p[j], j);
+}
+template <typename F>
+__device__ __forceinline__ void tdt_stream(const float* __restrict__ p, size_t window, float* tile, F f)
+{
+    tdt_stream2(p, window, tile, f, f);
 }
 
 // (1) per (row, global window): sum and count of the non-zero samples.       libc.c:553-571
@@ -85,9 +142,12 @@ __global__ __launch_bounds__(64) void tdt_glob_sum_kernel(const float* __restric
     size_t row = live ? idx / n_glob : 0, q = live ? idx % n_glob : 0;
     const float* p = x + row * n + q * window;
     float acc = 0.0f;
-    unsigned long long c = 0;
-    tdt_stream(p, window, tile, [&](float v, size_t) {  // strictly sequential adds
-        if (v != 0.0f) { acc += v; ++c; }
+    unsigned c = 0;                               // (window < 2^31: tdt_sizes)
+    // strictly sequential adds.  Adding an exact zero leaves a float sum that started at +0 unchanged,
+    // sign included (x + -0 = x, +0 + -0 = +0), so only the count needs the test.
+    tdt_stream(p, window, tile, [&](float v, size_t) {
+        acc += v;
+        c += v != 0.0f ? 1u : 0u;
     });
     if (!live) return;
     part[idx] = acc;
@@ -162,17 +222,23 @@ __global__ __launch_bounds__(64) void tdt_window_kernel(const float* __restrict_
     const float c = centre[row], dv = dev[row];
     float acc = 0.0f;
     unsigned g0 = (unsigned)(i0 % GAUSSIAN_LEN);  // gauss index of sample j: (g0 + j) mod 500
-    tdt_stream(p, window, tile, [&](float v, size_t j) {
-        if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
-        acc += v;
-    });
+    tdt_stream2(p, window, tile, [&](float v, size_t) { acc += v; },
+                [&](float v, size_t j) {
+                    if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
+                    acc += v;
+                });
     const float mean = acc / (float)window;
     float ss = 0.0f;
-    tdt_stream(p, window, tile, [&](float v, size_t j) {
-        if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
-        double d = (double)(v - mean);
-        ss = (float)((double)ss + d * d);
-    });
+    tdt_stream2(p, window, tile,
+                [&](float v, size_t) {
+                    double d = (double)(v - mean);
+                    ss = (float)((double)ss + d * d);
+                },
+                [&](float v, size_t j) {
+                    if (v == 0.0f) v = __fadd_rn(c, __fmul_rn(gauss[(g0 + j) % GAUSSIAN_LEN], dv));
+                    double d = (double)(v - mean);
+                    ss = (float)((double)ss + d * d);
+                });
     if (live) thr_win[idx] = __fadd_rn(mean, __fmul_rn(num_dev, sqrtf(ss / (float)window)));
 }
 
@@ -293,7 +359,7 @@ static int tdt_sizes(size_t n, size_t half_window, size_t shift, size_t* window,
     *window = 2 * half_window;
     // (shift == window + 1: an odd sliding window with overlap 0 -- the reference's size_t
     // arithmetic wraps to (n + 1) / shift windows, all inside the series: libc.c:528)
-    if (*window == 0 || shift == 0 || shift > *window + 1 || n < *window) return -1;
+    if (*window == 0 || *window > 0x7fffffffull || shift == 0 || shift > *window + 1 || n < *window) return -1;
     *n_win = (n - (*window - shift)) / shift;
     *n_glob = n / *window;
     return *n_win >= 1 ? 0 : -1;
