@@ -1739,20 +1739,57 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 tpt = cnd;
         }
     }
-    if (!tpt) {
-        set_error("bpmf_bp_plan_create: one source's %zu station-phase windows do not fit in LDS",
-                  S * P);
-        return -1;
-    }
     PlanHost& ph = share ? classes[0].ph : ph_own;
-    if (ph.NT > 256) {
-        set_error("bpmf_bp_plan_create: %d station-phase terms per source (max 256)", ph.NT);
-        return -1;
-    }
     BPMF_BIND_DEVICE(device);
     bpmf_bp_plan* pl = new bpmf_bp_plan();
     pl->device = device;
     pl->K = K; pl->S = S; pl->P = P;
+    if (!tpt || ph.NT > 256 || option(OPT_BP_DIRECT) != 0) {
+        // No LDS plan: one source's station-phase windows do not fit at the smallest tile, or a source has
+        // more than 256 (station, phase) terms (or option bp.direct asks for it: the tests).  The grid runs
+        // bp_direct.hip on compact term lists in the oracle's order.
+        std::vector<int4> hdr(K);
+        std::vector<long long> first(K + 1, 0);
+        std::vector<int4> terms;
+        for (size_t k = 0; k < K; ++k) {
+            int lo = 0, hi = 0, any = 0;
+            first[k] = (long long)terms.size();
+            for (size_t s = 0; s < S; ++s) {
+                const float b = w_sources[k * S + s];
+                if (b == 0.0f) continue;
+                for (size_t p = 0; p < P; ++p) {
+                    const int tau = moveouts[(k * S + s) * P + p];
+                    if (!any || tau < lo) lo = tau;
+                    if (!any || tau > hi) hi = tau;
+                    any = 1;
+                    terms.push_back(make_int4((int)(s * P + p), tau, __builtin_bit_cast(int, b), 0));
+                }
+            }
+            hdr[k] = make_int4(any, lo, hi, 0);
+        }
+        first[K] = (long long)terms.size();
+        if (terms.empty()) terms.push_back(make_int4(0, 0, 0, 0));
+        pl->direct = true;
+        pl->tpt = 4;
+        pl->NT = (int)std::min<size_t>(SP, 0x7fffffff);
+        pl->n_groups = 0;
+        pl->id_offset = source_id_offset;
+        pl->tmin_all = tmin_all;
+        pl->tmax_all = tmax_all;
+        pl->wps = 0;
+        if (verbose)
+            fprintf(stderr, "[bpmf] bp plan: K=%zu, no LDS plan (%s): global-memory gathers over %zu terms\n", K,
+                    !tpt ? "windows exceed the LDS" : (ph.NT > 256 ? "> 256 terms per source" : "bp.direct"),
+                    terms.size());
+        int rcd = 0;
+        if ((rcd = upload(hdr, &pl->d_dhdr)) || (rcd = upload(first, &pl->d_dfirst)) ||
+            (rcd = upload(terms, &pl->d_dterms))) {
+            bpmf_bp_plan_destroy(pl);
+            return rcd;
+        }
+        *plan_out = pl;
+        return 0;
+    }
     pl->tpt = tpt;
     pl->chunk = chunk;
     pl->NT = ph.NT;
@@ -1857,6 +1894,9 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
 extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
 {
     if (!pl) return;
+    (void)hipFree(pl->d_dhdr);
+    (void)hipFree(pl->d_dfirst);
+    (void)hipFree(pl->d_dterms);
     (void)hipFree(pl->d_groups);
     (void)hipFree(pl->d_chunks);
     (void)hipFree(pl->d_srcs);
@@ -1877,6 +1917,13 @@ extern "C" int bpmf_bp_plan_info(const bpmf_bp_plan* pl, bpmf_bp_plan_stats* out
     if (!pl || !out) {
         set_error("bpmf_bp_plan_info: bad argument");
         return -1;
+    }
+    if (pl->direct) {               // no LDS plan: global-memory gathers (bp_direct.hip)
+        memset(out, 0, sizeof(*out));
+        out->tile = 1024;
+        out->gather_bytes = 4;
+        out->waves_per_cu = 8;
+        return 0;
     }
     out->n_groups = pl->n_groups;
     out->tile = BP_THREADS * pl->tpt;
@@ -1961,7 +2008,7 @@ extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size
     if (!pl) return 0;
     // the prestacked traces + the partial maxima: one row per group range of a short series
     // (bp_split_count) and per station-count class of the interior kernel
-    size_t rows = (size_t)bp_split_count(pl, N);
+    size_t rows = pl->direct ? (size_t)direct_split_count(pl, N) : (size_t)bp_split_count(pl, N);
     if (pl->fast) {
         int n_split, n_split_edge;
         bp_fast_split_counts(pl, N, n_split, n_split_edge);
@@ -2263,6 +2310,22 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
     float* const beam_final = d_beam_out;
     int32_t* const arg_final = d_arg_out;
     char* const part = (char*)d_workspace + align_up((size_t)S * P * N * sizeof(float), 256);
+    if (pl->direct) {
+        // no LDS plan: global-memory gathers, ranges of sources per tile folded by the merge kernel
+        const int rows = reduce == BPMF_BP_REDUCE_MAX ? direct_split_count(pl, N) : 1;
+        float* pbeam = rows > 1 ? (float*)part : beam_final;
+        int32_t* parg = rows > 1 ? (int32_t*)(part + (size_t)rows * N * sizeof(float)) : arg_final;
+        profile_mark(BPMF_KERNEL_BP_BEAM, 0, stream);
+        int rc = launch_beam_direct(pl, U, N, out_of_bounds, reduce, stream, pbeam, parg, rows, (long long)N, t_best0);
+        if (!rc && rows > 1) {
+            bp_merge_splits_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
+                pbeam, parg, rows, rows, 0, (long long)N, N, beam_final, arg_final);
+            BPMF_LAUNCH_CHECK();
+        }
+        if (!rc && reduce == BPMF_BP_REDUCE_MAX) rc = finish(beam_final, arg_final);
+        profile_mark(BPMF_KERNEL_BP_BEAM, 1, stream);
+        return rc;
+    }
     if (pl->fast && reduce == BPMF_BP_REDUCE_MAX) {
         // Samples on which no source can leave the trace -- t + tmin_all >= 0 and t + tmax_all (+ the
         // staging slack of 8 samples) < N, rounded to multiples of 1024 (whole tiles of every kernel) --
@@ -2409,8 +2472,11 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     // million, so the last plans are kept.
     bpmf_bp_plan* pl = nullptr;
     const size_t b_mv = K * S * P * sizeof(int32_t), b_wsrc = K * S * sizeof(float);
+    // (the option generation is part of the key: a plan is built under the options of its creation,
+    // and bpmf_set_option must not leave a plan of the previous settings in use)
     const uint64_t key = hash_words(moveouts, b_mv, 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
-                         hash_words(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full);
+                         hash_words(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full) ^
+                         (option_generation() * 0xd6e8feb86659fd93ull);
     const uint64_t key2 = hash_words(moveouts, b_mv, 0x165667b19e3779f9ull) +
                           hash_words(w_sources, b_wsrc, 0x27d4eb2f165667c5ull);
     const bool keep_tables = b_mv + b_wsrc <= PLAN_KEEP_BYTES;

@@ -95,6 +95,12 @@ struct bpmf_bp_plan {
     bool fast_shares_generic = false;  // the single class was built from the generic (dual) plan: the
                                        // edge tiles run the 8-byte-gather flavour of the generic kernel
     int tmin_all = 0, tmax_all = 0;   // extreme used moveouts over all sources
+    // no LDS plan exists for this grid (a source's windows exceed the LDS, or > 256 terms per source):
+    // bp_direct.hip gathers from global memory along compact per-source term lists
+    bool direct = false;
+    int4* d_dhdr = nullptr;            // [K] {any station used, tmin, tmax, -}
+    long long* d_dfirst = nullptr;     // [K + 1] first term of every source
+    int4* d_dterms = nullptr;          // {row, moveout, weight bits, -}: stations ascending, phases inside
     // the few edge tiles of a day run the general kernel on a side stream, beside the interior
     // kernel (fork / join through the two events): a serial launch of 3-6 workgroups would add the
     // full duration of one tile (5 ms at cfg3) to every call.  A plan serves one call at a time.
@@ -113,4 +119,9 @@ namespace bpmf {
 int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_t N, long long tile_lo,
                      long long tile_hi, hipStream_t stream, float* beam, int32_t* arg,
                      int n_split = 1, long long split_stride = 0, float best0 = 0.0f);
+// bp_direct.hip: the whole series for a plan without LDS windows (pl->direct)
+int direct_split_count(const bpmf_bp_plan* pl, size_t N);
+int launch_beam_direct(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int reduce,
+                       hipStream_t stream, float* beam, int32_t* arg, int n_split, long long split_stride,
+                       float best0);
 }

@@ -45,6 +45,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"bp.verbose", 0, 0, 1},
     {"bp.fast_tile", 0, 0, 512},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
     {"bp.halves", 1, 0, 1},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
+    {"bp.direct", 0, 0, 1},             // 1: every plan takes the global-memory path of bp_direct.hip (tests)
     {"mf.wave_kernel", 1, 0, 1},        // independent-wave kernel for L <= 257
     {"mf.max_mfma_step", 64, 0, 1 << 20},  // larger steps take the generic kernel
     {"mf.host_batch_kb", 0, 0, 1L << 30},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
@@ -70,6 +71,9 @@ int find_option(const char* name)
 }
 }  // namespace
 
+std::atomic<unsigned long long> g_option_generation{0};
+unsigned long long option_generation() { return g_option_generation.load(std::memory_order_relaxed); }
+
 long option(Option which)
 {
     std::call_once(g_options_once, init_options);
@@ -90,7 +94,8 @@ extern "C" int bpmf_set_option(const char* name, long value)
         bpmf::set_error("bpmf_set_option: %s = %ld outside [%ld, %ld]", d.name, value, d.lo, d.hi);
         return -1;
     }
-    bpmf::g_options[i].store(value, std::memory_order_relaxed);
+    if (bpmf::g_options[i].exchange(value, std::memory_order_relaxed) != value)
+        bpmf::g_option_generation.fetch_add(1, std::memory_order_relaxed);
     return 0;
 }
 

@@ -115,12 +115,18 @@ def test_mf_random_shapes_signed_moveouts(oracle_lib, seed):
         assert np.isfinite(got).all()
 
 
+@pytest.mark.parametrize("direct", [0, 1])
 @pytest.mark.parametrize("seed", _fuzz_seeds(40))
-def test_bp_random_shapes_signed_moveouts(oracle_lib, seed):
+def test_bp_random_shapes_signed_moveouts(oracle_lib, seed, direct, hip_opts):
     """Moveouts of both signs, series spanning several 512-sample tiles (interior tiles run
     bp_beam_fast_kernel, the ends round 1's kernel on the side stream), 1..20 weighted stations,
-    uniform and per-station weights."""
+    uniform and per-station weights.  direct = 1: the same grids through bp_direct.hip (option
+    bp.direct), the path of grids that have no LDS plan."""
     from seismic_bpmf_amd import beamform
+    if direct:
+        if seed >= 16 and seed < 40:
+            pytest.skip("the direct path takes the first 16 seeds of the default sweep")
+        hip_opts("bp.direct", 1)
     rng = np.random.default_rng(8000 + seed)
     K = int(rng.integers(1, 600))
     S = int(rng.integers(1, 22))

@@ -293,9 +293,53 @@ def test_bad_arguments_raise_with_a_message():
         sb.matched_filter(tp, np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 1, 50), np.float32), 1)
     with pytest.raises(ValueError, match="step"):
         sb.matched_filter(tp, np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 1, 500), np.float32), 0)
-    with pytest.raises(_lib.BpmfHipError, match="station-phase"):
-        sb.beamform(np.zeros((150, 1, 100), np.float32), np.zeros((2, 150, 2), np.int32),
-                    np.ones((150, 1, 2), np.float32), np.ones((2, 150), np.float32))
+    with pytest.raises(_lib.BpmfHipError, match="unknown option"):
+        _lib.set_option("bp.no_such_option", 1)
+
+
+# ------------------------------------------ grids without an LDS plan (bp_direct.hip) ---
+@pytest.mark.parametrize("S,P,K,N,tau_max,density,label", [
+    (150, 2, 6, 3000, 200, 1.0, "150 stations x 2 phases: 300 terms per source"),
+    (90, 3, 5, 2500, 120, 1.0, "270 terms, three phases"),
+    (200, 2, 4, 2000, 300, 0.6, "200 stations, sparse weights"),
+    (400, 1, 3, 1500, 100, 1.0, "400 stations, one phase")])
+def test_bp_grids_without_an_lds_plan_run_the_direct_kernel(oracle_lib, S, P, K, N, tau_max, density, label):
+    """More station-phase rows than the 160 KB of LDS hold windows for (or than the 256-term tables of
+    the planned kernels): rounds 1-2 failed with "windows do not fit in LDS"; the reference has no such
+    limit (beampower.beamform at template_search.py:549-569).  Same results as the oracle, bit for bit."""
+    from seismic_bpmf_amd import BeamformerGPU
+    rng = np.random.default_rng(S + P)
+    f, tau, wp, ws = _bp_inputs(rng, K, S, P, N, tau_max, density)
+    ws[K - 1] = 0.0                                   # a source without any station
+    tau[0] -= tau_max // 2                            # negative moveouts
+    bf = BeamformerGPU(tau, ws)
+    info = bf.plan_info()
+    assert info["n_groups"] == 0 and info["gather_bytes"] == 4 and info["tile"] == 1024, info
+    bf.close()
+    _bp_check(oracle_lib, f, tau, wp, ws, label)
+
+
+@pytest.mark.parametrize("N", [700, 5000, 40_000])
+@pytest.mark.parametrize("first_computed", [0, 1])
+def test_bp_direct_kernel_on_ordinary_grids(oracle_lib, N, first_computed, hip_opts):
+    """Option bp.direct sends a grid that HAS a plan through the direct kernel: source ranges per tile
+    and the merge, ties, the arg-max start convention and its compat switch, ids with an offset."""
+    from seismic_bpmf_amd import BeamformerGPU
+    hip_opts("bp.direct", 1)
+    hip_opts("bp.compat_first_computed", first_computed)
+    rng = np.random.default_rng(N)
+    f, tau, wp, ws = _bp_inputs(rng, 300, 12, 2, N, 180, 0.5)
+    f[:, :, N // 3: N // 3 + 50] = 0.0               # equal (zero) beams: ties
+    f -= 0.3                                          # beams of both signs
+    tau[:, ::3] -= 90
+    with oracle_lib.compat(oracle_lib.COMPAT_FIRST_COMPUTED if first_computed else 0):
+        for oob in ("strict", "flexible"):
+            ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+            bf = BeamformerGPU(tau, ws, source_id_offset=1000)
+            mb, ma = (x.cpu().numpy() for x in bf.run(f, wp, reduce="max", out_of_bounds=oob))
+            bf.close()
+            _same(mb, ob, f"direct {oob} maxbeam")
+            assert np.array_equal(ma, oa + 1000), f"direct {oob}: {(ma != oa + 1000).sum()} arg-max differ"
 
 
 # ------------------------------------------------------------ interior-tile fast path ---
