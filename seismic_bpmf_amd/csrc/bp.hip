@@ -1013,8 +1013,8 @@ struct PlanHost {
     std::vector<float> beta;
     size_t lds_floats = 0;
     int NT = 4;
-    int n_pass = 1;             // 2: every group is two consecutive entries of `groups` (station halves)
-    std::vector<int> half;      // n_pass == 2: stations of source q that belong to the first half
+    int n_pass = 1;             // > 1: every group is n_pass consecutive entries of `groups` (LDS residencies)
+    int per = 0;                // n_pass > 1: weighted stations of a source per residency
 };
 
 // Processing order: recursive median bisection of the sources on the moveout column with
@@ -1190,14 +1190,15 @@ bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& orde
     return true;
 }
 
-// Two-residency plan (bp_fast.hip, HALVES): dual windows at `tile`, groups of at most `max_group`
-// sources, the weighted stations of every source split in two halves (the first ceil(n / 2) in
-// station order, then the rest); a group is closed when either half's windows would exceed the LDS.
-// Every group becomes TWO consecutive entries of ph.groups (same sources, the chunks of one half each);
-// ph.off holds the offsets of a source's terms inside the residency its half belongs to.
+// Multi-residency plan (bp_fast.hip, HALVES): dual windows at `tile`, groups of at most `max_group`
+// sources, the weighted stations of every source dealt to residencies of `per` stations each (in
+// station order: the first `per`, the next `per`, ...); a group is closed when any residency's windows
+// would exceed `hard_floats` of LDS.  Every group becomes ph.n_pass consecutive entries of ph.groups
+// (same sources, the chunks of one residency each); ph.off holds the offsets of a source's terms inside
+// the residency they belong to.
 bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int>& order_in, size_t S, size_t P,
                        int tile, int chunk, const size_t hard_floats, int max_group, int32_t id_offset,
-                       PlanHost& ph)
+                       int per, int n_pass, PlanHost& ph)
 {
     auto row_len = [&](int spread) -> size_t { return ((size_t)tile + (size_t)spread + 3) & ~(size_t)3; };
     auto row_cost = [&](int spread) -> size_t { return 2 * row_len(spread); };
@@ -1208,16 +1209,14 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     const size_t slab_extra = (size_t)4 * std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64);
     size_t max_terms = 1;
     ph = PlanHost();
-    ph.n_pass = 2;
+    ph.n_pass = n_pass;
+    ph.per = per;
     ph.srcs.resize(K);
-    ph.half.assign(K, 0);
-    auto src_of = [&](size_t k, int& n_sta) {
+    auto src_of = [&](size_t k) {
         int n = 0;
         long long lo = 0, hi = 0;
-        n_sta = 0;
         for (size_t s = 0; s < S; ++s) {
             if (ws[k * S + s] == 0.0f) continue;
-            ++n_sta;
             for (size_t p = 0; p < P; ++p) {
                 const long long tau = mv[(k * S + s) * P + p];
                 if (n == 0 || tau < lo) lo = tau;
@@ -1228,35 +1227,33 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
         max_terms = std::max(max_terms, (size_t)n);
         return BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi, (n + chunk - 1) / chunk * chunk};
     };
-    for (size_t q = 0; q < K; ++q) {
-        int n_sta;
-        ph.srcs[q] = src_of((size_t)order[q], n_sta);
-        ph.half[q] = (n_sta + 1) / 2;
-    }
+    for (size_t q = 0; q < K; ++q) ph.srcs[q] = src_of((size_t)order[q]);
+    if (max_terms > (size_t)per * n_pass * P) return false;
     const int NT = (int)((max_terms + chunk - 1) / chunk * chunk);
     ph.NT = NT;
     ph.off.assign(K * (size_t)NT, 0);
     ph.beta.assign(K * (size_t)NT, 0.0f);
-    std::vector<int> gmin[2], gmax[2], base[2];
-    std::vector<char> used[2];
-    for (int h = 0; h < 2; ++h) { gmin[h].resize(SP); gmax[h].resize(SP); base[h].resize(SP); used[h].resize(SP); }
+    std::vector<std::vector<int>> gmin(n_pass, std::vector<int>(SP)), gmax(n_pass, std::vector<int>(SP)),
+        base(n_pass, std::vector<int>(SP));
+    std::vector<std::vector<char>> used(n_pass, std::vector<char>(SP));
     struct RowUpdate { int h; size_t row; int lo, hi; };
     std::vector<RowUpdate> upd;
+    std::vector<size_t> need(n_pass), need2(n_pass);
     size_t first = 0;
     while (first < K) {
-        for (int h = 0; h < 2; ++h) std::fill(used[h].begin(), used[h].end(), 0);
-        size_t need[2] = {zero_slab + slab_extra, zero_slab + slab_extra}, q = first;
+        for (int h = 0; h < n_pass; ++h) {
+            std::fill(used[h].begin(), used[h].end(), 0);
+            need[h] = zero_slab + slab_extra;
+        }
+        size_t q = first;
         for (; q < K && (int)(q - first) < max_group; ++q) {
             const size_t k = (size_t)order[q];
-            int n_sta;
-            (void)src_of(k, n_sta);
-            const int h0 = (n_sta + 1) / 2;
-            size_t need2[2] = {need[0], need[1]};
+            need2 = need;
             upd.clear();
             int ord = 0;
             for (size_t s = 0; s < S; ++s) {
                 if (ws[k * S + s] == 0.0f) continue;
-                const int h = ord < h0 ? 0 : 1;
+                const int h = ord / per;
                 ++ord;
                 for (size_t p = 0; p < P; ++p) {
                     const size_t r = s * P + p;
@@ -1270,11 +1267,13 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
                         need2[h] += row_cost(0);
                     }
                     upd.push_back(RowUpdate{h, r, lo, hi});
-                    // (a row may appear in both halves of a GROUP -- different sources put a station in
-                    // different halves -- but only once per half)
+                    // (a row may appear in several residencies of a GROUP -- different sources count a
+                    // station differently -- but only once per residency)
                 }
             }
-            if (need2[0] > hard_floats || need2[1] > hard_floats) {
+            bool fits = true;
+            for (int h = 0; h < n_pass; ++h) fits = fits && need2[h] <= hard_floats;
+            if (!fits) {
                 if (q == first) return false;
                 break;
             }
@@ -1283,16 +1282,11 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
                 gmin[u.h][u.row] = u.lo;
                 gmax[u.h][u.row] = u.hi;
             }
-            need[0] = need2[0];
-            need[1] = need2[1];
+            need = need2;
         }
         std::sort(order.begin() + first, order.begin() + q);          // ascending ids inside the group
-        for (size_t qq = first; qq < q; ++qq) {
-            int n_sta;
-            ph.srcs[qq] = src_of((size_t)order[qq], n_sta);
-            ph.half[qq] = (n_sta + 1) / 2;
-        }
-        for (int h = 0; h < 2; ++h) {
+        for (size_t qq = first; qq < q; ++qq) ph.srcs[qq] = src_of((size_t)order[qq]);
+        for (int h = 0; h < n_pass; ++h) {
             BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
             size_t o = zero_slab + slab_extra;
             for (size_t r = 0; r < SP; ++r) {
@@ -1316,7 +1310,7 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
             int ord = 0;
             for (size_t s = 0; s < S; ++s) {
                 if (ws[k * S + s] == 0.0f) continue;
-                const int h = ord < ph.half[qq] ? 0 : 1;
+                const int h = ord / per;
                 ++ord;
                 for (size_t p = 0; p < P; ++p, ++j) {
                     const size_t r = s * P + p;
@@ -1393,16 +1387,16 @@ bool fast_parts(int n, int tile, int& tp, int& nparts)
 // whose units carry more address arithmetic per byte), all of it amortised over `tile` samples.
 double plan_cost(const PlanHost& ph, int tile)
 {
-    const double eff = tile == 512 ? 0.70 : (tile == 256 ? 0.66 : 0.58);
+    const double eff = tile == 512 ? 0.70 : (tile == 256 ? 0.66 : 0.40);   // (tile 128: measured 0.35 at 40 stations, VALU-bound)
     double cycles = 0.0;
     for (const BpGroup& g : ph.groups) {
         double terms = 0.0;
         for (int q = g.first_src; q < g.first_src + g.n_src; ++q) terms += ph.srcs[q].nterm;
-        if (ph.n_pass == 2) {                  // an entry is one residency: half of every source's stations,
-            terms *= 0.5;                      // and a short group is padded to 16 x BPF_HALVES_SLOTS sources
-            if (g.n_src > 0) terms *= 16.0 * BPF_HALVES_SLOTS / g.n_src;
-        }
-        cycles += 6000.0 + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
+        // an entry of a multi-residency plan is one residency: `per` stations of every source (padded
+        // records), and a short group is padded to 16 x BPF_HALVES_SLOTS sources; ~8800 cycles between the
+        // gathers of two entries were measured there (cfg5's share, 40 stations)
+        if (ph.n_pass > 1) terms = 2.0 * ph.per * 16 * BPF_HALVES_SLOTS;
+        cycles += (ph.n_pass > 1 ? 8800.0 : 6000.0) + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
     }
     return cycles / tile;
 }
@@ -1495,22 +1489,21 @@ bool build_fast_host(const PlanHost& ph, int tile, bool allow_uniform, FastHost&
     return true;
 }
 
-// Tables of a two-residency class (build_plan_halves): per group two BpFastGroup entries, each with ONE
-// run that lists all the group's sources (ascending id: wave w owns sources w, w + 16, ... in both
-// residencies -- the slots of the kernel's `carry` registers) as exactly two records of `tp` stations.
+// Tables of a multi-residency class (build_plan_halves): per group ph.n_pass BpFastGroup entries, each
+// with ONE run that lists all the group's sources (ascending id: wave w owns sources w, w + 16, ... in
+// every residency -- the slots of the kernel's `carry` registers) as exactly two records of ph.per / 2
+// stations.
 bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform)
 {
     const int NT = ph.NT;
     fh = FastHost();
     fh.uniform = allow_uniform;
     const size_t K = ph.srcs.size();
-    int max_half = 1;
     for (size_t q = 0; q < K; ++q) {
         const BpSource& sr = ph.srcs[q];
         if (sr.nterm <= 0) return false;                  // (sources without stations are not in this class)
         ++fh.n_sources;
         fh.max_sta = std::max(fh.max_sta, sr.nterm / 2);
-        max_half = std::max(max_half, std::max(ph.half[q], sr.nterm / 2 - ph.half[q]));
         float w0 = 0.0f;
         for (int j = 0; j < NT; j += 2) {
             const float b = ph.beta[q * NT + j];
@@ -1519,17 +1512,16 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
             else if (b != w0) fh.uniform = false;
         }
     }
-    // two records per half for everyone: tp = half the largest half, even, 6 / 8 / 10
-    const int tp = std::max(6, ((max_half + 1) / 2 + 1) / 2 * 2);
-    if (tp > 10 || fh.n_sources == 0) return false;
-    const int np = 2;
+    const int tp = ph.per / 2, np = 2, WPB = 16, full = WPB * BPF_HALVES_SLOTS;
+    if ((tp != 6 && tp != 8 && tp != 10) || fh.n_sources == 0) return false;
     const int rec_dw = (2 + 2 * tp + 3) / 4 * 4;
     fh.rec_dw = rec_dw;
     for (size_t gi = 0; gi < ph.groups.size(); ++gi) {
         const BpGroup& g = ph.groups[gi];
-        const int h = (int)(gi & 1);
-        if (g.n_src > 16 * BPF_HALVES_SLOTS) return false;
-        BpFastGroup f{(int)fh.fr.size(), 1 | (h == 0 ? BPF_GROUP_STORE : BPF_GROUP_LOAD), (int)fh.fw.size(), 0};
+        const int h = (int)(gi % (size_t)ph.n_pass);
+        if (g.n_src > full) return false;
+        const int flags = (h > 0 ? BPF_GROUP_LOAD : 0) | (h + 1 < ph.n_pass ? BPF_GROUP_STORE : 0);
+        BpFastGroup f{(int)fh.fr.size(), 1 | flags, (int)fh.fw.size(), 0};
         for (int c = g.first_chunk; c < g.first_chunk + g.n_chunk; ++c) {
             const BpChunk& ck = ph.chunks[c];
             if ((int)fh.fw.size() > f.first_win && fh.fw.back().row == ck.row &&
@@ -1544,22 +1536,22 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
         // every wave walks exactly BPF_HALVES_SLOTS sources (the kernel's slots are straight-line code):
         // a short group is padded with records of weight 0 at LDS offset 0 and id -1 (never a maximum)
         const size_t n = (size_t)g.n_src, rounds = BPF_HALVES_SLOTS;
-        fh.rec.resize(fh.rec.size() + rounds * np * 16 * rec_dw, 0);
-        fh.fr.push_back(BpRun{(int)first_rec, 16 * BPF_HALVES_SLOTS, tp, np});
-        for (size_t m = n; m < (size_t)16 * BPF_HALVES_SLOTS; ++m)
-            for (int part = 0; part < np; ++part) fh.rec[(first_rec + ((m / 16) * np + part) * 16 + m % 16) * rec_dw] = -1;
+        fh.rec.resize(fh.rec.size() + rounds * np * WPB * rec_dw, 0);
+        fh.fr.push_back(BpRun{(int)first_rec, full, tp, np});
+        for (size_t m = n; m < (size_t)full; ++m)
+            for (int part = 0; part < np; ++part) fh.rec[(first_rec + ((m / WPB) * np + part) * WPB + m % WPB) * rec_dw] = -1;
         for (size_t m = 0; m < n; ++m) {
             const int q = g.first_src + (int)m;
-            const int st_lo = h == 0 ? 0 : ph.half[q], st_hi = h == 0 ? ph.half[q] : ph.srcs[q].nterm / 2;
+            const int st_lo = h * ph.per, st_hi = std::min((h + 1) * ph.per, ph.srcs[q].nterm / 2);
             float w0 = 0.0f;
             for (int j = 0; j < NT && w0 == 0.0f; j += 2) w0 = ph.beta[(size_t)q * NT + j];
             for (int part = 0; part < np; ++part) {
-                const size_t r0 = (first_rec + ((m / 16) * np + part) * 16 + m % 16) * rec_dw;
+                const size_t r0 = (first_rec + ((m / WPB) * np + part) * WPB + m % WPB) * rec_dw;
                 fh.rec[r0] = ph.srcs[q].id;
                 fh.rec[r0 + 1] = fh.uniform ? __builtin_bit_cast(int, w0) : 0;
                 for (int i = 0; i < tp; ++i) {
                     const int st = st_lo + part * tp + i;
-                    const bool real = st < st_hi && 2 * st + 1 < NT;    // beyond this half: the zero slab, weight 0
+                    const bool real = st < st_hi && 2 * st + 1 < NT;    // beyond this residency: the zero slab, weight 0
                     const int oP = real ? ph.off[(size_t)q * NT + 2 * st] : 0;
                     const int oS = real ? ph.off[(size_t)q * NT + 2 * st + 1] : 0;
                     if (fh.uniform) {
@@ -1694,13 +1686,20 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 ClassHost ch;
                 ch.tile = 256;
                 ch.halves = true;
-                if (build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard, std::min(max_group, 16 * BPF_HALVES_SLOTS),
-                                      source_id_offset, ch.ph) &&
+                // 2-4 residencies of at most 20 stations, every source as two records of 6 / 8 / 10 stations in
+                // each of them
+                int cmax = 0;
+                for (int m : members) cmax = std::max(cmax, nsta[m]);
+                const int n_pass = std::max(2, (cmax + 19) / 20);
+                const int tp_h = std::max(6, (((cmax + n_pass - 1) / n_pass + 1) / 2 + 1) / 2 * 2), per = 2 * tp_h;
+                if (tp_h <= 10 &&
+                    build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard,
+                                      std::min(max_group, 16 * BPF_HALVES_SLOTS), source_id_offset, per, n_pass, ch.ph) &&
                     build_fast_host_halves(ch.ph, ch.fh, option(OPT_BP_FAST_UNIFORM) != 0)) {
                     const double cost = plan_cost(ch.ph, 256);
                     if (verbose)
-                        fprintf(stderr, "[bpmf] bp class %d, two residencies at tile 256: %zu group halves, cost %.1f\n",
-                                c, ch.ph.groups.size(), cost);
+                        fprintf(stderr, "[bpmf] bp class %d, %d residencies of %d stations at tile 256: %zu entries, cost %.1f\n",
+                                c, n_pass, per, ch.ph.groups.size(), cost);
                     if (!best.tile || cost < best_cost || forced_tile == 256) {
                         best = std::move(ch);
                         best_cost = cost;

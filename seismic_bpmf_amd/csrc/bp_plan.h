@@ -37,7 +37,7 @@ struct BpRun { int first_rec, n_src, tp, nparts; };
 struct BpFastGroup { int first_run, n_run, first_win, n_win; };
 // Two-residency groups (sources with 33-64 stations at tile 256, see bp_fast.hip): flags in n_run
 constexpr int BPF_GROUP_LOAD = 1 << 16, BPF_GROUP_STORE = 1 << 17;
-constexpr int BPF_HALVES_SLOTS = 6;      // sources per wave of a two-residency group (16 waves: 96 per group)
+constexpr int BPF_HALVES_SLOTS = 6;      // sources per wave of a multi-residency group (16 waves: 96 per group)
 // one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
 // offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
 struct BpWindow { int row, gofs, dst, len; };
@@ -50,7 +50,7 @@ constexpr int BPF_ZERO_SLAB = 512, BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
 struct BpFastClass {
     int tile = 512;              // 512 / 256 / 128 time samples per workgroup
     bool uniform = false;        // every source's non-zero weights are equal: ready-made addresses
-    bool halves = false;         // groups of <= 128 sources computed in two LDS residencies (station halves)
+    bool halves = false;         // groups of <= 96 sources computed in 2-4 LDS residencies (<= 20 stations each)
     int rec_dw = 0;              // dwords per record
     int n_groups = 0;
     int desc_waves = 1;          // waves that copy the next group's window descriptors

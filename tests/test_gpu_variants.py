@@ -420,16 +420,17 @@ def test_bp_fast_path_dense_station_weights(oracle_lib, n_used, uniform, hip_opt
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_used,uniform", [(33, True), (36, False), (40, True), (40, False)])
+@pytest.mark.parametrize("n_used,uniform", [(33, True), (36, False), (40, True), (40, False), (41, True), (47, False),
+                                            (52, True), (60, False), (61, True), (64, False)])
 def test_bp_two_residency_groups_for_33_to_40_stations(oracle_lib, n_used, uniform, hip_opts):
-    """Sources with 33-40 weighted stations at tile 256: every group of <= 128 sources is computed in two
-    LDS residencies (the station halves of every source), the partial beams of a wave's 8 sources
-    carried in registers between them.  Forced (bp.fast_tile = 256) and switched off (bp.halves = 0:
-    tile 128), smooth moveouts (several full groups of 128) and ragged ones, mixed station counts,
-    negative moveouts, ties -- the same bits as the oracle."""
+    """Sources with 33-64 weighted stations at tile 256: every group of <= 96 sources is computed in two
+    (<= 40 stations), three (<= 60) or four LDS residencies (<= 20 stations of every source each), the
+    partial beams of a wave's 6 sources carried in registers between them.  Forced (bp.fast_tile = 256)
+    and switched off (bp.halves = 0: tile 128), smooth moveouts (several full groups of 96) and ragged
+    ones, mixed station counts, negative moveouts, ties -- the same bits as the oracle."""
     from seismic_bpmf_amd import BeamformerGPU
     rng = np.random.default_rng(77 * n_used + int(uniform))
-    K, S, C, P, N = 700, 44, 3, 2, 5000
+    K, S, C, P, N = 700, max(44, min(64, n_used + 4)), 3, 2, 5000     # (a group stages at most 256 windows: 64 stations)
     f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4
     base = rng.integers(-30, 90, (1, S, P))
     tau = (base + rng.integers(-6, 7, (K, S, P))).astype(np.int32)          # smooth: groups fill up to 128 sources
