@@ -552,7 +552,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     static_assert(NTILE == 4 || NTILE == 2 || NTILE == 1, "tiles per wave");
     constexpr int LAGS_W = 256 * NTILE, LAGS_WG = 4 * LAGS_W;
     const int Ww = LAGS_W - 16 + Kpad;          // this wave's window
-    const int wave_floats = tp_len + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64;
+    const int wave_floats = tp_len + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64;   // (+ 64: whole 64-lane chunks are written)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -597,26 +597,30 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 (void*)(tmpl + ((size_t)t * n_ch + ch) * (size_t)L), 0, L * 4, 0x00020000);
             mf_stage_band<MAXT, 64>(rt, rs_t, lane);
         };
-        const bool full_window = Ww == 64 * MAXR;  // L = 241..257: every staging register is used
+        // Staging registers -> LDS in WHOLE 64-lane chunks, as many as the band / the window need (wave-
+        // uniform counts, one scalar jump): the lanes of the last chunk past the end of the band land in
+        // the first floats of the window, which is written afterwards; those past the end of the window in
+        // the 64 floats of slack behind it.  What they carry is real data or the zero fill of the buffer
+        // load, and nobody reads it.  A per-lane `if (x < Ww)` cost 160 instructions per channel (exec masks
+        // per register) -- and an instruction of a wave that is NOT in its K loop waits 40-60 cycles for
+        // an issue slot while the other three waves of the SIMD stream MFMAs: 4 500-8 800 cycles per
+        // channel and wave for L < 241 against 860 on the full-window path (s_memtime around the stage,
+        // profiles/r03_mf_phase_cycles.txt).
+        const int rd_chunks = (Ww + 63) >> 6, rt_chunks = (tp_len + 63) >> 6;
         auto write_stage = [&]() {
-            if (full_window) {
-#pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
-                    const int x = lane + 64 * r;
-                    dw[x + 2 * (x >> 4)] = rd[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
-                    const int x = lane + 64 * r;
-                    if (x < Ww) dw[x + 2 * (x >> 4)] = rd[r];
-                }
+#define MF_WT(r) case (r) + 1: if constexpr ((r) < MAXT) tp[lane + 64 * ((r) < MAXT ? (r) : 0)] = rt[(r) < MAXT ? (r) : 0]; [[fallthrough]];
+            switch (rt_chunks) {
+                MF_WT(4) MF_WT(3) MF_WT(2) MF_WT(1) MF_WT(0)
+                default: break;
             }
-#pragma unroll
-            for (int r = 0; r < MAXT; ++r) {
-                const int x = lane + 64 * r;
-                if (x < tp_len) tp[x] = rt[r];
+#undef MF_WT
+#define MF_WD(r) case (r) + 1: if constexpr ((r) < MAXR) { const int x = lane + 64 * (r); dw[x + 2 * (x >> 4)] = rd[(r) < MAXR ? (r) : 0]; } [[fallthrough]];
+            switch (rd_chunks) {
+                MF_WD(19) MF_WD(18) MF_WD(17) MF_WD(16) MF_WD(15) MF_WD(14) MF_WD(13) MF_WD(12) MF_WD(11) MF_WD(10)
+                MF_WD(9) MF_WD(8) MF_WD(7) MF_WD(6) MF_WD(5) MF_WD(4) MF_WD(3) MF_WD(2) MF_WD(1) MF_WD(0)
+                default: break;
             }
+#undef MF_WD
         };
 
         int4 rec = recs[0];
@@ -632,17 +636,24 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             const int4 rec2 = recs[ri + 2];
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
             f32x4 ed[NTILE];
+            // One 16-byte load per group of 4 lags.  A group that straddles an end of the valid range
+            // reads up to 3 floats outside this channel's row of norms -- the neighbouring row or the
+            // slack around the array -- and those lanes are masked in the epilogue (`ok`).  The wave-
+            // uniform test first: all but the first and last waves of a template take the loads without
+            // a lane mask (every instruction outside the K loop waits for an issue slot behind the MFMAs
+            // of the other waves).
+            if (wave_inside) {
 #pragma unroll
-            for (int u = 0; u < NTILE; ++u) {
-                const long long lag = lag_w + 256 * u;
-                // One 16-byte load per group of 4 lags.  A group that straddles an end of the
-                // valid range reads up to 3 floats outside this channel's row of norms -- the
-                // neighbouring row or the slack around the array -- and those lanes are masked in
-                // the epilogue (`ok`).
-                if (wave_inside || (lag + 3 >= rg.x && lag <= rg.y)) {
-                    ed[u] = *(const f32x4u*)(edc + lag + mvc);
-                } else {
-                    ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                for (int u = 0; u < NTILE; ++u) ed[u] = *(const f32x4u*)(edc + lag_w + 256 * u + mvc);
+            } else {
+#pragma unroll
+                for (int u = 0; u < NTILE; ++u) {
+                    const long long lag = lag_w + 256 * u;
+                    if (lag + 3 >= rg.x && lag <= rg.y) {
+                        ed[u] = *(const f32x4u*)(edc + lag + mvc);
+                    } else {
+                        ed[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    }
                 }
             }
             if (rec1.x >= 0) issue_stage(rec1.x, rec1.y);
@@ -993,7 +1004,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                 return -1;
             }
             dim3 grid_w((unsigned)(T * 8 * ((n_blocks_w + 7) / 8)));
-            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64) * sizeof(float) + 256;
+            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256;
 #define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT)                                                     \
     mf_mfma_wave_kernel<NS, R, 5, S1, NT><<<grid_w, dim3(MF_THREADS), wl, stream>>>(            \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
