@@ -17,6 +17,9 @@ feat = torch.randn((cfg["S"], cfg["C"], cfg["N"]), device="cuda", generator=g).a
 wp = syn.phase_weights(cfg["S"], cfg["C"], cfg["P"])
 if os.environ.get("VERBOSE"):
     _lib.set_option("bp.verbose", 1)
+for kv in os.environ.get("BP_OPTS", "").split(","):      # e.g. BP_OPTS=bp.fast_uniform=0,bp.halves=0
+    if "=" in kv:
+        _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if len(sys.argv) > 3:                       # force the tile of every class (256 on 33-64 stations: two residencies)
     _lib.set_option("bp.fast_tile", int(sys.argv[3]))
 
