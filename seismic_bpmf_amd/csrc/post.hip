@@ -281,19 +281,19 @@ __global__ void tdt_expand_kernel(const float* __restrict__ thr_win, size_t n_ro
 // Candidate extraction: every sample with cc > min(threshold, cap[row]) becomes one record
 // (row, index, cc, threshold).  BPMF/similarity_search.py:629 (cap) and :231-232 (test).
 // Records are appended in arbitrary order; the host sorts the (few thousand) survivors.
+constexpr unsigned CAND_CHUNKS = 4;       // 16-byte loads per thread
 __global__ __launch_bounds__(256) void cand_extract_kernel(
     const float* __restrict__ x, const float* __restrict__ thr_win, const float* __restrict__ row_cap,
     size_t n_rows, size_t n, size_t shift, size_t n_win, unsigned head_len, unsigned head_win,
     unsigned tail_start, unsigned tail_win, unsigned capacity,
     unsigned* __restrict__ count, int4* __restrict__ records)
 {
-    // 4 consecutive samples per thread (one 16-byte load); the window of a sample costs a division,
-    // so it is looked up for the first and the last of the four and only recomputed in between
-    // when they differ (n < 2^31: 32-bit arithmetic)
+    // 4 x 4 consecutive samples per thread (four 16-byte loads, all issued before the first test: a
+    // workgroup streams 16 KB, not 4 -- 4.2 million 4 KB workgroups ran at 3.5 TB/s); the window of a
+    // sample costs a division, so it is looked up for the first and the last of the four and only
+    // recomputed in between when they differ (n < 2^31: 32-bit arithmetic)
     const size_t row = blockIdx.y;
-    const unsigned i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const unsigned nn = (unsigned)n, sh = (unsigned)shift, nw = (unsigned)n_win;
-    if (i0 >= nn) return;
     // samples before head_len take window head_win, samples from tail_start on window tail_win (RMS
     // threshold: the first / last `shift` samples take the first / last window; MAD threshold: the
     // first half window and the last window - half samples repeat the ends of the indexed array)
@@ -306,24 +306,35 @@ __global__ __launch_bounds__(256) void cand_extract_kernel(
     const float* xr = x + row * n;
     const float* tw = thr_win + row * n_win;
     const float cap = row_cap ? row_cap[row] : INFINITY;
-    const unsigned cnt = nn - i0 < 4u ? nn - i0 : 4u;
-    float v[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (cnt == 4) {
-        const f32x4a v4 = *(const f32x4a*)(xr + i0);
-        v[0] = v4[0]; v[1] = v4[1]; v[2] = v4[2]; v[3] = v4[3];
-    } else {
-        for (unsigned e = 0; e < cnt; ++e) v[e] = xr[i0 + e];
-    }
-    const unsigned w_first = window_of(i0), w_last = window_of(i0 + cnt - 1);
+    float v[CAND_CHUNKS][4];
+    unsigned i0[CAND_CHUNKS], cnt[CAND_CHUNKS];
 #pragma unroll
-    for (unsigned e = 0; e < 4; ++e) {
-        if (e >= cnt) break;
-        const unsigned w = w_first == w_last ? w_first : window_of(i0 + e);
-        const float t = fminf(cap, tw[w]);
-        if (v[e] > t) {
-            unsigned slot = atomicAdd(count, 1u);
-            if (slot < capacity)
-                records[slot] = make_int4((int)row, (int)(i0 + e), __float_as_int(v[e]), __float_as_int(t));
+    for (int c = 0; c < CAND_CHUNKS; ++c) {
+        // (< 2^32: n < 2^31 and the grid covers n rounded up to 4096)
+        i0[c] = ((blockIdx.x * CAND_CHUNKS + c) * 256u + threadIdx.x) * 4u;
+        cnt[c] = i0[c] >= nn ? 0u : (nn - i0[c] < 4u ? nn - i0[c] : 4u);
+        v[c][0] = v[c][1] = v[c][2] = v[c][3] = -INFINITY;
+        if (cnt[c] == 4) {
+            const f32x4a v4 = *(const f32x4a*)(xr + i0[c]);
+            v[c][0] = v4[0]; v[c][1] = v4[1]; v[c][2] = v4[2]; v[c][3] = v4[3];
+        } else {
+            for (unsigned e = 0; e < cnt[c]; ++e) v[c][e] = xr[i0[c] + e];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CAND_CHUNKS; ++c) {
+        if (cnt[c] == 0) continue;
+        const unsigned w_first = window_of(i0[c]), w_last = window_of(i0[c] + cnt[c] - 1);
+#pragma unroll
+        for (unsigned e = 0; e < 4; ++e) {
+            if (e >= cnt[c]) break;
+            const unsigned w = w_first == w_last ? w_first : window_of(i0[c] + e);
+            const float t = fminf(cap, tw[w]);
+            if (v[c][e] > t) {
+                unsigned slot = atomicAdd(count, 1u);
+                if (slot < capacity)
+                    records[slot] = make_int4((int)row, (int)(i0[c] + e), __float_as_int(v[c][e]), __float_as_int(t));
+            }
         }
     }
 }
@@ -443,7 +454,7 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
         return -1;
     }
     BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-    cand_extract_kernel<<<dim3((unsigned)((n + 1023) / 1024), (unsigned)n_rows), dim3(256), 0, stream>>>(
+    cand_extract_kernel<<<dim3((unsigned)((n + 1024 * CAND_CHUNKS - 1) / (1024 * CAND_CHUNKS)), (unsigned)n_rows), dim3(256), 0, stream>>>(
         d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, (unsigned)shift, 0u,
         (unsigned)(n - shift), (unsigned)(n_win - 1), capacity, d_count, (int4*)d_records);
     BPMF_LAUNCH_CHECK();
@@ -475,7 +486,7 @@ extern "C" int bpmf_extract_candidates_mad_dev(const float* d_series, const floa
     const size_t head_win = std::min(half / shift, n_win - 1);
     const size_t tail_win = std::min((tail_start - 1) / shift, n_win - 1);
     BPMF_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-    cand_extract_kernel<<<dim3((unsigned)((n + 1023) / 1024), (unsigned)n_rows), dim3(256), 0, stream>>>(
+    cand_extract_kernel<<<dim3((unsigned)((n + 1024 * CAND_CHUNKS - 1) / (1024 * CAND_CHUNKS)), (unsigned)n_rows), dim3(256), 0, stream>>>(
         d_series, d_thr_windows, d_row_cap, n_rows, n, shift, n_win, (unsigned)half, (unsigned)head_win,
         (unsigned)tail_start, (unsigned)tail_win, capacity, d_count, (int4*)d_records);
     BPMF_LAUNCH_CHECK();
