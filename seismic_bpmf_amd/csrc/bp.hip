@@ -1015,6 +1015,7 @@ struct PlanHost {
     int NT = 4;
     int n_pass = 1;             // > 1: every group is n_pass consecutive entries of `groups` (LDS residencies)
     int per = 0;                // n_pass > 1: weighted stations of a source per residency
+    int slots = 0;              // n_pass > 1: sources per wave of a group (6, or 9 when every weight is uniform)
 };
 
 // Processing order: recursive median bisection of the sources on the moveout column with
@@ -1198,7 +1199,7 @@ bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& orde
 // the residency they belong to.
 bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int>& order_in, size_t S, size_t P,
                        int tile, int chunk, const size_t hard_floats, int max_group, int32_t id_offset,
-                       int per, int n_pass, PlanHost& ph)
+                       int per, int n_pass, int slots, PlanHost& ph)
 {
     auto row_len = [&](int spread) -> size_t { return ((size_t)tile + (size_t)spread + 3) & ~(size_t)3; };
     auto row_cost = [&](int spread) -> size_t { return 2 * row_len(spread); };
@@ -1211,6 +1212,7 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     ph = PlanHost();
     ph.n_pass = n_pass;
     ph.per = per;
+    ph.slots = slots;
     ph.srcs.resize(K);
     auto src_of = [&](size_t k) {
         int n = 0;
@@ -1395,7 +1397,7 @@ double plan_cost(const PlanHost& ph, int tile)
         // an entry of a multi-residency plan is one residency: `per` stations of every source (padded
         // records), and a short group is padded to 16 x BPF_HALVES_SLOTS sources; ~8800 cycles between the
         // gathers of two entries were measured there (cfg5's share, 40 stations)
-        if (ph.n_pass > 1) terms = 2.0 * ph.per * 16 * BPF_HALVES_SLOTS;
+        if (ph.n_pass > 1) terms = 2.0 * ph.per * 16 * ph.slots;
         cycles += (ph.n_pass > 1 ? 8800.0 : 6000.0) + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
     }
     return cycles / tile;
@@ -1512,8 +1514,9 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
             else if (b != w0) fh.uniform = false;
         }
     }
-    const int tp = ph.per / 2, np = 2, WPB = 16, full = WPB * BPF_HALVES_SLOTS;
+    const int tp = ph.per / 2, np = 2, WPB = 16, full = WPB * ph.slots;
     if ((tp != 6 && tp != 8 && tp != 10) || fh.n_sources == 0) return false;
+    if (fh.uniform != (ph.slots == BPF_HALVES_SLOTS_UNI)) return false;      // (the caller sized the groups for the other kernel)
     const int rec_dw = (2 + 2 * tp + 3) / 4 * 4;
     fh.rec_dw = rec_dw;
     for (size_t gi = 0; gi < ph.groups.size(); ++gi) {
@@ -1533,9 +1536,9 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
         f.n_win = (int)fh.fw.size() - f.first_win;
         if (f.n_win > BPF_DESC_MAX) return false;
         const size_t first_rec = fh.rec.size() / rec_dw;
-        // every wave walks exactly BPF_HALVES_SLOTS sources (the kernel's slots are straight-line code):
+        // every wave walks exactly ph.slots sources (the kernel's slots are straight-line code):
         // a short group is padded with records of weight 0 at LDS offset 0 and id -1 (never a maximum)
-        const size_t n = (size_t)g.n_src, rounds = BPF_HALVES_SLOTS;
+        const size_t n = (size_t)g.n_src, rounds = (size_t)ph.slots;
         fh.rec.resize(fh.rec.size() + rounds * np * WPB * rec_dw, 0);
         fh.fr.push_back(BpRun{(int)first_rec, full, tp, np});
         for (size_t m = n; m < (size_t)full; ++m)
@@ -1692,9 +1695,22 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 for (int m : members) cmax = std::max(cmax, nsta[m]);
                 const int n_pass = std::max(2, (cmax + 19) / 20);
                 const int tp_h = std::max(6, (((cmax + n_pass - 1) / n_pass + 1) / 2 + 1) / 2 * 2), per = 2 * tp_h;
+                // uniform weights (every source's non-zero weights equal): the kernel keeps the records in
+                // SGPRs and carries 9 sources per wave instead of 6
+                bool uni = option(OPT_BP_FAST_UNIFORM) != 0;
+                for (size_t mi = 0; mi < members.size() && uni; ++mi) {
+                    const float* wk = w_sources + (size_t)members[mi] * S;
+                    float w0 = 0.0f;
+                    for (size_t st = 0; st < S && uni; ++st) {
+                        if (wk[st] == 0.0f) continue;
+                        if (w0 == 0.0f) w0 = wk[st];
+                        else if (wk[st] != w0) uni = false;
+                    }
+                }
+                const int slots = uni ? BPF_HALVES_SLOTS_UNI : BPF_HALVES_SLOTS;
                 if (tp_h <= 10 &&
                     build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard,
-                                      std::min(max_group, 16 * BPF_HALVES_SLOTS), source_id_offset, per, n_pass, ch.ph) &&
+                                      std::min(max_group, 16 * slots), source_id_offset, per, n_pass, slots, ch.ph) &&
                     build_fast_host_halves(ch.ph, ch.fh, option(OPT_BP_FAST_UNIFORM) != 0)) {
                     const double cost = plan_cost(ch.ph, 256);
                     if (verbose)

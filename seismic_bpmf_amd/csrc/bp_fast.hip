@@ -134,7 +134,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     extern __shared__ float lds[];
     static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
     static_assert(!HALVES || TPW == 4, "two-residency groups run at tile 256");
-    constexpr int NSLOT = BPF_HALVES_SLOTS;                       // HALVES: sources per wave and group
+    // HALVES: sources per wave and group; uniform weights keep the records in SGPRs (walk_s) and carry more
+    constexpr int NSLOT = UNI ? BPF_HALVES_SLOTS_UNI : BPF_HALVES_SLOTS;
     f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the two residencies
     constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     constexpr int TPU = 8 / TPW;      // terms per unit
@@ -452,6 +453,115 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 #undef BPF_LOADQC
 #undef BPF_VMWAIT_ALL
             };
+            // ---- HALVES with uniform weights: the records live in SGPRs.  A record {id, weight, 2 TP LDS
+            // byte addresses} is wave-uniform; as vector loads (walk) every quad of it costs 16 cycles of
+            // the vector memory path -- 18 000 cycles per group entry against 15 000 of LDS gathers, 7-10 %
+            // of the kernel at every tile (profiles/r03_bp_fast_phase_cycles.txt) -- and a 20-register
+            // ring in VGPRs.  Here the wave's NEXT record is fetched with s_load_dwordx8 at the start of a
+            // part into the spare one of two SGPR buffers and waited for once, where the look-ahead first
+            // needs it (lgkmcnt(0): scalar loads return out of order, so that wait also drains the wave's
+            // gathers -- one bubble per record, covered by the other 15 waves).  The addresses reach
+            // v_add_u32 as SGPR operands, id and weight need no v_readfirstlane, and the 20 VGPRs go to
+            // four more carried sources per wave (10 instead of 6: 160 sources per group entry).
+            auto walk_s = [&](auto tp_c) {
+                constexpr int TP = decltype(tp_c)::value;
+                constexpr int NTERM = 2 * TP, NU = NTERM / TPU, AH = 2, RING = AH + 1;
+                constexpr int NV = (2 + NTERM + 7) / 8;          // s_load_dwordx8 per record (the table is padded)
+                static_assert(TPU == 2 && NV <= 3 && NU >= AH + 1, "tile 256, at most 11 stations per record");
+                i32x8 A[NV], B[NV];
+                const int* p = p_first;
+#define BPS_LOAD(dst)                                                                          \
+    {                                                                                          \
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst[0]) : "s"(p));                    \
+        if constexpr (NV > 1) asm volatile("s_load_dwordx8 %0, %1, 0x20" : "=s"(dst[NV > 1 ? 1 : 0]) : "s"(p)); \
+        if constexpr (NV > 2) asm volatile("s_load_dwordx8 %0, %1, 0x40" : "=s"(dst[NV > 2 ? 2 : 0]) : "s"(p)); \
+    }
+// lgkmcnt(0) with every register of the record as an in/out operand: nothing that reads them can be
+// scheduled above the wait (tools/check_inflight.py checks the listing)
+#define BPS_WAIT(dst)                                                                          \
+    {                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst[0]) :: "memory");                       \
+        if constexpr (NV > 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst[NV > 1 ? 1 : 0]) :: "memory"); \
+        if constexpr (NV > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst[NV > 2 ? 2 : 0]) :: "memory"); \
+    }
+#define BPS_DW(rec, i) (rec[(i) >> 3][(i) & 7])
+#define BPS_ISSUE(rec, w, sl)                                                                  \
+    {                                                                                          \
+        const unsigned a_ = v_base + (unsigned)BPS_DW(rec, 2 + 2 * (w)), b_ = v_base + (unsigned)BPS_DW(rec, 3 + 2 * (w)); \
+        BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                                \
+        BPF_RD64(X[sl][2], b_, 0); BPF_RD64(X[sl][3], b_, 512);                                \
+    }
+                BPS_LOAD(A)
+                BPS_WAIT(A)
+                f32x2 X[RING][4];
+                BPS_ISSUE(A, 0, 0) BPS_ISSUE(A, 1, 1)
+                f32x2 ac[RPT];
+                auto part = [&](auto& cur, auto& nxt, auto ph_c, auto upd_c) __attribute__((always_inline)) {
+                    constexpr int PH = decltype(ph_c)::value;
+                    constexpr int UPD = decltype(upd_c)::value;
+                    p = (const int*)((const char*)p + rec_stride);
+                    BPS_LOAD(nxt)                    // (the table is padded by one round of records: no clamp)
+                    i32x2 sp;
+                    sp[0] = 0;
+                    sp[1] = BPS_DW(cur, 1);
+                    auto unit_step = [&](auto uc) __attribute__((always_inline)) {
+                        constexpr int u = decltype(uc)::value;
+                        (void)&X; (void)&ac; (void)&cur; (void)&nxt; (void)&sp;
+                        constexpr int SL_ISSUE = (u + AH + PH) % RING, SL_USE = (u + PH) % RING;
+                        if constexpr (u + AH < NU) {
+                            BPS_ISSUE(cur, u + AH, SL_ISSUE)
+                        } else {
+                            if constexpr (u + AH == NU) BPS_WAIT(nxt)     // first look into the next record
+                            BPS_ISSUE(nxt, u + AH - NU, SL_ISSUE)
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * AH) : "memory");
+#pragma unroll
+                        for (int k = 0; k < TPU; ++k)
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) BPF_PKFMA(ac[r], sp, X[SL_USE][k * RPT + r]);
+                    };
+                    bpf_for_each(unit_step, std::make_integer_sequence<int, NU>{});
+                    if constexpr (UPD == 2) {
+                        const int sid = BPS_DW(cur, 0);
+                        if (!g_store && sid >= 0) {              // (id -1: the padding of a short group)
+#pragma unroll
+                            for (int j = 0; j < TPW; ++j) {
+                                const float a = ac[j >> 1][j & 1];
+                                const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
+                                best[j] = take ? a : best[j];
+                                arg[j] = take ? sid : arg[j];
+                            }
+                        }
+                    }
+                };
+                using ic1 = std::integral_constant<int, 1>;
+                using ic2 = std::integral_constant<int, 2>;
+                auto slot_step = [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int SLOT = decltype(sc)::value;
+                    (void)&carry; (void)&ac; (void)&A; (void)&B;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
+                        ac[r][1] = g_load ? carry[SLOT][r][1] : 0.0f;
+                    }
+                    part(A, B, std::integral_constant<int, (2 * SLOT * NU) % RING>{}, ic1{});
+                    part(B, A, std::integral_constant<int, ((2 * SLOT + 1) * NU) % RING>{}, ic2{});
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) carry[SLOT][r] = ac[r];      // (dead in the last residency)
+                };
+                bpf_for_each(slot_step, std::make_integer_sequence<int, NSLOT>{});
+                // the units issued past the wave's last part (they read whatever record follows: valid LDS
+                // addresses, or the zero slab) and the record behind it
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[0][2]), "+v"(X[0][3]), "+v"(X[1][0]), "+v"(X[1][1]),
+                               "+v"(X[1][2]), "+v"(X[1][3]), "+v"(X[2][0]), "+v"(X[2][1]), "+v"(X[2][2]), "+v"(X[2][3])
+                             :: "memory");
+                BPS_WAIT(A)
+#undef BPS_LOAD
+#undef BPS_WAIT
+#undef BPS_DW
+#undef BPS_ISSUE
+            };
             using std::integral_constant;
             using one_part = std::false_type;
             using parts = std::true_type;
@@ -466,6 +576,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     case 12: walk(integral_constant<int, 12>{}, one_part{}); break;
                     case 14: walk(integral_constant<int, 14>{}, one_part{}); break;
                     case 16: walk(integral_constant<int, 16>{}, one_part{}); break;
+                    default: break;
+                }
+            } else if constexpr (HALVES && UNI) {
+                switch (run.tp) {
+                    case 6: walk_s(integral_constant<int, 6>{}); break;
+                    case 8: walk_s(integral_constant<int, 8>{}); break;
+                    case 10: walk_s(integral_constant<int, 10>{}); break;
                     default: break;
                 }
             } else if constexpr (HALVES) {   // records of at most 10 stations: the record ring leaves room for `carry`
