@@ -54,6 +54,24 @@ namespace bpmf {
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+#ifndef BPF_SREC_MAX_TP_V
+#define BPF_SREC_MAX_TP_V 16
+#endif
+constexpr int BPF_SREC_MAX_TP = BPF_SREC_MAX_TP_V;   // longer records keep the VGPR ring (SGPR budget)
+// A record {id, weight, NTERM LDS byte addresses} in SGPRs: N8 octets and a tail of 2 (NTERM = 2 mod 8
+// leaves 2 dwords) or one more octet (the record table is padded: reading past the record is harmless)
+template <int RD>
+struct BpSRec {
+    static constexpr int N8 = RD / 8, TAIL2 = (RD % 8) == 2, NV = TAIL2 ? N8 : (RD + 7) / 8;
+    i32x8 v[NV ? NV : 1];
+    i32x2 t;
+    template <int I>
+    __device__ __forceinline__ int dw() const
+    {
+        if constexpr (I < 8 * NV) return v[I >> 3][I & 7];
+        else return t[I & 1];
+    }
+};
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -453,6 +471,134 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 #undef BPF_LOADQC
 #undef BPF_VMWAIT_ALL
             };
+            // ---- Uniform weights, one LDS residency per group: the same SGPR records as walk_s below (read
+            // its comment first) under the general part logic of `walk`: any number of parts per source,
+            // runs of a run-time number of sources (the two buffers alternate: the part loop is unrolled
+            // by two, which also carries the ring phase of NU = 2 mod 4), the group-local maximum.
+            auto walk_g = [&](auto tp_c, auto multi_c) {
+                constexpr int TP = decltype(tp_c)::value;
+                constexpr bool MULTI = decltype(multi_c)::value;
+                constexpr int NTERM = 2 * TP, NU = NTERM / TPU, AH = 3, RING = AH + 1, RD = 2 + NTERM;
+                static_assert(NU >= AH + 1 && (NU % 4 == 0 || NU % 4 == 2), "units per part");
+                using Rec = BpSRec<RD>;
+                Rec A, B;
+                const int* p = p_first;
+#define BPG_LOAD(dst)                                                                          \
+    {                                                                                          \
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst.v[0]) : "s"(p));                  \
+        if constexpr (Rec::NV > 1) asm volatile("s_load_dwordx8 %0, %1, 0x20" : "=s"(dst.v[Rec::NV > 1 ? 1 : 0]) : "s"(p)); \
+        if constexpr (Rec::NV > 2) asm volatile("s_load_dwordx8 %0, %1, 0x40" : "=s"(dst.v[Rec::NV > 2 ? 2 : 0]) : "s"(p)); \
+        if constexpr (Rec::NV > 3) asm volatile("s_load_dwordx8 %0, %1, 0x60" : "=s"(dst.v[Rec::NV > 3 ? 3 : 0]) : "s"(p)); \
+        static_assert(Rec::NV <= 4, "at most 16 stations per record");                         \
+        if constexpr (Rec::TAIL2) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(dst.t) : "s"(p), "n"(32 * Rec::NV)); \
+    }
+#define BPG_WAIT(dst)                                                                          \
+    {                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.v[0]) :: "memory");                     \
+        if constexpr (Rec::NV > 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.v[Rec::NV > 1 ? 1 : 0]) :: "memory"); \
+        if constexpr (Rec::NV > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.v[Rec::NV > 2 ? 2 : 0]) :: "memory"); \
+        if constexpr (Rec::NV > 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.v[Rec::NV > 3 ? 3 : 0]) :: "memory"); \
+        if constexpr (Rec::TAIL2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.t) :: "memory"); \
+    }
+#define BPG_ADDR(rec, tm) (v_base + (unsigned)rec.template dw<2 + (tm)>())
+#define BPG_ISSUE(rec, w, sl)                                                                  \
+    {                                                                                          \
+        if constexpr (TPU == 1) {                                                              \
+            const unsigned a_ = BPG_ADDR(rec, (w));                                            \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                            \
+            BPF_RD64(X[sl][2], a_, 1024); BPF_RD64(X[sl][3], a_, 1536);                        \
+        } else if constexpr (TPU == 2) {                                                       \
+            const unsigned a_ = BPG_ADDR(rec, 2 * (w)), b_ = BPG_ADDR(rec, 2 * (w) + 1);       \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                            \
+            BPF_RD64(X[sl][2], b_, 0); BPF_RD64(X[sl][3], b_, 512);                            \
+        } else {                                                                               \
+            const unsigned a_ = BPG_ADDR(rec, 4 * (w)), b_ = BPG_ADDR(rec, 4 * (w) + 1);       \
+            const unsigned c_ = BPG_ADDR(rec, 4 * (w) + 2), d_ = BPG_ADDR(rec, 4 * (w) + 3);   \
+            BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], b_, 0);                              \
+            BPF_RD64(X[sl][2], c_, 0); BPF_RD64(X[sl][3], d_, 0);                              \
+        }                                                                                      \
+    }
+                BPG_LOAD(A)
+                BPG_WAIT(A)
+                f32x2 X[RING][4];
+                BPG_ISSUE(A, 0, 0) BPG_ISSUE(A, 1, 1) BPG_ISSUE(A, 2, 2)
+                f32x2 ac[RPT];
+                if constexpr (MULTI) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
+                }
+                int part = 0;                 // MULTI: parts of the current source already accumulated
+                const int n_it = MULTI ? n_mine * nparts : n_mine;
+                auto part_g = [&](auto& cur, auto& nxt, auto ph_c) __attribute__((always_inline)) {
+                    constexpr int PH = decltype(ph_c)::value;
+                    p = (const int*)((const char*)p + rec_stride);
+                    BPG_LOAD(nxt)                    // (the table is padded by one round of records: no clamp)
+                    i32x2 sp;
+                    sp[0] = 0;
+                    sp[1] = cur.template dw<1>();
+                    auto unit_step = [&](auto uc) __attribute__((always_inline)) {
+                        constexpr int u = decltype(uc)::value;
+                        (void)&X; (void)&ac; (void)&cur; (void)&nxt; (void)&sp;
+                        constexpr int SL_ISSUE = (u + AH + PH) % RING, SL_USE = (u + PH) % RING;
+                        if constexpr (u + AH < NU) {
+                            BPG_ISSUE(cur, u + AH, SL_ISSUE)
+                        } else {
+                            if constexpr (u + AH == NU) BPG_WAIT(nxt)     // first look into the next record
+                            BPG_ISSUE(nxt, u + AH - NU, SL_ISSUE)
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * AH) : "memory");
+#pragma unroll
+                        for (int k = 0; k < TPU; ++k) {
+                            const int tm = u * TPU + k;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) {
+                                if (!MULTI && tm == 0) BPF_PKFMA0(ac[r], sp, X[SL_USE][k * RPT + r]);
+                                else BPF_PKFMA(ac[r], sp, X[SL_USE][k * RPT + r]);
+                            }
+                        }
+                    };
+                    bpf_for_each(unit_step, std::make_integer_sequence<int, NU>{});
+                    bool last = true;
+                    if constexpr (MULTI) { ++part; last = part == nparts; }
+                    if (last) {
+                        int vsid;                    // (v_cndmask takes one scalar operand: the mask)
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(vsid) : "s"(cur.template dw<0>()));
+                        unsigned long long mk[TPW];
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j)
+                            asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(mk[j]) : "v"(ac[j >> 1][j & 1]), "v"(bestg[j]));
+#pragma unroll
+                        for (int j = 0; j < TPW; ++j) {
+                            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(bestg[j]) : "v"(ac[j >> 1][j & 1]), "s"(mk[j]));
+                            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(argg[j]) : "v"(vsid), "s"(mk[j]));
+                        }
+                        if constexpr (MULTI) {
+                            part = 0;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
+                        }
+                    }
+                };
+                using ic0 = std::integral_constant<int, 0>;
+                using icn = std::integral_constant<int, NU % 4>;      // ring phase of the odd parts (0 or 2)
+                int it = 0;
+                for (; it + 1 < n_it; it += 2) {
+                    part_g(A, B, ic0{});
+                    part_g(B, A, icn{});
+                }
+                if (it < n_it) part_g(A, B, ic0{});   // odd number of parts
+                // the three units issued past the wave's last part (they read whatever record follows: valid LDS
+                // addresses of some group, or the zero slab)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[0][2]), "+v"(X[0][3]), "+v"(X[1][0]), "+v"(X[1][1]),
+                               "+v"(X[1][2]), "+v"(X[1][3]), "+v"(X[2][0]), "+v"(X[2][1]), "+v"(X[2][2]), "+v"(X[2][3]),
+                               "+v"(X[3][0]), "+v"(X[3][1]), "+v"(X[3][2]), "+v"(X[3][3])
+                             :: "memory");
+#undef BPG_LOAD
+#undef BPG_WAIT
+#undef BPG_ADDR
+#undef BPG_ISSUE
+            };
             // ---- HALVES with uniform weights: the records live in SGPRs.  A record {id, weight, 2 TP LDS
             // byte addresses} is wave-uniform; as vector loads (walk) every quad of it costs 16 cycles of
             // the vector memory path -- 18 000 cycles per group entry against 15 000 of LDS gathers, 7-10 %
@@ -567,15 +713,20 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             using parts = std::true_type;
             // wave-uniform, once per run.  Tile 512 serves <= 16 stations per source (one part);
             // the smaller tiles take any number of parts.
+            // uniform weights: records of at most BPF_SREC_MAX_TP stations travel in SGPRs (walk_g)
+            auto go = [&](auto tp_c, auto multi_c) __attribute__((always_inline)) {
+                if constexpr (UNI && !HALVES && decltype(tp_c)::value <= BPF_SREC_MAX_TP) walk_g(tp_c, multi_c);
+                else walk(tp_c, multi_c);
+            };
             if constexpr (TPW == 8) {
                 switch (run.tp) {
-                    case 4: walk(integral_constant<int, 4>{}, one_part{}); break;
-                    case 6: walk(integral_constant<int, 6>{}, one_part{}); break;
-                    case 8: walk(integral_constant<int, 8>{}, one_part{}); break;
-                    case 10: walk(integral_constant<int, 10>{}, one_part{}); break;
-                    case 12: walk(integral_constant<int, 12>{}, one_part{}); break;
-                    case 14: walk(integral_constant<int, 14>{}, one_part{}); break;
-                    case 16: walk(integral_constant<int, 16>{}, one_part{}); break;
+                    case 4: go(integral_constant<int, 4>{}, one_part{}); break;
+                    case 6: go(integral_constant<int, 6>{}, one_part{}); break;
+                    case 8: go(integral_constant<int, 8>{}, one_part{}); break;
+                    case 10: go(integral_constant<int, 10>{}, one_part{}); break;
+                    case 12: go(integral_constant<int, 12>{}, one_part{}); break;
+                    case 14: go(integral_constant<int, 14>{}, one_part{}); break;
+                    case 16: go(integral_constant<int, 16>{}, one_part{}); break;
                     default: break;
                 }
             } else if constexpr (HALVES && UNI) {
@@ -594,21 +745,21 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 }
             } else if constexpr (TPW == 4) {
                 switch (run.tp) {
-                    case 6: walk(integral_constant<int, 6>{}, parts{}); break;
-                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
-                    case 10: walk(integral_constant<int, 10>{}, parts{}); break;
-                    case 12: walk(integral_constant<int, 12>{}, parts{}); break;
-                    case 14: walk(integral_constant<int, 14>{}, parts{}); break;
-                    case 16: walk(integral_constant<int, 16>{}, parts{}); break;
+                    case 6: go(integral_constant<int, 6>{}, parts{}); break;
+                    case 8: go(integral_constant<int, 8>{}, parts{}); break;
+                    case 10: go(integral_constant<int, 10>{}, parts{}); break;
+                    case 12: go(integral_constant<int, 12>{}, parts{}); break;
+                    case 14: go(integral_constant<int, 14>{}, parts{}); break;
+                    case 16: go(integral_constant<int, 16>{}, parts{}); break;
                     default: break;
                 }
             } else {
                 switch (run.tp) {
-                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
-                    case 12: walk(integral_constant<int, 12>{}, parts{}); break;
-                    case 16: walk(integral_constant<int, 16>{}, parts{}); break;
-                    case 20: walk(integral_constant<int, 20>{}, parts{}); break;
-                    case 24: walk(integral_constant<int, 24>{}, parts{}); break;
+                    case 8: go(integral_constant<int, 8>{}, parts{}); break;
+                    case 12: go(integral_constant<int, 12>{}, parts{}); break;
+                    case 16: go(integral_constant<int, 16>{}, parts{}); break;
+                    case 20: go(integral_constant<int, 20>{}, parts{}); break;
+                    case 24: go(integral_constant<int, 24>{}, parts{}); break;
                     default: break;
                 }
             }
