@@ -1516,7 +1516,6 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
     }
     const int tp = ph.per / 2, np = 2, WPB = 16, full = WPB * ph.slots;
     if ((tp != 6 && tp != 8 && tp != 10) || fh.n_sources == 0) return false;
-    if (fh.uniform != (ph.slots == BPF_HALVES_SLOTS_UNI)) return false;      // (the caller sized the groups for the other kernel)
     const int rec_dw = (2 + 2 * tp + 3) / 4 * 4;
     fh.rec_dw = rec_dw;
     for (size_t gi = 0; gi < ph.groups.size(); ++gi) {
@@ -1695,19 +1694,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 for (int m : members) cmax = std::max(cmax, nsta[m]);
                 const int n_pass = std::max(2, (cmax + 19) / 20);
                 const int tp_h = std::max(6, (((cmax + n_pass - 1) / n_pass + 1) / 2 + 1) / 2 * 2), per = 2 * tp_h;
-                // uniform weights (every source's non-zero weights equal): the kernel keeps the records in
-                // SGPRs and carries 9 sources per wave instead of 6
-                bool uni = option(OPT_BP_FAST_UNIFORM) != 0;
-                for (size_t mi = 0; mi < members.size() && uni; ++mi) {
-                    const float* wk = w_sources + (size_t)members[mi] * S;
-                    float w0 = 0.0f;
-                    for (size_t st = 0; st < S && uni; ++st) {
-                        if (wk[st] == 0.0f) continue;
-                        if (w0 == 0.0f) w0 = wk[st];
-                        else if (wk[st] != w0) uni = false;
-                    }
-                }
-                const int slots = uni ? BPF_HALVES_SLOTS_UNI : BPF_HALVES_SLOTS;
+                const int slots = BPF_HALVES_SLOTS;
                 if (tp_h <= 10 &&
                     build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard,
                                       std::min(max_group, 16 * slots), source_id_offset, per, n_pass, slots, ch.ph) &&

@@ -152,8 +152,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     extern __shared__ float lds[];
     static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
     static_assert(!HALVES || TPW == 4, "two-residency groups run at tile 256");
-    // HALVES: sources per wave and group; uniform weights keep the records in SGPRs (walk_s) and carry more
-    constexpr int NSLOT = UNI ? BPF_HALVES_SLOTS_UNI : BPF_HALVES_SLOTS;
+    constexpr int NSLOT = BPF_HALVES_SLOTS;      // HALVES: sources per wave and group
     f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the two residencies
     constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     constexpr int TPU = 8 / TPW;      // terms per unit
@@ -500,7 +499,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         if constexpr (Rec::NV > 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.v[Rec::NV > 3 ? 3 : 0]) :: "memory"); \
         if constexpr (Rec::TAIL2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst.t) :: "memory"); \
     }
-#define BPG_ADDR(rec, tm) (v_base + (unsigned)rec.template dw<2 + (tm)>())
+// LDS byte offset of term `tm`: the dword itself (uniform weights), or a 16-bit float offset out of
+// the station's {offs_P | offs_S << 16, weight} pair -- scalar shifts, not VALU
+#define BPG_OFF(rec, tm)                                                                       \
+    (UNI ? (unsigned)rec.template dw<UNI ? 2 + (tm) : 2>()                                     \
+         : ((((tm) & 1) ? ((unsigned)rec.template dw<2 + 2 * ((tm) >> 1)>() >> 16)             \
+                        : ((unsigned)rec.template dw<2 + 2 * ((tm) >> 1)>() & 0xffffu)) << 2))
+#define BPG_ADDR(rec, tm) (v_base + BPG_OFF(rec, tm))
 #define BPG_ISSUE(rec, w, sl)                                                                  \
     {                                                                                          \
         if constexpr (TPU == 1) {                                                              \
@@ -547,15 +552,18 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             BPG_ISSUE(nxt, u + AH - NU, SL_ISSUE)
                         }
                         asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * AH) : "memory");
-#pragma unroll
-                        for (int k = 0; k < TPU; ++k) {
-                            const int tm = u * TPU + k;
+                        auto term_step = [&](auto kc) __attribute__((always_inline)) {
+                            constexpr int k = decltype(kc)::value, tm = u * TPU + k;
+                            (void)&X; (void)&ac; (void)&cur; (void)&sp;
+                            // per-station weights: the station's weight enters the SGPR pair at its first term
+                            if constexpr (!UNI && (tm & 1) == 0) sp[1] = cur.template dw<UNI ? 1 : 3 + 2 * (tm >> 1)>();
 #pragma unroll
                             for (int r = 0; r < RPT; ++r) {
                                 if (!MULTI && tm == 0) BPF_PKFMA0(ac[r], sp, X[SL_USE][k * RPT + r]);
                                 else BPF_PKFMA(ac[r], sp, X[SL_USE][k * RPT + r]);
                             }
-                        }
+                        };
+                        bpf_for_each(term_step, std::make_integer_sequence<int, TPU>{});
                     };
                     bpf_for_each(unit_step, std::make_integer_sequence<int, NU>{});
                     bool last = true;
@@ -631,9 +639,12 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         if constexpr (NV > 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dst[NV > 2 ? 2 : 0]) :: "memory"); \
     }
 #define BPS_DW(rec, i) (rec[(i) >> 3][(i) & 7])
+// unit w = station w: its two LDS byte addresses (uniform weights), or 16-bit float offsets out of the
+// station's {offs_P | offs_S << 16, weight} pair -- scalar shifts, not VALU
 #define BPS_ISSUE(rec, w, sl)                                                                  \
     {                                                                                          \
-        const unsigned a_ = v_base + (unsigned)BPS_DW(rec, 2 + 2 * (w)), b_ = v_base + (unsigned)BPS_DW(rec, 3 + 2 * (w)); \
+        const unsigned a_ = v_base + (UNI ? (unsigned)BPS_DW(rec, 2 + 2 * (w)) : (((unsigned)BPS_DW(rec, 2 + 2 * (w)) & 0xffffu) << 2)); \
+        const unsigned b_ = v_base + (UNI ? (unsigned)BPS_DW(rec, 3 + 2 * (w)) : (((unsigned)BPS_DW(rec, 2 + 2 * (w)) >> 16) << 2)); \
         BPF_RD64(X[sl][0], a_, 0); BPF_RD64(X[sl][1], a_, 512);                                \
         BPF_RD64(X[sl][2], b_, 0); BPF_RD64(X[sl][3], b_, 512);                                \
     }
@@ -661,6 +672,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             BPS_ISSUE(nxt, u + AH - NU, SL_ISSUE)
                         }
                         asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(4 * AH) : "memory");
+                        if constexpr (!UNI) sp[1] = BPS_DW(cur, 3 + 2 * u);      // the weight of station u
 #pragma unroll
                         for (int k = 0; k < TPU; ++k)
 #pragma unroll
@@ -715,7 +727,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             // the smaller tiles take any number of parts.
             // uniform weights: records of at most BPF_SREC_MAX_TP stations travel in SGPRs (walk_g)
             auto go = [&](auto tp_c, auto multi_c) __attribute__((always_inline)) {
-                if constexpr (UNI && !HALVES && decltype(tp_c)::value <= BPF_SREC_MAX_TP) walk_g(tp_c, multi_c);
+                if constexpr (!HALVES && decltype(tp_c)::value <= BPF_SREC_MAX_TP) walk_g(tp_c, multi_c);
                 else walk(tp_c, multi_c);
             };
             if constexpr (TPW == 8) {
@@ -729,18 +741,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     case 16: go(integral_constant<int, 16>{}, one_part{}); break;
                     default: break;
                 }
-            } else if constexpr (HALVES && UNI) {
+            } else if constexpr (HALVES) {
                 switch (run.tp) {
                     case 6: walk_s(integral_constant<int, 6>{}); break;
                     case 8: walk_s(integral_constant<int, 8>{}); break;
                     case 10: walk_s(integral_constant<int, 10>{}); break;
-                    default: break;
-                }
-            } else if constexpr (HALVES) {   // records of at most 10 stations: the record ring leaves room for `carry`
-                switch (run.tp) {
-                    case 6: walk(integral_constant<int, 6>{}, parts{}); break;
-                    case 8: walk(integral_constant<int, 8>{}, parts{}); break;
-                    case 10: walk(integral_constant<int, 10>{}, parts{}); break;
                     default: break;
                 }
             } else if constexpr (TPW == 4) {

@@ -37,8 +37,7 @@ struct BpRun { int first_rec, n_src, tp, nparts; };
 struct BpFastGroup { int first_run, n_run, first_win, n_win; };
 // Two-residency groups (sources with 33-64 stations at tile 256, see bp_fast.hip): flags in n_run
 constexpr int BPF_GROUP_LOAD = 1 << 16, BPF_GROUP_STORE = 1 << 17;
-constexpr int BPF_HALVES_SLOTS = 6;      // sources per wave of a multi-residency group (16 waves: 96 per group)
-constexpr int BPF_HALVES_SLOTS_UNI = 9;  // ... of a class with uniform weights (records in SGPRs: 160 per group)
+constexpr int BPF_HALVES_SLOTS = 9;      // sources per wave of a multi-residency group (16 waves: 144 per group)
 // one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
 // offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
 struct BpWindow { int row, gofs, dst, len; };
