@@ -100,7 +100,9 @@ __device__ __forceinline__ float lane_bcast(float v, int lane)
 // All per-source / per-chunk metadata is wave-uniform.  It is fetched with ONE coalesced
 // vector load per wave (lane l <- entry l) one source ahead of its use and broadcast with
 // v_readlane: no scalar-memory round trip sits between the LDS gathers (SMEM and LDS share
-// the lgkm counter, so an s_load in the gather loop would serialise it).
+// the lgkm counter; round 3 found that ONE lgkmcnt(0) per source is cheap with 16 waves per CU --
+// bp_fast.hip keeps its records in SGPRs -- but these general kernels predate that and only run the
+// edge tiles of a day, reduce="none" and the P != 2 grids).
 template <int TPT, int CHUNK, int NBLK, int OOB, int REDUCE>
 __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
     const float* __restrict__ U, long long N, const BpGroup* __restrict__ groups, int n_groups,
@@ -241,8 +243,8 @@ __global__ __launch_bounds__(BP_THREADS) void bp_beam_kernel(
 // metadata {LDS byte offset, weight} is loaded with VECTOR loads from a wave-uniform address
 // (every lane receives the same value), two sources ahead, so that the gather loop is three
 // instructions per term: v_add (address) / ds_read2st64_b32 (TPT = 2 gathers) / v_pk_fma.
-// Scalar loads cannot be used here (SMEM shares the lgkm counter with the LDS gathers) and
-// v_readlane broadcasting costs two more VALU issues per term (see bp_beam_kernel).
+// (Round 1 ruled scalar loads out here -- SMEM shares the lgkm counter with the LDS gathers -- see the
+// note above bp_beam_kernel; v_readlane broadcasting costs two more VALU issues per term.)
 struct BpTermV {
     int off_bytes;  // LDS byte offset of the term's window origin (+ moveout)
     float beta;     // source weight of the term's station
