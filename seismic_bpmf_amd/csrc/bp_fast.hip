@@ -123,19 +123,18 @@ __device__ __forceinline__ void bpf_for_each(F&& f, std::integer_sequence<int, I
 // ~48 at 128 (bp.hip picks the tile per station-count class of sources).
 //
 // HALVES (tile 256 only): sources with 33-64 weighted stations.  Their dual windows do not fit the
-// LDS at tile 256 (80 rows x 2 copies x 256 floats = 164 KB), and at tile 128 every gather carries its
-// own address add -- the kernel is VALU-bound there (0.35 of the gather rate at cfg5's share).  So
-// a group of at most 96 sources (6 per wave) is computed in TWO LDS residencies at tile 256: the
-// first stages the windows of every source's first half of stations and leaves the partial beams of
-// the wave's 6 sources in registers (`carry`, 24 VGPRs, statically indexed: the source loop is
-// unrolled over the 6 slots), the second stages the other half, continues the same fmaf chains and
-// updates the running maximum.  The plan lists the two residencies as consecutive groups with the
-// same sources in the same order, every source as exactly two records per residency;
-// BPF_GROUP_STORE / BPF_GROUP_LOAD in the group's run count tell the kernel which half it is.
-// Registers decide the shape: 128 VGPRs at the 4 waves per SIMD the LDS rate needs.  Eight carried
-// sources spill (the first version: 0.36 -- every spill reload is a vector load in front of a
-// wait); five fit with the 4-deep gather ring (0.51), six with a 3-deep ring and without the
-// group-local maximum (0.54).
+// LDS at tile 256 (80 rows x 2 copies x 256 floats = 164 KB), and tile 128 stops at 0.35 of the gather
+// rate.  So a group of at most 144 sources (BPF_HALVES_SLOTS = 9 per wave) is computed in two to four
+// LDS RESIDENCIES at tile 256: the first stages the windows of every source's first <= 20 stations and
+// leaves the partial beams of the wave's 9 sources in registers (`carry`, 36 VGPRs, statically indexed:
+// the source loop is unrolled over the slots), the next ones stage the following stations and continue
+// the same fmaf chains, the last one updates the running maximum.  The plan lists the residencies as
+// consecutive groups with the same sources in the same order, every source as exactly two records per
+// residency (short groups padded with records of weight 0 and id -1: no branch on the slot count);
+// BPF_GROUP_STORE / BPF_GROUP_LOAD in the group's run count tell the kernel where it is.
+// Registers decide the shape: 128 VGPRs at the 4 waves per SIMD the LDS rate needs.  With the records
+// in VGPRs (rounds of this kernel before walk_s) six carried sources fit: 0.52; with the records in
+// SGPRs nine: 0.61.
 template <bool UNI, int TPW, bool HALVES = false>
 __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
     static_assert(!HALVES || TPW == 4, "two-residency groups run at tile 256");
     constexpr int NSLOT = BPF_HALVES_SLOTS;      // HALVES: sources per wave and group
-    f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the two residencies
+    f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the residencies
     constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
     constexpr int TPU = 8 / TPW;      // terms per unit
     constexpr int RPT = TPW / 2;      // ds_read_b64 per term
@@ -247,10 +246,11 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 constexpr int TP = decltype(tp_c)::value;
                 constexpr bool MULTI = decltype(multi_c)::value;
                 constexpr int NTERM = 2 * TP, NU = NTERM / TPU, Q = NTERM / 4;
-                // units in flight ahead of the one being accumulated, and the ring that holds them: 3 + 1, or
-                // 2 + 1 in the two-residency kernel (8 VGPRs for a sixth carried source; the depth of the
-                // ring made no difference when it was measured at tile 512)
-                constexpr int AH = HALVES ? 2 : 3, RING = AH + 1;
+                // (the VGPR-record walk: records of more than BPF_SREC_MAX_TP stations only -- tile 128 with
+                // 20 or 24 stations per part; everything else keeps its records in SGPRs, walk_g / walk_s)
+                static_assert(!HALVES, "the multi-residency kernel has its own walk");
+                // units in flight ahead of the one being accumulated, and the ring that holds them
+                constexpr int AH = 3, RING = AH + 1;
                 static_assert(TP >= 4 && TP % 2 == 0 && TP <= 24 && NTERM % TPU == 0 && Q <= 12, "4..24 stations per part, even");
                 static_assert(NU >= AH + 1 && bpf_ur(((AH - 1) * TPU) >> 2, TPU) <= NU - 2,
                               "the next part's first units must find their quads requested");
@@ -303,9 +303,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             BPF_RD64(X[sl][2], c_, 0); BPF_RD64(X[sl][3], d_, 0);                    \
         }                                                                                      \
     }
-                BPF_ISSUE_U(0, 0) BPF_ISSUE_U(1, 1)
-                if constexpr (AH == 3) BPF_ISSUE_U(2, 2)
-                static_assert(AH == 2 || AH == 3, "prologue");
+                BPF_ISSUE_U(0, 0) BPF_ISSUE_U(1, 1) BPF_ISSUE_U(2, 2)
+                static_assert(AH == 3, "prologue");
                 f32x2 ac[RPT];
                 if constexpr (MULTI) {
 #pragma unroll
@@ -313,11 +312,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 }
                 int part = 0;                 // MULTI: parts of the current source already accumulated
                 const int n_it = MULTI ? n_mine * nparts : n_mine;
-                // UPD: 0 = the part logic of MULTI (update behind a source's last part); 1 = no update
-                // (HALVES: first record of a source); 2 = HALVES: second record -- park or update.
-                auto part_body = [&](auto ph_c, auto upd_c) __attribute__((always_inline)) {
+                auto part_body = [&](auto ph_c) __attribute__((always_inline)) {
                     constexpr int PH = decltype(ph_c)::value;
-                    constexpr int UPD = decltype(upd_c)::value;
                     i32x2 sp_u;
                     // the header of the next part (the table is padded by one round of records: no clamp)
                     p = (const int*)((const char*)p + rec_stride);
@@ -385,21 +381,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     // ---- max / arg-max update behind a source's last part, strict >: TPW compares, then
                     // 2 TPW selects; the next part's first three units are in flight meanwhile
                     bool last = true;
-                    if constexpr (UPD == 0 && MULTI) { ++part; last = part == nparts; }
-                    if constexpr (UPD == 1) last = false;
-                    if constexpr (UPD == 2) last = !g_store && h_cur[0] >= 0;     // (id -1: the padding of a short group)
-                    if constexpr (HALVES) {
-                        if (last) {
-                            const int sid = h_cur[0];
-#pragma unroll
-                            for (int j = 0; j < TPW; ++j) {
-                                const float a = ac[j >> 1][j & 1];
-                                const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
-                                best[j] = take ? a : best[j];
-                                arg[j] = take ? sid : arg[j];
-                            }
-                        }
-                    } else if (last) {
+                    if constexpr (MULTI) { ++part; last = part == nparts; }
+                    if (last) {
                         unsigned long long mk[TPW];
 #pragma unroll
                         for (int j = 0; j < TPW; ++j)
@@ -409,7 +392,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(bestg[j]) : "v"(ac[j >> 1][j & 1]), "s"(mk[j]));
                             asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(argg[j]) : "v"(h_cur[0]), "s"(mk[j]));
                         }
-                        if constexpr (UPD == 0 && MULTI) {
+                        if constexpr (MULTI) {
                             part = 0;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r) ac[r] = (f32x2){0.0f, 0.0f};
@@ -418,41 +401,17 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     h_cur = h_next;
                 };
                 using ic0 = std::integral_constant<int, 0>;
-                using ic1 = std::integral_constant<int, 1>;
                 using ic2 = std::integral_constant<int, 2>;
-                if constexpr (HALVES) {
-                    // every wave has exactly NSLOT sources (the plan pads a short group with records of
-                    // weight 0 and id -1, whose update is skipped), two records each, straight-line: slot
-                    // s's partial beams are carry[s] in both residencies, and the ring phase of record k
-                    // is (k NU) mod RING.  No branch on the slot count: a register that a gather or a
-                    // record load still has in flight must never reach a control-flow merge, where the
-                    // compiler is free to copy it (tools/check_inflight.py found exactly that in the
-                    // version with `if (slot < n_mine)` exits).
-                    (void)n_it;
-                    auto slot_step = [&](auto sc) __attribute__((always_inline)) {
-                        constexpr int SLOT = decltype(sc)::value;
-                        (void)&carry; (void)&ac;
-#pragma unroll
-                        for (int r = 0; r < RPT; ++r) {
-                            ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
-                            ac[r][1] = g_load ? carry[SLOT][r][1] : 0.0f;
-                        }
-                        part_body(std::integral_constant<int, (2 * SLOT * NU) % RING>{}, ic1{});
-                        part_body(std::integral_constant<int, ((2 * SLOT + 1) * NU) % RING>{}, ic2{});
-#pragma unroll
-                        for (int r = 0; r < RPT; ++r) carry[SLOT][r] = ac[r];      // (dead in the second residency)
-                    };
-                    bpf_for_each(slot_step, std::make_integer_sequence<int, NSLOT>{});
-                } else if constexpr (NU % 4 == 0) {
-                    for (int it = 0; it < n_it; ++it) part_body(ic0{}, ic0{});
+                if constexpr (NU % 4 == 0) {
+                    for (int it = 0; it < n_it; ++it) part_body(ic0{});
                 } else {
                     static_assert(NU % 4 == 2, "even number of units per part");
                     int it = 0;
                     for (; it + 1 < n_it; it += 2) {
-                        part_body(ic0{}, ic0{});
-                        part_body(ic2{}, ic0{});
+                        part_body(ic0{});
+                        part_body(ic2{});
                     }
-                    if (it < n_it) part_body(ic0{}, ic0{});   // odd number of parts
+                    if (it < n_it) part_body(ic0{});   // odd number of parts
                 }
                 // the three units issued past the wave's last part (they read whatever record follows:
                 // valid LDS addresses of some group, or the zero slab) and the last refills.  Every
