@@ -1857,6 +1857,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             BpFastClass& fc = pl->cls[pl->n_classes];
             fc.tile = ch.tile;
             fc.halves = ch.halves;
+            fc.n_pass = ch.halves ? ch.ph.n_pass : 1;
             fc.uniform = ch.fh.uniform;
             fc.rec_dw = ch.fh.rec_dw;
             fc.n_groups = (int)ch.fh.fg.size();
@@ -1996,8 +1997,7 @@ void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int& n_split, int& n
 {
     long long want = split_wanted(N);
     for (int c = 0; c < pl->n_classes; ++c) {
-        want = std::min<long long>(want, pl->cls[c].n_groups);
-        if (pl->cls[c].halves) want = 1;       // a group is two consecutive entries there: no group ranges
+        want = std::min<long long>(want, pl->cls[c].n_groups / pl->cls[c].n_pass);   // (groups of sources, not entries)
     }
     const bool gsplit = generic_can_split(pl);
     if (gsplit) want = std::min<long long>(want, pl->n_groups);

@@ -140,12 +140,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass)
 {
     // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
-    // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel)
-    const int g_lo = (int)((long long)n_groups * blockIdx.y / gridDim.y);
-    const int g_hi = (int)((long long)n_groups * (blockIdx.y + 1) / gridDim.y);
+    // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel);
+    // a multi-residency class is cut between groups of sources (n_pass consecutive entries each)
+    const int g_lo = (int)((long long)(n_groups / n_pass) * blockIdx.y / gridDim.y) * n_pass;
+    const int g_hi = (int)((long long)(n_groups / n_pass) * (blockIdx.y + 1) / gridDim.y) * n_pass;
     out_beam += (size_t)blockIdx.y * (size_t)split_stride;
     out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     extern __shared__ float lds[];
@@ -779,7 +780,8 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
                                            (int)BP_LDS_MAX));                                      \
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
-            fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0);  \
+            fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0,   \
+            fc.halves ? fc.n_pass : 1);                                                               \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
     else if (fc.tile == 256 && fc.halves) { if (fc.uniform) BPF_LAUNCH(true, 4, true); else BPF_LAUNCH(false, 4, true); }

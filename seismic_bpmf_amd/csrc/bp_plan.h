@@ -50,7 +50,8 @@ constexpr int BPF_ZERO_SLAB = 512, BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
 struct BpFastClass {
     int tile = 512;              // 512 / 256 / 128 time samples per workgroup
     bool uniform = false;        // every source's non-zero weights are equal: ready-made addresses
-    bool halves = false;         // groups of <= 96 sources computed in 2-4 LDS residencies (<= 20 stations each)
+    bool halves = false;         // groups of <= 144 sources computed in 2-4 LDS residencies (<= 20 stations each)
+    int n_pass = 1;              // halves: consecutive entries of d_groups per group of sources
     int rec_dw = 0;              // dwords per record
     int n_groups = 0;
     int desc_waves = 1;          // waves that copy the next group's window descriptors

@@ -462,6 +462,34 @@ def test_bp_two_residency_groups_for_33_to_40_stations(oracle_lib, n_used, unifo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [-1, 2, 5])
+@pytest.mark.parametrize("n_used", [40, 52])
+def test_bp_multi_residency_class_on_a_short_series_is_cut_between_groups(oracle_lib, split, n_used, hip_opts):
+    """A short series (few tiles) deals the groups of a class to several workgroups per tile; a
+    multi-residency class must be cut between GROUPS of sources (2-3 consecutive plan entries each),
+    never inside one."""
+    from seismic_bpmf_amd import BeamformerGPU
+    hip_opts("bp.split", split)
+    rng = np.random.default_rng(900 + n_used + split)
+    K, S, C, P, N = 1100, 56, 2, 2, 3300
+    f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4
+    tau = (rng.integers(0, 60, (1, S, P)) + rng.integers(-4, 5, (K, S, P))).astype(np.int32)
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = np.zeros((K, S), np.float32)
+    for k in range(K):
+        ws[k, rng.choice(S, n_used - (k % 3), replace=False)] = 0.25
+    bf = BeamformerGPU(tau, ws)
+    info = bf.plan_info()
+    assert info["class_tile"][0] == 256 and info["class_groups"][0] >= 4, info
+    for oob in ("strict", "flexible"):
+        b, a = bf.run(f, wp, "max", oob)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        assert np.array_equal(b.cpu().numpy(), ob), (split, n_used, oob, info)
+        assert np.array_equal(a.cpu().numpy(), oa), (split, n_used, oob, info)
+    bf.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tile", [512, 256, 128])
 @pytest.mark.parametrize("uniform", [True, False])
 def test_bp_fast_path_every_part_size_on_every_tile(oracle_lib, tile, uniform, hip_opts):
