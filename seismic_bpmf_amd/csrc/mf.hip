@@ -26,30 +26,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ preparation ---
 
-// r_t[t,s,c] = 1 / sqrtf(E_t),  E_t = fmaf chain of tmpl^2 over l ascending.
-__global__ void mf_template_energy_kernel(const float* __restrict__ tmpl, size_t n_rows, int L,
-                                          float* __restrict__ e_t)
+// Per template, one workgroup: r_t[t,s,c] = 1 / sqrtf(E_t), E_t = the fmaf chain of tmpl^2 over l
+// ascending (the threads take the channels); then thread 0 writes the valid lag range [first, last]
+// (first > last = empty) and the template's compact list of used channels, one int4 {channel, moveout,
+// weight bits, r_t bits} per channel with w != 0, in channel order, closed by two {-1,..} sentinels: the
+// main kernel walks it with one (prefetched) scalar load per channel instead of chasing weights /
+// moveouts / norms through dependent loads.  (Rounds 1-2: two launches; an hour-long search of a
+// handful of templates -- BASELINE configs[0] -- is dependent launches of which the main kernel takes
+// 63 of 79 us, and a hipGraph of them is no faster: tools/probe_mf_graph.py.)
+__global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict__ tmpl, const int* __restrict__ mv,
+                                                         const float* __restrict__ w, int T, int n_ch, long long step,
+                                                         long long L, long long N, long long n_corr, int exclusive_last,
+                                                         float* __restrict__ e_t, int2* __restrict__ range,
+                                                         int4* __restrict__ chan_rec)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    const float* x = tmpl + i * (size_t)L;
-    float acc = 0.0f;
-    for (int l = 0; l < L; ++l) acc = __fmaf_rn(x[l], x[l], acc);
-    e_t[i] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
-}
-
-// Valid lag range [first, last] of each template (first > last = empty).
-// Also writes the template's compact list of used channels, one int4 {channel, moveout,
-// weight bits, r_t bits} per channel with w != 0, in channel order, closed by two {-1,..}
-// sentinels: the main kernel walks it with one (prefetched) scalar load per channel instead of
-// chasing weights / moveouts / norms through dependent loads.
-__global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restrict__ w,
-                                const float* __restrict__ r_t, int T, int n_ch, long long step,
-                                long long L, long long N, long long n_corr, int exclusive_last,
-                                int2* __restrict__ range, int4* __restrict__ chan_rec)
-{
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
+    const int t = blockIdx.x;
+    for (int ch = threadIdx.x; ch < n_ch; ch += 64) {
+        const float* x = tmpl + ((size_t)t * n_ch + ch) * (size_t)L;
+        float acc = 0.0f;
+        for (int l = 0; l < (int)L; ++l) acc = __fmaf_rn(x[l], x[l], acc);
+        e_t[(size_t)t * n_ch + ch] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
+    }
+    __syncthreads();       // (workgroup-scope release / acquire: thread 0 reads what the others stored)
+    if (threadIdx.x != 0) return;
     long long mv_min = 0, mv_max = 0;
     bool any = false;
     int4* rec = chan_rec + (size_t)t * (n_ch + 2);
@@ -58,7 +57,8 @@ __global__ void mf_range_kernel(const int* __restrict__ mv, const float* __restr
         const float wc = w[(size_t)t * n_ch + ch];
         if (wc == 0.0f) continue;
         long long m = mv[(size_t)t * n_ch + ch];
-        rec[n_used++] = make_int4(ch, (int)m, __float_as_int(wc), __float_as_int(r_t[(size_t)t * n_ch + ch]));
+        rec[n_used++] = make_int4(ch, (int)m, __float_as_int(wc),
+                                  __float_as_int(((volatile const float*)e_t)[(size_t)t * n_ch + ch]));
         if (!any || m < mv_min) mv_min = m;
         if (!any || m > mv_max) mv_max = m;
         any = true;
@@ -944,14 +944,10 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             return rc;
     }
     {
-        size_t n = T * n_ch;
-        mf_template_energy_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(
-            d_templates, n, (int)L, ws.e_t);
-        BPMF_LAUNCH_CHECK();
-        mf_range_kernel<<<dim3((unsigned)((T + 63) / 64)), dim3(64), 0, stream>>>(
-            d_moveouts, d_weights, ws.e_t, (int)T, (int)n_ch, (long long)step, (long long)L,
-            (long long)N, (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0, ws.range,
-            ws.chan_rec);
+        // template norms, lag ranges, channel records: one launch, one workgroup per template
+        mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(
+            d_templates, d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
+            (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
         BPMF_LAUNCH_CHECK();
     }
     if (!network_sum)
