@@ -13,17 +13,22 @@
 //   * records hold ready-made LDS byte addresses when the source weights are uniform per source
 //     (0/1 or row-normalised weights -- what Beamformer.set_weights_sources produces without
 //     density weighting): a unit's address is ONE v_add, no unpacking.
-//   * THE GATHER PIPELINE NEVER DRAINS AT A SOURCE BOUNDARY.  Round 1 kept a source's record in
-//     SGPRs; scalar loads share lgkmcnt with the LDS and return out of order, so the record of
-//     the next source could only be fetched behind an lgkmcnt(0), i.e. with no gather in flight:
-//     every source paid a drain, a scalar-cache round trip and a pipeline refill (the inner loop
-//     alone reaches 78 % of the ds_read_b64 rate with the max update, the kernel reached 67 %).
-//     Here the record lives in VGPRs (wave-uniform values) and is refilled by VECTOR loads, which
-//     have their own in-order counter (vmcnt): quad q of the record (4 dwords = 4 units) is
-//     re-loaded with the next source's quad as soon as its units have been accumulated, and the
-//     first three units of the next source are issued while the last three of the current one are
-//     still in flight -- 12 gathers stay outstanding across the whole run of sources, and the
-//     max / arg-max update of a source runs under the next source's gathers.
+//   * THE RECORD OF THE NEXT SOURCE IS NEVER WAITED FOR WITH ITS LATENCY EXPOSED.  Round 1 kept a
+//     source's record in SGPRs and fetched the next one behind an lgkmcnt(0) at the source boundary
+//     (scalar loads share lgkmcnt with the LDS and return out of order): every source paid a drain,
+//     a scalar-cache round trip and a pipeline refill (67 % of the ds_read_b64 rate).  Round 2 moved
+//     the record into VGPRs, refilled quad by quad with wave-uniform VECTOR loads (their own in-order
+//     counter, vmcnt), the first three units of the next source issued while the last three of the
+//     current one are in flight: no drain at all, 70-71 % -- but every such load costs 16 cycles of
+//     the vector memory path (64 lanes x 16 bytes, however uniform the address), per group more than
+//     the gathers cost the LDS (cycle counters of round 3, profiles/r03_bp_fast_phase_cycles.txt).
+//     Round 3 (walk_g / walk_s): SGPR records again, TWO buffers -- the next record is requested with
+//     s_load_dwordx8 at the START of the current part and waited for once, where the look-ahead first
+//     needs it; that lgkmcnt(0) drains the wave's own gathers, a bubble the other 15 waves cover, and
+//     the scalar-cache round trip is long over.  73-75 % at tile 512, +6-9 % at tile 256, and the
+//     20-28 VGPRs of the ring are free.  Records of more than 16 stations (tile 128) keep the VGPR
+//     ring (walk): the max / arg-max update of a source runs under the next source's gathers in
+//     every variant.
 //   * the record pointer advances by a constant (tables are padded by one round of records, so the
 //     prefetch of the source after the last needs no clamp): 2 SALU per source.
 //   * the accumulators start from the fma's own constant-0 addend (no zero-init moves), and the
