@@ -1488,7 +1488,7 @@ bool build_fast_host(const PlanHost& ph, int tile, bool allow_uniform, FastHost&
         }
         fh.fg.push_back(f);
     }
-    fh.rec.resize(fh.rec.size() + (size_t)16 * rec_dw, 0);        // one round of records: the prefetch past the last part
+    fh.rec.resize(fh.rec.size() + (size_t)17 * rec_dw, 0);        // one round of records (+ 1: whole s_load_dwordx8): the prefetch past the last part
     fh.fw.resize(fh.fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});   // the descriptor prefetch past the last group
     return true;
 }
@@ -1570,7 +1570,9 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
         }
         fh.fg.push_back(f);
     }
-    fh.rec.resize(fh.rec.size() + (size_t)16 * rec_dw, 0);
+    // one round of records behind the last one (the look-ahead past a wave's last part), and one more
+    // record: the kernel fetches a record in whole s_load_dwordx8 (24 dwords where rec_dw is 20)
+    fh.rec.resize(fh.rec.size() + (size_t)17 * rec_dw, 0);
     fh.fw.resize(fh.fw.size() + BPF_DESC_MAX, BpWindow{0, 0, 0, 0});
     return true;
 }
