@@ -11,6 +11,7 @@
 // evaluated with the exact-fp32 v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain; the band's
 // zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
+#include <system_error>
 #include <thread>
 #include <chrono>
 #include <vector>
@@ -1066,7 +1067,12 @@ void parallel_copy(char* dst, const char* src, size_t bytes)
     for (size_t i = 0; i < nth; ++i) {
         const size_t o = i * per;
         if (o >= bytes) break;
-        th.emplace_back([=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); });
+        auto piece = [=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); };
+        try {
+            th.emplace_back(piece);
+        } catch (const std::system_error&) {
+            piece();               // no thread to be had (process / cgroup limit): this piece is copied here
+        }
     }
     for (auto& t : th) t.join();
 }

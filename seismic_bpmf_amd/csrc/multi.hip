@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -96,15 +97,33 @@ int run_blocks(size_t n_blocks, Fn fn)
 {
     std::vector<int> rc(n_blocks, 0);
     std::vector<std::string> msg(n_blocks);
+    // Nothing may leave a worker as an exception (an exception that escapes a std::thread, or one thrown
+    // while joinable threads are alive, ends the process with std::terminate -- the "Aborted" that the
+    // 8-process fuzz sessions of round 3 saw once in ~1 000 multi-device calls, profiles/r03_fuzz_long.txt).
     auto work = [&](size_t i) {
-        rc[i] = fn(i);
-        if (rc[i]) msg[i] = bpmf_last_error();
+        try {
+            rc[i] = fn(i);
+            if (rc[i]) msg[i] = bpmf_last_error();
+        } catch (const std::exception& e) {
+            rc[i] = -3;
+            msg[i] = std::string("exception in a device block: ") + e.what();
+        } catch (...) {
+            rc[i] = -3;
+            msg[i] = "unknown exception in a device block";
+        }
     };
     if (n_blocks == 1) {
         work(0);
     } else {
         std::vector<std::thread> th;
-        for (size_t i = 0; i < n_blocks; ++i) th.emplace_back(work, i);
+        th.reserve(n_blocks);
+        for (size_t i = 0; i < n_blocks; ++i) {
+            try {
+                th.emplace_back(work, i);
+            } catch (const std::system_error&) {
+                work(i);           // no thread to be had (process / cgroup limit): this block runs here
+            }
+        }
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < n_blocks; ++i)
@@ -182,9 +201,11 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
     // (option bp.compat_first_computed: a device's result carries (0, first id) where it computed no
     // beam, which the host merge cannot tell from a real 0 -- the switch runs on one device)
     if (bpmf::option(bpmf::OPT_BP_COMPAT_FIRST_COMPUTED) != 0 && dev.size() > 1) dev.resize(1);
-    if (dev.size() == 1)
-        return bpmf_bp_run(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds,
-                           reduce, dev[0], beam_out, arg_out);
+    if (dev.size() == 1)   // (through run_blocks: its exception barrier)
+        return run_blocks(1, [&](size_t) -> int {
+            return bpmf_bp_run(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds,
+                               reduce, dev[0], beam_out, arg_out);
+        });
     // block 0 writes into the caller's arrays, the others into scratch vectors
     std::vector<std::vector<float>> pb(dev.size());
     std::vector<std::vector<int32_t>> pa(dev.size());
@@ -216,7 +237,13 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
     if (tb.size() == 2) {
         merge(0, N);
     } else {
-        for (size_t q = 0; q + 1 < tb.size(); ++q) th.emplace_back(merge, tb[q], tb[q + 1]);
+        for (size_t q = 0; q + 1 < tb.size(); ++q) {
+            try {
+                th.emplace_back(merge, tb[q], tb[q + 1]);
+            } catch (const std::system_error&) {
+                merge(tb[q], tb[q + 1]);
+            }
+        }
         for (auto& t : th) t.join();
     }
     return 0;
