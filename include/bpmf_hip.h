@@ -53,6 +53,21 @@ int bpmf_device_info(int device, char *name, size_t name_len, size_t *total_mem_
 void bpmf_profile_enable(int enable); /* enabling clears the log; disabling keeps it */
 int bpmf_profile_count(int which_kernel); /* launches logged since enable */
 int bpmf_profile_get_ms(int which_kernel, int launch_index, float *milliseconds);
+/* The device that launch ran on (-1: no such launch).  Launches made by several host threads (the
+ * *_multi entry points: one thread per GPU) are logged per thread and per device: a start edge and
+ * a stop edge pair up only on the thread that recorded both. */
+int bpmf_profile_get_device(int which_kernel, int launch_index);
+
+/* The host-pointer entry points (bpmf_mf_run, bpmf_bp_run, their *_multi forms,
+ * bpmf_find_similar_sources) keep, per device and process: two private streams, a side stream, four
+ * events, two pinned staging pieces and the device working set of the largest recent call -- created
+ * once, reused by every call, never destroyed while the library is loaded; calls on one device take
+ * turns (the reference's counterpart: the third-party back-ends allocate and free per call,
+ * BPMF/similarity_search.py:526-533, BPMF/template_search.py:549-558).  bpmf_release_device_memory
+ * gives the working set and the pinned pieces back (device < 0: every device; waits for a running
+ * call); bpmf_device_memory_held reports what is held right now.  The *_dev entry points hold nothing. */
+int bpmf_release_device_memory(int device);
+int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_bytes);
 
 /* Execution options.  The library reads NOTHING from the environment.  An option selects among
  * code paths and sizes that produce identical results (kernel family, LDS budget, batch sizes of

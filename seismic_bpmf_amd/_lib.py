@@ -34,6 +34,9 @@ SIGNATURES = {
     "bpmf_profile_enable": (None, [C.c_int]),
     "bpmf_profile_count": (C.c_int, [C.c_int]),
     "bpmf_profile_get_ms": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "bpmf_profile_get_device": (C.c_int, [C.c_int, C.c_int]),
+    "bpmf_release_device_memory": (C.c_int, [C.c_int]),
+    "bpmf_device_memory_held": (C.c_int, [C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
     "bpmf_mf_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _sz]),
     "bpmf_mf_prepare_data_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp]),
     "bpmf_mf_run_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int,
@@ -167,8 +170,25 @@ class options:
         return False
 
 
+def release_device_memory(device=-1):
+    """Give back the working set and pinned pieces the host-pointer calls keep on `device` (-1: all)."""
+    check(lib().bpmf_release_device_memory(int(device)), "bpmf_release_device_memory")
+
+
+def device_memory_held(device=-1):
+    """(device bytes, pinned host bytes) the host-pointer calls hold between calls."""
+    dv, pn = _sz(0), _sz(0)
+    check(lib().bpmf_device_memory_held(int(device), C.byref(dv), C.byref(pn)), "bpmf_device_memory_held")
+    return dv.value, pn.value
+
+
 def profile_enable(on=True):
     lib().bpmf_profile_enable(1 if on else 0)
+
+
+def profile_devices(which):
+    """The device of every logged launch of dominant kernel `which` (same order as profile_times_ms)."""
+    return [lib().bpmf_profile_get_device(which, i) for i in range(lib().bpmf_profile_count(which))]
 
 
 def profile_times_ms(which):

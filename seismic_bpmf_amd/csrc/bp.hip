@@ -16,6 +16,7 @@
 //      (max, arg-max) per time sample: no atomics, no cross-workgroup merge, and the
 //      sequential source order gives the "lowest index wins ties" rule for free.
 #include "bp_plan.h"
+#include "context.h"
 #include <mutex>
 #include <cstring>
 #include <type_traits>
@@ -1876,12 +1877,15 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                         c, fc.tile, fc.n_sources, fc.max_stations, fc.n_groups, ch.fh.fr.size(), (int)fc.uniform, fc.rec_dw);
         }
         if (rc) { bpmf_bp_plan_destroy(pl); return rc; }
-        hipError_t e1 = hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking);
+        // the side stream is the device's (context.h: created once per device, never destroyed);
+        // the fork / join events are the plan's own
+        pl->side_stream = device_side_stream(device);
+        if (!pl->side_stream) { bpmf_bp_plan_destroy(pl); return -2; }
         hipError_t e2 = hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming);
         hipError_t e3 = hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-            set_error("bpmf_bp_plan_create: side stream / events: %s",
-                      hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+        if (e2 != hipSuccess || e3 != hipSuccess) {
+            set_error("bpmf_bp_plan_create: fork / join events: %s",
+                      hipGetErrorString(e2 != hipSuccess ? e2 : e3));
             bpmf_bp_plan_destroy(pl);
             return -2;
         }
@@ -1912,7 +1916,6 @@ extern "C" void bpmf_bp_plan_destroy(bpmf_bp_plan* pl)
     (void)hipFree(pl->d_termsv);
     (void)hipFree(pl->d_recs);
     (void)hipFree(pl->d_hdr2);
-    if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
     if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
     if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
     for (int c = 0; c < BPF_MAX_CLASSES; ++c) free_fast_class(pl->cls[c]);
@@ -1975,29 +1978,30 @@ bool generic_can_split(const bpmf_bp_plan* pl)
     return pl->nsv == 4 || pl->nsv == 8 || pl->nsv == 12 || pl->nsv == 16 || pl->nsv == 32;   // dispatch_beam<2>'s packed kernels
 }
 
-long long split_wanted(size_t N)
+// `forced` = option bp.split as the CALLER read it (once per call: the size check of the workspace and the
+// launches must see the same value even if another thread sets the option in between)
+long long split_wanted(size_t N, int forced)
 {
     const long long n_tiles = (long long)((N + 511) / 512);
     // enough workgroups for ~4 rounds over the 256 CUs (a split costs one merge pass and nothing else:
     // the ranges stage disjoint windows), none from 1024 tiles (N >= 524 288) on
     long long want = n_tiles >= 1024 ? 1 : (1024 + n_tiles - 1) / n_tiles;
-    const int forced = (int)option(OPT_BP_SPLIT);   // read per call: the tests switch it
     if (forced >= 0) want = forced < 1 ? 1 : forced;
     return want;
 }
 
 // the general kernels alone (reduce="none", plans without interior classes)
-int bp_split_count(const bpmf_bp_plan* pl, size_t N)
+int bp_split_count(const bpmf_bp_plan* pl, size_t N, int forced)
 {
     if (!pl || !generic_can_split(pl)) return 1;
-    return (int)std::max<long long>(1, std::min<long long>(split_wanted(N), pl->n_groups));
+    return (int)std::max<long long>(1, std::min<long long>(split_wanted(N, forced), pl->n_groups));
 }
 
 // reduce="max" on a plan with interior classes: group ranges per tile of every class kernel, and of
 // the general kernel on the edge tiles (1 when that kernel cannot split)
-void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int& n_split, int& n_split_edge)
+void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int forced, int& n_split, int& n_split_edge)
 {
-    long long want = split_wanted(N);
+    long long want = split_wanted(N, forced);
     for (int c = 0; c < pl->n_classes; ++c) {
         want = std::min<long long>(want, pl->cls[c].n_groups / pl->cls[c].n_pass);   // (groups of sources, not entries)
     }
@@ -2008,20 +2012,27 @@ void bp_fast_split_counts(const bpmf_bp_plan* pl, size_t N, int& n_split, int& n
 }
 }  // namespace
 
-extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size_t C)
+namespace {
+// workspace of one call under bp.split = `forced`: the prestacked traces + the partial maxima, one row per
+// group range of a short series (bp_split_count) and per station-count class of the interior kernel
+size_t bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, int forced)
 {
-    (void)C;
-    if (!pl) return 0;
-    // the prestacked traces + the partial maxima: one row per group range of a short series
-    // (bp_split_count) and per station-count class of the interior kernel
-    size_t rows = pl->direct ? (size_t)direct_split_count(pl, N) : (size_t)bp_split_count(pl, N);
+    size_t rows = pl->direct ? (size_t)direct_split_count(pl, N) : (size_t)bp_split_count(pl, N, forced);
     if (pl->fast) {
         int n_split, n_split_edge;
-        bp_fast_split_counts(pl, N, n_split, n_split_edge);
+        bp_fast_split_counts(pl, N, forced, n_split, n_split_edge);
         rows = std::max(rows, (size_t)n_split * (size_t)pl->n_classes);
     }
     return align_up(pl->S * pl->P * N * sizeof(float), 256) +
            (rows > 1 ? align_up(rows * N * (sizeof(float) + sizeof(int32_t)), 256) : 0);
+}
+}  // namespace
+
+extern "C" size_t bpmf_bp_workspace_bytes(const bpmf_bp_plan* pl, size_t N, size_t C)
+{
+    (void)C;
+    if (!pl) return 0;
+    return bp_workspace_bytes(pl, N, (int)option(OPT_BP_SPLIT));
 }
 
 namespace {
@@ -2036,6 +2047,9 @@ thread_local long long t_split_stride = 0;       // elements between the partial
 // becomes the maximum) or -inf (option bp.compat_first_computed: the maximum over the computed
 // beams whatever their sign; samples without any computed beam are set to (0, first id) at the end)
 thread_local float t_best0 = 0.0f;
+}  // namespace
+namespace bpmf { thread_local bool t_bp_defer_finish = false; }
+namespace {
 
 // tiles [base, base + count) of a kernel with `tile` samples per workgroup
 inline void tile_range(size_t N, size_t tile, long long& base, long long& count)
@@ -2280,8 +2294,11 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         set_error("bpmf_bp_run_dev: N exceeds the int32 index range");
         return -1;
     }
-    if (workspace_bytes < bpmf_bp_workspace_bytes(pl, N, C)) {
-        set_error("bpmf_bp_run_dev: workspace too small");
+    // option bp.split is read ONCE: the size check and every launch below use this value
+    const int forced_split = (int)option(OPT_BP_SPLIT);
+    if (workspace_bytes < bp_workspace_bytes(pl, N, forced_split)) {
+        set_error("bpmf_bp_run_dev: workspace too small (%zu < %zu)", workspace_bytes,
+                  bp_workspace_bytes(pl, N, forced_split));
         return -1;
     }
     float* U = (float*)d_workspace;
@@ -2306,7 +2323,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         ~Best0Scope() { t_best0 = 0.0f; }
     } best0_scope(first_computed ? -INFINITY : 0.0f);
     auto finish = [&](float* beam, int32_t* arg) -> int {
-        if (first_computed) {
+        if (first_computed && !t_bp_defer_finish) {
             bp_finish_first_computed_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
                 beam, arg, N, pl->id_offset);
             BPMF_LAUNCH_CHECK();
@@ -2340,7 +2357,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         // sources.  Several classes, or several group ranges per tile on a short series, write
         // partial rows behind the prestack, folded by one merge launch (value, then lowest id).
         int n_split, n_split_edge;
-        bp_fast_split_counts(pl, N, n_split, n_split_edge);
+        bp_fast_split_counts(pl, N, forced_split, n_split, n_split_edge);
         const int rows = n_split * pl->n_classes;
         long long lo_s = pl->tmin_all < 0 ? ((long long)(-pl->tmin_all) + 1023) / 1024 * 1024 : 0;
         long long hi_s = ((long long)N - pl->tmax_all - 8) / 1024 * 1024;
@@ -2393,7 +2410,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
     }
     // the general kernels over the whole series.  Short series: several group ranges per tile
     // (bp_split_count); reduce="max" goes through partial rows and one merge launch
-    const int n_split = bp_split_count(pl, N);
+    const int n_split = bp_split_count(pl, N, forced_split);
     SplitScope split_scope(n_split, n_split > 1 && reduce == BPMF_BP_REDUCE_MAX ? (long long)N : 0);
     if (n_split > 1 && reduce == BPMF_BP_REDUCE_MAX) {
         d_beam_out = (float*)part;
@@ -2473,12 +2490,17 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     // Every call binds its thread to `device` first: the plan cache below may skip
     // bpmf_bp_plan_create, and a fresh host thread starts on device 0.
     BPMF_BIND_DEVICE(device);
+    // One host-pointer call per device at a time, on the device's own streams and working set
+    // (context.h): nothing is created or destroyed per call, nothing runs on the null stream.
+    DeviceContext* ctx = device_context(device);
+    if (!ctx) return -2;
+    std::lock_guard<std::mutex> call_lock(ctx->call_mutex);
     // BPMF calls beamform once per day with the same moveout table and source weights
     // (template_search.py:549-558); building the plan costs 0.04 s for 50 000 sources but 3 s for a
     // million, so the last plans are kept.
     bpmf_bp_plan* pl = nullptr;
     const size_t b_mv = K * S * P * sizeof(int32_t), b_wsrc = K * S * sizeof(float);
-    // (the option generation is part of the key: a plan is built under the options of its creation,
+    // (the plan generation is part of the key: a plan is built under the options of its creation,
     // and bpmf_set_option must not leave a plan of the previous settings in use)
     const uint64_t key = hash_words(moveouts, b_mv, 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
                          hash_words(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full) ^
@@ -2521,9 +2543,12 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
             slot = &g_plan_cache.back();
         }
         if (!slot) {
+            // the least recently used plan OF THIS DEVICE goes (its calls are serialised by the
+            // context mutex this thread holds, so nobody can be about to take it); a cache filled
+            // by other devices' plans is left alone
             for (auto& e : g_plan_cache)
-                if (e.pl && (!slot || e.stamp < slot->stamp)) slot = &e;
-            if (!slot) {               // every slot reserved by a concurrent call: do not cache
+                if (e.pl && e.device == device && (!slot || e.stamp < slot->stamp)) slot = &e;
+            if (!slot) {
                 bpmf_bp_plan_destroy(pl);
                 return;
             }
@@ -2549,15 +2574,14 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     const size_t o_f = 0, o_wp = o_f + align_up(b_f, 256), o_ws = o_wp + align_up(b_wp, 256),
                  o_beam = o_ws + align_up(b_ws, 256), o_arg = o_beam + align_up(b_beam, 256),
                  total = o_arg + b_arg;
-    char* base = nullptr;
-    hipError_t e = hipMalloc((void**)&base, total);
-    if (e != hipSuccess) {
-        set_error("bpmf_bp_run: hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    char* base = ctx->reserve_device(total);
+    if (!base) {
         release_plan();
         return -2;
     }
     int rc = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = ctx->s_run;
+    hipError_t e = hipSuccess;
     auto fail = [&](hipError_t err, const char* what) {
         set_error("bpmf_bp_run: %s failed: %s", what, hipGetErrorString(err));
         rc = -2;
@@ -2573,8 +2597,10 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     if (!rc && (e = hipMemcpyAsync(beam_out, base + o_beam, b_beam, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H beam");
     if (!rc && reduce == BPMF_BP_REDUCE_MAX && arg_out &&
         (e = hipMemcpyAsync(arg_out, base + o_arg, b_arg, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H argmax");
-    if (!rc && (e = hipStreamSynchronize(stream)) != hipSuccess) fail(e, "synchronize");
-    (void)hipFree(base);
+    // (always drained, also after a failure: the working set and the plan go back to their caches)
+    hipError_t es = hipStreamSynchronize(stream);
+    if (pl->side_stream) (void)hipStreamSynchronize(pl->side_stream);
+    if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
     return rc;
 }

@@ -105,6 +105,8 @@ struct bpmf_bp_plan {
     // the few edge tiles of a day run the general kernel on a side stream, beside the interior
     // kernel (fork / join through the two events): a serial launch of 3-6 workgroups would add the
     // full duration of one tile (5 ms at cfg3) to every call.  A plan serves one call at a time.
+    // The stream belongs to the device (context.h: one per device and process, shared by its plans, never
+    // destroyed); the events are the plan's own.
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Two host threads may run the same resident plan on different streams: the fork / join
@@ -114,6 +116,10 @@ struct bpmf_bp_plan {
 };
 
 namespace bpmf {
+// bp.hip, option bp.compat_first_computed: set by bpmf_bp_run_multi on the thread that runs a device's
+// share -- the share keeps -inf where it computed no beam, and the host finishes (0, first id) after
+// the merge of all shares (a finished share could not be told from a real 0)
+extern thread_local bool t_bp_defer_finish;
 // bp_fast.hip: running (max, arg-max) over the sources of one class for its tiles [tile_lo, tile_hi)
 // (units of fc.tile samples), every one of which lies inside [-tmin_all, N - tmax_all) (no bounds
 // test per source).

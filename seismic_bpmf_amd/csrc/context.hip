@@ -1,0 +1,182 @@
+// Per-device context of the host-pointer entry points: see context.h.
+#include "context.h"
+#include "../../include/bpmf_hip.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace bpmf {
+namespace {
+std::mutex g_registry_mutex;
+std::vector<DeviceContext*> g_contexts;     // by device index; entries live until the process ends
+
+constexpr size_t DEV_GRANULE = (size_t)2 << 20;
+constexpr size_t SHRINK_ABOVE = (size_t)1 << 30;   // a cached block this large is given back ...
+constexpr size_t SHRINK_RATIO = 4;                 // ... when a call needs less than 1/4 of it
+
+void drain(DeviceContext* c)
+{
+    if (c->s_run) (void)hipStreamSynchronize(c->s_run);
+    if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
+    if (c->s_side) (void)hipStreamSynchronize(c->s_side);
+}
+}  // namespace
+
+char* DeviceContext::reserve_device(size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 256);
+    const bool too_small = bytes > dev_cap;
+    const bool too_large = dev_cap >= SHRINK_ABOVE && bytes < dev_cap / SHRINK_RATIO;
+    if (dev_buf && !too_small && !too_large) return dev_buf;
+    if (dev_buf) {
+        drain(this);
+        (void)hipFree(dev_buf);
+        dev_buf = nullptr;
+        dev_cap = 0;
+    }
+    // growth with slack (a sequence of slightly larger calls does not reallocate every time)
+    size_t want = too_small && bytes < SHRINK_ABOVE ? bytes + bytes / 8 : bytes;
+    want = align_up(want, DEV_GRANULE);
+    hipError_t e = hipMalloc((void**)&dev_buf, want);
+    if (e != hipSuccess && want > bytes) {          // the slack is a convenience, not a need
+        (void)hipGetLastError();
+        want = align_up(bytes, 256);
+        e = hipMalloc((void**)&dev_buf, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dev_buf = nullptr;
+        set_error("device %d: hipMalloc(%zu) for the working set failed: %s", device, want, hipGetErrorString(e));
+        return nullptr;
+    }
+    dev_cap = want;
+    return dev_buf;
+}
+
+int DeviceContext::reserve_pinned(size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 4096);
+    if (pinned[0] && pinned[1] && bytes <= pinned_cap) return 0;
+    drain(this);
+    for (int i = 0; i < 2; ++i) {
+        if (pinned[i]) (void)hipHostFree(pinned[i]);
+        pinned[i] = nullptr;
+    }
+    pinned_cap = 0;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipHostMalloc((void**)&pinned[i], bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("device %d: hipHostMalloc(%zu) failed: %s", device, bytes, hipGetErrorString(e));
+            if (i == 1) { (void)hipHostFree(pinned[0]); pinned[0] = nullptr; }
+            pinned[i] = nullptr;
+            return -2;
+        }
+    }
+    pinned_cap = bytes;
+    return 0;
+}
+
+void DeviceContext::release_memory()
+{
+    drain(this);
+    if (dev_buf) (void)hipFree(dev_buf);
+    dev_buf = nullptr;
+    dev_cap = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (pinned[i]) (void)hipHostFree(pinned[i]);
+        pinned[i] = nullptr;
+    }
+    pinned_cap = 0;
+}
+
+DeviceContext* device_context(int device)
+{
+    std::lock_guard<std::mutex> g(g_registry_mutex);
+    if (device < 0) {
+        set_error("device %d out of range", device);
+        return nullptr;
+    }
+    if ((size_t)device < g_contexts.size() && g_contexts[device]) return g_contexts[device];
+    int visible = 0;
+    hipError_t e = hipGetDeviceCount(&visible);
+    if (e != hipSuccess || device >= visible) {
+        set_error("device %d out of range (%d visible%s%s)", device, visible, e != hipSuccess ? ": " : "",
+                  e != hipSuccess ? hipGetErrorString(e) : "");
+        return nullptr;
+    }
+    DeviceGuard bind(device);
+    if (bind.error() != hipSuccess) {
+        set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(bind.error()));
+        return nullptr;
+    }
+    DeviceContext* c = new DeviceContext();
+    c->device = device;
+    hipError_t err = hipSuccess;
+    auto step = [&](hipError_t r) { if (err == hipSuccess) err = r; };
+    step(hipStreamCreateWithFlags(&c->s_run, hipStreamNonBlocking));
+    step(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+    step(hipStreamCreateWithFlags(&c->s_side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        step(hipEventCreateWithFlags(&c->ev_batch[i], hipEventDisableTiming));
+        step(hipEventCreateWithFlags(&c->ev_piece[i], hipEventDisableTiming));
+    }
+    if (err != hipSuccess) {
+        // (a half-built context is dropped without destroying what exists: this path means the
+        // runtime is already in trouble, and the objects are a few hundred bytes)
+        set_error("device %d: creating the streams / events of the host entry points failed: %s", device,
+                  hipGetErrorString(err));
+        delete c;
+        return nullptr;
+    }
+    if (g_contexts.size() <= (size_t)device) g_contexts.resize((size_t)device + 1, nullptr);
+    g_contexts[device] = c;
+    return c;
+}
+
+hipStream_t device_side_stream(int device)
+{
+    DeviceContext* c = device_context(device);
+    return c ? c->s_side : nullptr;
+}
+
+}  // namespace bpmf
+
+// Gives back what the host-pointer entry points keep between calls on `device` (all devices when
+// device < 0): the device working set and the pinned staging pieces.  Waits for a running call.
+extern "C" int bpmf_release_device_memory(int device)
+{
+    std::vector<bpmf::DeviceContext*> todo;
+    {
+        std::lock_guard<std::mutex> g(bpmf::g_registry_mutex);
+        if (device >= 0 && ((size_t)device >= bpmf::g_contexts.size() || !bpmf::g_contexts[device])) return 0;
+        for (size_t d = 0; d < bpmf::g_contexts.size(); ++d)
+            if (bpmf::g_contexts[d] && (device < 0 || (size_t)device == d)) todo.push_back(bpmf::g_contexts[d]);
+    }
+    for (bpmf::DeviceContext* c : todo) {
+        std::lock_guard<std::mutex> call(c->call_mutex);
+        bpmf::DeviceGuard bind(c->device);
+        if (bind.error() != hipSuccess) {
+            bpmf::set_error("bpmf_release_device_memory: hipSetDevice(%d) failed: %s", c->device,
+                            hipGetErrorString(bind.error()));
+            return -2;
+        }
+        c->release_memory();
+    }
+    return 0;
+}
+
+extern "C" int bpmf_device_memory_held(int device, size_t* device_bytes, size_t* pinned_bytes)
+{
+    std::lock_guard<std::mutex> g(bpmf::g_registry_mutex);
+    size_t dv = 0, pn = 0;
+    for (size_t d = 0; d < bpmf::g_contexts.size(); ++d) {
+        const bpmf::DeviceContext* c = bpmf::g_contexts[d];
+        if (!c || (device >= 0 && (size_t)device != d)) continue;
+        dv += c->dev_cap.load();               // (atomics: read without the call mutex)
+        pn += 2 * c->pinned_cap.load();
+    }
+    if (device_bytes) *device_bytes = dv;
+    if (pinned_bytes) *pinned_bytes = pn;
+    return 0;
+}

@@ -12,6 +12,7 @@
 // subtraction, square in double, float accumulator), so the result equals the single-threaded
 // reference bit for bit (tests/golden/similar_sources.npz).
 #include "common.h"
+#include "context.h"
 #include "../../include/bpmf_hip.h"
 
 #include <algorithm>
@@ -195,26 +196,26 @@ extern "C" int bpmf_find_similar_sources(const float* moveouts, const float* sou
     BPMF_BIND_DEVICE(device);
     // threshold^2 * n_diff exactly as the reference: (float)n * pow(threshold, 2) -> float
     const float thr2 = (float)((double)(float)n_stations_for_diff * ((double)threshold * (double)threshold));
-    hipStream_t stream = nullptr;
-    float* d_mv = nullptr; int* d_order = nullptr; int* d_red = nullptr; int* d_sub = nullptr;
-    FsState* d_st = nullptr; int* d_batch = nullptr; unsigned char* d_close = nullptr;
-    unsigned char* d_alive = nullptr; float* d_scratch = nullptr;
+    // the device's private stream and working set (context.h): nothing allocated or freed per call,
+    // nothing on the null stream; calls on one device take turns
+    DeviceContext* ctx = device_context(device);
+    if (!ctx) return -2;
+    std::lock_guard<std::mutex> call_lock(ctx->call_mutex);
+    hipStream_t stream = ctx->s_run;
     const size_t scratch_floats = method == 0 ? std::max<size_t>((size_t)FS_BATCH * FS_BATCH, (K + 255) / 256 * 256) * S : 1;
+    size_t total = 0;
+    auto carve = [&](size_t bytes) { const size_t o = total; total += align_up(std::max<size_t>(bytes, 1), 256); return o; };
+    const size_t o_mv = carve(K * S * sizeof(float)), o_order = carve(K * S * sizeof(int)),
+                 o_red = carve(K * sizeof(int)), o_sub = carve(K * sizeof(int)), o_st = carve(sizeof(FsState)),
+                 o_batch = carve(FS_BATCH * sizeof(int)), o_close = carve((size_t)FS_BATCH * FS_BATCH),
+                 o_alive = carve(FS_BATCH), o_scratch = carve(scratch_floats * sizeof(float));
+    char* base = ctx->reserve_device(total);
+    if (!base) return -2;
+    float* d_mv = (float*)(base + o_mv); int* d_order = (int*)(base + o_order); int* d_red = (int*)(base + o_red);
+    int* d_sub = (int*)(base + o_sub); FsState* d_st = (FsState*)(base + o_st); int* d_batch = (int*)(base + o_batch);
+    unsigned char* d_close = (unsigned char*)(base + o_close); unsigned char* d_alive = (unsigned char*)(base + o_alive);
+    float* d_scratch = (float*)(base + o_scratch);
     int rc = 0;
-    auto alloc = [&](void** p, size_t bytes) {
-        if (rc) return;
-        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
-        if (e != hipSuccess) { set_error("bpmf_find_similar_sources: hipMalloc failed: %s", hipGetErrorString(e)); rc = -2; }
-    };
-    alloc((void**)&d_mv, K * S * sizeof(float));
-    alloc((void**)&d_order, K * S * sizeof(int));
-    alloc((void**)&d_red, K * sizeof(int));
-    alloc((void**)&d_sub, K * sizeof(int));
-    alloc((void**)&d_st, sizeof(FsState));
-    alloc((void**)&d_batch, FS_BATCH * sizeof(int));
-    alloc((void**)&d_close, FS_BATCH * FS_BATCH);
-    alloc((void**)&d_alive, FS_BATCH);
-    alloc((void**)&d_scratch, scratch_floats * sizeof(float));
     auto run = [&]() -> int {
         BPMF_HIP_CHECK(hipMemcpyAsync(d_mv, moveouts, K * S * sizeof(float), hipMemcpyHostToDevice, stream));
         BPMF_HIP_CHECK(hipMemsetAsync(d_red, 0, K * sizeof(int), stream));
@@ -249,9 +250,7 @@ extern "C" int bpmf_find_similar_sources(const float* moveouts, const float* sou
         BPMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     };
-    if (!rc) rc = run();
-    (void)hipFree(d_mv); (void)hipFree(d_order); (void)hipFree(d_red); (void)hipFree(d_sub);
-    (void)hipFree(d_st); (void)hipFree(d_batch); (void)hipFree(d_close); (void)hipFree(d_alive);
-    (void)hipFree(d_scratch);
+    rc = run();
+    (void)hipStreamSynchronize(stream);   // (also after a failure: the working set goes back to its cache)
     return rc;
 }

@@ -11,6 +11,7 @@
 // evaluated with the exact-fp32 v_mfma_f32_16x16x4_f32 (a k-ordered fmaf chain; the band's
 // zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
+#include "context.h"
 #include <system_error>
 #include <thread>
 #include <chrono>
@@ -1103,28 +1104,29 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     const size_t b_tp = T * n_ch * L * sizeof(float), b_mv = T * n_ch * sizeof(int32_t),
                  b_w = T * n_ch * sizeof(float), b_d = n_ch * N * sizeof(float),
                  b_out = TB * row_bytes, b_ws = bpmf_mf_workspace_bytes(L, N, TB, S, C);
-    char* base = nullptr;
-    char* pinned[2] = {nullptr, nullptr};
-    hipStream_t s_run = nullptr, s_copy = nullptr;
-    hipEvent_t ev_batch[2] = {nullptr, nullptr}, ev_piece[2] = {nullptr, nullptr};
+    // streams, events, pinned pieces and the device working set are the device's (context.h): created
+    // once, reused by every call, one call per device at a time -- nothing is created or destroyed here
+    DeviceContext* ctx = device_context(device);
+    if (!ctx) return -2;
+    std::lock_guard<std::mutex> call_lock(ctx->call_mutex);
     size_t o_tp = 0, o_mv = o_tp + align_up(b_tp, 256), o_w = o_mv + align_up(b_mv, 256),
            o_d = o_w + align_up(b_w, 256), o_out0 = o_d + align_up(b_d, 256),
            o_out1 = o_out0 + align_up(b_out, 256),
            o_ws = o_out1 + (n_batch > 1 ? align_up(b_out, 256) : 0), total = o_ws + b_ws;
+    char* base = ctx->reserve_device(total);
+    if (!base) return -2;
+    // (a pinned piece never needs to be larger than one batch of output)
+    if (int prc = ctx->reserve_pinned(std::min(PIECE, std::max<size_t>(b_out, 4096)))) return prc;
+    char* const* pinned = ctx->pinned;
+    hipStream_t s_run = ctx->s_run, s_copy = ctx->s_copy;
+    hipEvent_t* ev_batch = ctx->ev_batch;
+    hipEvent_t* ev_piece = ctx->ev_piece;
     int rc = 0;
     auto fail = [&](hipError_t e, const char* what) {
         if (!rc) set_error("bpmf_mf_run: %s failed: %s", what, hipGetErrorString(e));
         rc = -2;
     };
 #define MF_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) fail(e_, what); } while (0)
-    MF_TRY(hipMalloc((void**)&base, total), "hipMalloc");
-    if (!rc) MF_TRY(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), "stream");
-    if (!rc) MF_TRY(hipStreamCreateWithFlags(&s_copy, hipStreamNonBlocking), "stream");
-    for (int i = 0; i < 2 && !rc; ++i) {
-        MF_TRY(hipHostMalloc((void**)&pinned[i], PIECE, hipHostMallocDefault), "hipHostMalloc");
-        if (!rc) MF_TRY(hipEventCreateWithFlags(&ev_batch[i], hipEventDisableTiming), "event");
-        if (!rc) MF_TRY(hipEventCreateWithFlags(&ev_piece[i], hipEventDisableTiming), "event");
-    }
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
@@ -1175,19 +1177,12 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
             t_copy += now() - t1w;
         }
     }
-    if (s_run) (void)hipStreamSynchronize(s_run);
-    if (s_copy) (void)hipStreamSynchronize(s_copy);
+    // (always drained, also after a failure: the working set goes back to its cache)
+    (void)hipStreamSynchronize(s_run);
+    (void)hipStreamSynchronize(s_copy);
     if (verbose)
         fprintf(stderr, "[bpmf] mf_run: %zu batches of %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
-    for (int i = 0; i < 2; ++i) {
-        if (ev_batch[i]) (void)hipEventDestroy(ev_batch[i]);
-        if (ev_piece[i]) (void)hipEventDestroy(ev_piece[i]);
-        if (pinned[i]) (void)hipHostFree(pinned[i]);
-    }
-    if (s_run) (void)hipStreamDestroy(s_run);
-    if (s_copy) (void)hipStreamDestroy(s_copy);
-    (void)hipFree(base);
     return rc;
 }

@@ -1,6 +1,6 @@
 // Multi-device host entry points: one call, host pointers in / host pointers out, the work
 // block-partitioned over several GPUs of the node from inside the library (one host thread per
-// device) -- what a ctypes binding of the reference's third-party back-ends would call with
+// DISTINCT device; a device listed n times computes n blocks one after the other) -- what a ctypes binding of the reference's third-party back-ends would call with
 // `n_devices`.  Upstream's GPU back-ends split the same way inside one
 // process: templates (matched filter) or sources (backprojection) dealt to the devices, the whole
 // day of data copied to each.
@@ -14,6 +14,7 @@
 //                   reduce="none": device d writes rows [k_d, k_{d+1}) of the (K, N) beam.
 #include "common.h"
 #include "../../include/bpmf_hip.h"
+#include "bp_plan.h"
 
 #include <algorithm>
 #include <cstring>
@@ -53,9 +54,9 @@ int resolve_devices(int n_devices, const int* devices, size_t n_items, std::vect
 
 // Contiguous partition of the templates into `parts` blocks of balanced COST: a template costs its
 // number of channels with a non-zero weight (the kernels skip the others), and block r ends at the
-// first template where the running cost reaches (r + 1) / parts of the total -- the rule of
-// seismic_bpmf_amd.parallel.shard_bounds_weighted (np.searchsorted(cumsum, total * r / parts,
-// side="left") on float64 sums), so that the library's own multi-device split and the
+// first template where the running cost reaches (r + 1) / parts of the total, and no block is empty
+// while T >= parts -- the rule of seismic_bpmf_amd.parallel.shard_bounds_weighted
+// (np.searchsorted(cumsum, total * r / parts, side="left") on float64 sums), so that the library's own multi-device split and the
 // one-process-per-GPU split of torch.distributed agree on who computes which template.
 std::vector<size_t> weighted_bounds(const float* weights, size_t T, size_t n_ch, size_t parts)
 {
@@ -78,6 +79,12 @@ std::vector<size_t> weighted_bounds(const float* weights, size_t T, size_t n_ch,
         b[r] = std::min(std::max(k, b[r - 1]), T);
     }
     b[parts] = T;
+    // no empty block while there are at least as many templates as blocks (one heavy template must
+    // not leave a device idle): cuts pushed apart forwards, then pulled back from the end
+    if (T >= parts) {
+        for (size_t r = 1; r < parts; ++r) b[r] = std::max(b[r], b[r - 1] + 1);
+        for (size_t r = parts - 1; r >= 1; --r) b[r] = std::min(b[r], T - (parts - r));
+    }
     return b;
 }
 
@@ -90,40 +97,57 @@ std::vector<size_t> block_bounds(size_t n, size_t parts)
     return b;
 }
 
-// Run fn(block) for every block on its own host thread; the error text of a failing block is
-// thread-local to its thread, so it is carried back and re-raised on the caller's thread.
+// Run fn(block) for every block: ONE host thread per DISTINCT device, the blocks of a device one
+// after the other on its thread (a device listed several times gets several blocks, not several
+// threads -- the per-device context of context.h would serialise them anyway); a single device
+// runs on the caller's thread.  The error text of a failing block is thread-local to its thread,
+// so it is carried back and re-raised on the caller's thread.
 template <typename Fn>
-int run_blocks(size_t n_blocks, Fn fn)
+int run_blocks(const std::vector<int>& dev, Fn fn)
 {
+    const size_t n_blocks = dev.size();
     std::vector<int> rc(n_blocks, 0);
     std::vector<std::string> msg(n_blocks);
+    // blocks of every distinct device, in list order
+    std::vector<int> distinct;
+    std::vector<std::vector<size_t>> blocks_of;
+    for (size_t i = 0; i < n_blocks; ++i) {
+        size_t q = 0;
+        while (q < distinct.size() && distinct[q] != dev[i]) ++q;
+        if (q == distinct.size()) { distinct.push_back(dev[i]); blocks_of.emplace_back(); }
+        blocks_of[q].push_back(i);
+    }
     // Nothing may leave a worker as an exception (an exception that escapes a std::thread, or one thrown
-    // while joinable threads are alive, ends the process with std::terminate -- the "Aborted" that the
-    // 8-process fuzz sessions of round 3 saw once in ~1 000 multi-device calls, profiles/r03_fuzz_long.txt).
-    auto work = [&](size_t i) {
-        try {
-            rc[i] = fn(i);
-            if (rc[i]) msg[i] = bpmf_last_error();
-        } catch (const std::exception& e) {
-            rc[i] = -3;
-            msg[i] = std::string("exception in a device block: ") + e.what();
-        } catch (...) {
-            rc[i] = -3;
-            msg[i] = "unknown exception in a device block";
+    // while joinable threads are alive, ends the process with std::terminate); a failure stays visible
+    // as status -3 with its text.
+    auto work = [&](size_t q) {
+        for (size_t i : blocks_of[q]) {
+            try {
+                rc[i] = fn(i);
+                if (rc[i]) msg[i] = bpmf_last_error();
+            } catch (const std::exception& e) {
+                rc[i] = -3;
+                msg[i] = std::string("exception in a device block: ") + e.what();
+            } catch (...) {
+                rc[i] = -3;
+                msg[i] = "unknown exception in a device block";
+            }
+            if (rc[i]) break;          // the call fails anyway: the device's other blocks are not run
         }
     };
-    if (n_blocks == 1) {
+    if (distinct.size() == 1) {
         work(0);
     } else {
         std::vector<std::thread> th;
-        th.reserve(n_blocks);
-        for (size_t i = 0; i < n_blocks; ++i) {
+        th.reserve(distinct.size());
+        for (size_t q = 1; q < distinct.size(); ++q) {
             try {
-                th.emplace_back(work, i);
+                th.emplace_back(work, q);
             } catch (const std::system_error&) {
-                work(i);           // no thread to be had (process / cgroup limit): this block runs here
+                work(q);           // no thread to be had (process / cgroup limit): this device runs here
             }
         }
+        work(0);                   // the first device on the caller's thread
         for (auto& t : th) t.join();
     }
     for (size_t i = 0; i < n_blocks; ++i)
@@ -151,7 +175,7 @@ extern "C" int bpmf_mf_run_multi(const float* templates, const int32_t* moveouts
     const size_t n_ch = S * C;
     const std::vector<size_t> b = weighted_bounds(weights, T, n_ch, dev.size());
     const size_t row = n_corr * (network_sum ? 1 : n_ch);   // floats of output per template
-    return run_blocks(dev.size(), [&](size_t i) -> int {
+    return run_blocks(dev, [&](size_t i) -> int {
         const size_t t0 = b[i], nt = b[i + 1] - b[i];
         if (nt == 0) return 0;
         return bpmf_mf_run(templates + t0 * n_ch * L, moveouts + t0 * n_ch, weights + t0 * n_ch, data,
@@ -191,28 +215,32 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
     if (int rc = resolve_devices(n_devices, devices, K, dev, "bpmf_bp_run_multi")) return rc;
     const std::vector<size_t> b = block_bounds(K, dev.size());
     if (reduce != BPMF_BP_REDUCE_MAX) {
-        return run_blocks(dev.size(), [&](size_t i) -> int {
+        return run_blocks(dev, [&](size_t i) -> int {
             const size_t k0 = b[i], nk = b[i + 1] - b[i];
             if (nk == 0) return 0;
             return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S,
                                C, P, out_of_bounds, reduce, dev[i], beam_out + k0 * N, nullptr);
         });
     }
-    // (option bp.compat_first_computed: a device's result carries (0, first id) where it computed no
-    // beam, which the host merge cannot tell from a real 0 -- the switch runs on one device)
-    if (bpmf::option(bpmf::OPT_BP_COMPAT_FIRST_COMPUTED) != 0 && dev.size() > 1) dev.resize(1);
     if (dev.size() == 1)   // (through run_blocks: its exception barrier)
-        return run_blocks(1, [&](size_t) -> int {
+        return run_blocks(dev, [&](size_t) -> int {
             return bpmf_bp_run(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds,
                                reduce, dev[0], beam_out, arg_out);
         });
+    // option bp.compat_first_computed: every share keeps -inf where it computed no beam (a finished
+    // share's (0, first id) could not be told from a real 0); the host finishes after the merge
+    const bool first_computed = bpmf::option(bpmf::OPT_BP_COMPAT_FIRST_COMPUTED) != 0;
     // block 0 writes into the caller's arrays, the others into scratch vectors
     std::vector<std::vector<float>> pb(dev.size());
     std::vector<std::vector<int32_t>> pa(dev.size());
     for (size_t i = 1; i < dev.size(); ++i) { pb[i].resize(N); pa[i].resize(N); }
-    int rc = run_blocks(dev.size(), [&](size_t i) -> int {
+    int rc = run_blocks(dev, [&](size_t i) -> int {
         const size_t k0 = b[i], nk = b[i + 1] - b[i];
         if (nk == 0) return 0;
+        struct Defer {
+            explicit Defer(bool on) { bpmf::t_bp_defer_finish = on; }
+            ~Defer() { bpmf::t_bp_defer_finish = false; }
+        } defer(first_computed);
         return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S, C,
                            P, out_of_bounds, reduce, dev[i], i ? pb[i].data() : beam_out,
                            i ? pa[i].data() : arg_out);
@@ -233,6 +261,9 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
             for (size_t t = lo; t < hi; ++t)
                 if (bb[t] > beam_out[t]) { beam_out[t] = bb[t]; arg_out[t] = aa[t] + k0; }
         }
+        if (first_computed)
+            for (size_t t = lo; t < hi; ++t)
+                if (beam_out[t] == -INFINITY) { beam_out[t] = 0.0f; arg_out[t] = 0; }
     };
     if (tb.size() == 2) {
         merge(0, N);

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace bpmf {
 
@@ -27,34 +28,35 @@ void set_error(const char* fmt, ...)
 // ---- execution options (see common.h: identical results whatever their values) ----
 namespace bpmf {
 namespace {
-struct OptionDef { const char* name; long dflt; long lo, hi; };
+// plan: bpmf_bp_plan_create reads it (a change starts a new generation of cached plans)
+struct OptionDef { const char* name; long dflt; long lo, hi; bool plan; };
 const OptionDef OPTION_DEFS[OPT_COUNT] = {
-    {"bp.lds_kb", 80, 8, 160},          // soft LDS budget of a group (single-window plans)
-    {"bp.max_group", 4096, 1, 1 << 20}, // sources per group at most
-    {"bp.tpt", 2, 1, 4},                // samples per thread of the generic kernels (tile = 256 x tpt)
-    {"bp.reorder", 1, 0, 1},            // kd-tree processing order of the sources
-    {"bp.dual", 1, 0, 1},               // dual (shifted) windows + 8-byte gathers where they fit
-    {"bp.packed", 1, 0, 1},             // packed per-station records (P = 2)
-    {"bp.wps", 1, 0, 1},                // wave-per-source kernels
-    {"bp.uvgpr", 1, 0, 1},              // uniform-VGPR metadata kernels
-    {"bp.fast", 1, 0, 1},               // interior-tile kernel of bp_fast.hip
-    {"bp.fast_uniform", 1, 0, 1},       // ready-made addresses when a source's weights are uniform
-    {"bp.split", -1, -1, 1 << 16},      // group ranges per tile: -1 = automatic (short series)
-    {"bp.wpb", 12, 8, 12},              // waves per workgroup of the 4-byte-gather kernel
-    {"bp.smeta", 1, 0, 1},              // SGPR metadata for 32-station records
-    {"bp.verbose", 0, 0, 1},
-    {"bp.fast_tile", 0, 0, 512},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
-    {"bp.halves", 1, 0, 1},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
-    {"bp.direct", 0, 0, 1},             // 1: every plan takes the global-memory path of bp_direct.hip (tests)
-    {"mf.wave_kernel", 1, 0, 1},        // independent-wave kernel for L <= 257
-    {"mf.max_mfma_step", 64, 0, 1 << 20},  // larger steps take the generic kernel
-    {"mf.host_batch_kb", 0, 0, 1L << 30},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
-    {"mf.host_piece_kb", 0, 0, 1L << 30},  // host-pointer call: pinned piece (0 = 64 MB)
-    {"mf.verbose", 0, 0, 1},
-    {"mf.tiles_per_wave", 0, 0, 4},     // 16x16 tiles per wave of the L <= 257 kernel: 0 = by problem size, 1 / 2 / 4
-    {"mf.compat_exclusive_last_lag", 0, 0, 1},  // last valid data offset i * step < N - L - mv_max (default: <=)
-    {"mf.compat_sqrt_norm", 0, 0, 1},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (generic kernel; default: num * r_t * r_d)
-    {"bp.compat_first_computed", 0, 0, 1},      // running max starts from the first computed beam (default: from (0, source 0))
+    {"bp.lds_kb", 80, 8, 160, true},          // soft LDS budget of a group (single-window plans)
+    {"bp.max_group", 4096, 1, 1 << 20, true}, // sources per group at most
+    {"bp.tpt", 2, 1, 4, true},                // samples per thread of the generic kernels (tile = 256 x tpt)
+    {"bp.reorder", 1, 0, 1, true},            // kd-tree processing order of the sources
+    {"bp.dual", 1, 0, 1, true},               // dual (shifted) windows + 8-byte gathers where they fit
+    {"bp.packed", 1, 0, 1, true},             // packed per-station records (P = 2)
+    {"bp.wps", 1, 0, 1, true},                // wave-per-source kernels
+    {"bp.uvgpr", 1, 0, 1, true},              // uniform-VGPR metadata kernels
+    {"bp.fast", 1, 0, 1, true},               // interior-tile kernel of bp_fast.hip
+    {"bp.fast_uniform", 1, 0, 1, true},       // ready-made addresses when a source's weights are uniform
+    {"bp.split", -1, -1, 1 << 16, false},      // group ranges per tile: -1 = automatic (short series)
+    {"bp.wpb", 12, 8, 12, false},              // waves per workgroup of the 4-byte-gather kernel
+    {"bp.smeta", 1, 0, 1, false},              // SGPR metadata for 32-station records
+    {"bp.verbose", 0, 0, 1, false},
+    {"bp.fast_tile", 0, 0, 512, true},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
+    {"bp.halves", 1, 0, 1, true},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
+    {"bp.direct", 0, 0, 1, true},             // 1: every plan takes the global-memory path of bp_direct.hip (tests)
+    {"mf.wave_kernel", 1, 0, 1, false},        // independent-wave kernel for L <= 257
+    {"mf.max_mfma_step", 64, 0, 1 << 20, false},  // larger steps take the generic kernel
+    {"mf.host_batch_kb", 0, 0, 1L << 30, false},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
+    {"mf.host_piece_kb", 0, 0, 1L << 30, false},  // host-pointer call: pinned piece (0 = 64 MB)
+    {"mf.verbose", 0, 0, 1, false},
+    {"mf.tiles_per_wave", 0, 0, 4, false},     // 16x16 tiles per wave of the L <= 257 kernel: 0 = by problem size, 1 / 2 / 4
+    {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
+    {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (generic kernel; default: num * r_t * r_d)
+    {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))
 };
 std::atomic<long> g_options[OPT_COUNT];
 std::once_flag g_options_once;
@@ -94,7 +96,9 @@ extern "C" int bpmf_set_option(const char* name, long value)
         bpmf::set_error("bpmf_set_option: %s = %ld outside [%ld, %ld]", d.name, value, d.lo, d.hi);
         return -1;
     }
-    if (bpmf::g_options[i].exchange(value, std::memory_order_relaxed) != value)
+    // cached plans are keyed by the generation: only the options a plan is BUILT under count (a
+    // verbosity or matched-filter setting must not orphan every resident backprojection plan)
+    if (bpmf::g_options[i].exchange(value, std::memory_order_relaxed) != value && bpmf::OPTION_DEFS[i].plan)
         bpmf::g_option_generation.fetch_add(1, std::memory_order_relaxed);
     return 0;
 }
@@ -115,38 +119,63 @@ extern "C" int bpmf_get_option(const char* name, long* value, long* default_valu
 // ---- optional per-kernel timing (bench.py's roofline leg) -------------------------
 // Every launch of a dominant kernel gets its own start/stop event pair, recorded on the
 // launch stream without synchronising; the pairs are read back after the timed region.
+//
+// The multi-device entry points launch the same kernel from several host threads, one per GPU:
+// a pair belongs to the THREAD that opened it (thread-local slot index) and to the DEVICE that was
+// current when it was opened (an event can only be recorded on a stream of the device it was
+// created on), so edges of two threads never pair up and events never cross devices.
 namespace bpmf {
 constexpr int PROFILE_MAX_LAUNCHES = 512;
-struct ProfileLog {
-    hipEvent_t ev[PROFILE_MAX_LAUNCHES][2];
-    int created = 0;  // event pairs that exist
-    int count = 0;    // launches recorded since the last reset
-    bool open = false;
+struct ProfilePair {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int device = -1;
+    bool closed = false;      // stop edge recorded
 };
-// The log is shared by every host thread that launches (the multi-device entry points run one
-// thread per GPU): all accesses go through g_profile_mutex.  The enable flag is read without the
-// lock on the fast path (a launch with profiling off takes no lock at all).
-static volatile bool g_profile = false;
+struct ProfileLog {
+    std::vector<ProfilePair> rec;      // launches since the last reset, in the order they were opened
+    std::vector<ProfilePair> spare;    // pairs of earlier sessions, reused by device
+};
+static std::atomic<bool> g_profile{false};
+static std::atomic<unsigned> g_profile_session{0};
 static ProfileLog g_log[BPMF_KERNEL_COUNT];
 static std::mutex g_profile_mutex;
+// the pair this thread has open, per kernel kind: (session, index into rec), -1 = none
+static thread_local int t_open_slot[BPMF_KERNEL_COUNT] = {-1, -1};
+static thread_local unsigned t_open_session[BPMF_KERNEL_COUNT] = {0, 0};
 
 void profile_mark(int which, int edge, hipStream_t stream)
 {
-    if (!g_profile || which < 0 || which >= BPMF_KERNEL_COUNT) return;
+    if (!g_profile.load(std::memory_order_relaxed) || which < 0 || which >= BPMF_KERNEL_COUNT) return;
     std::lock_guard<std::mutex> lock(g_profile_mutex);
     ProfileLog& lg = g_log[which];
+    const unsigned session = g_profile_session.load(std::memory_order_relaxed);
     if (edge == 0) {
-        lg.open = false;
-        if (lg.count >= PROFILE_MAX_LAUNCHES) return;
-        if (lg.count >= lg.created) {
-            if (hipEventCreate(&lg.ev[lg.created][0]) != hipSuccess) return;
-            if (hipEventCreate(&lg.ev[lg.created][1]) != hipSuccess) return;
-            lg.created++;
+        t_open_slot[which] = -1;
+        if (lg.rec.size() >= (size_t)PROFILE_MAX_LAUNCHES) return;
+        int device = -1;
+        if (hipGetDevice(&device) != hipSuccess) return;
+        ProfilePair pr;
+        for (size_t i = 0; i < lg.spare.size(); ++i)
+            if (lg.spare[i].device == device) {
+                pr = lg.spare[i];
+                lg.spare.erase(lg.spare.begin() + (long)i);
+                break;
+            }
+        if (!pr.ev[0]) {
+            if (hipEventCreate(&pr.ev[0]) != hipSuccess) return;
+            if (hipEventCreate(&pr.ev[1]) != hipSuccess) { (void)hipEventDestroy(pr.ev[0]); return; }
+            pr.device = device;
         }
-        lg.open = hipEventRecord(lg.ev[lg.count][0], stream) == hipSuccess;
-    } else if (lg.open) {
-        if (hipEventRecord(lg.ev[lg.count][1], stream) == hipSuccess) lg.count++;
-        lg.open = false;
+        pr.closed = false;
+        if (hipEventRecord(pr.ev[0], stream) != hipSuccess) { lg.spare.push_back(pr); return; }
+        lg.rec.push_back(pr);
+        t_open_slot[which] = (int)lg.rec.size() - 1;
+        t_open_session[which] = session;
+    } else {
+        const int slot = t_open_slot[which];
+        t_open_slot[which] = -1;
+        if (slot < 0 || t_open_session[which] != session || (size_t)slot >= lg.rec.size()) return;
+        lg.rec[slot].closed = hipEventRecord(lg.rec[slot].ev[1], stream) == hipSuccess;
     }
 }
 }  // namespace bpmf
@@ -154,30 +183,49 @@ void profile_mark(int which, int edge, hipStream_t stream)
 extern "C" void bpmf_profile_enable(int enable)
 {
     std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
-    bpmf::g_profile = enable != 0;
+    bpmf::g_profile.store(enable != 0);
     if (!enable) return;  // the log stays readable after the timed region is closed
-    for (int k = 0; k < BPMF_KERNEL_COUNT; ++k) { bpmf::g_log[k].count = 0; bpmf::g_log[k].open = false; }
+    bpmf::g_profile_session.fetch_add(1);
+    for (int k = 0; k < BPMF_KERNEL_COUNT; ++k) {
+        bpmf::ProfileLog& lg = bpmf::g_log[k];
+        for (auto& pr : lg.rec) lg.spare.push_back(pr);
+        lg.rec.clear();
+    }
 }
 
 extern "C" int bpmf_profile_count(int which)
 {
     if (which < 0 || which >= BPMF_KERNEL_COUNT) return -1;
     std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
-    return bpmf::g_log[which].count;
+    return (int)bpmf::g_log[which].rec.size();
 }
 
 extern "C" int bpmf_profile_get_ms(int which, int index, float* ms)
 {
     std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
     if (which < 0 || which >= BPMF_KERNEL_COUNT || !ms || index < 0 ||
-        index >= bpmf::g_log[which].count) {
+        (size_t)index >= bpmf::g_log[which].rec.size()) {
         bpmf::set_error("bpmf_profile_get_ms: no launch %d recorded for kernel %d", index, which);
         return -1;
     }
-    BPMF_HIP_CHECK(hipEventSynchronize(bpmf::g_log[which].ev[index][1]));
-    BPMF_HIP_CHECK(hipEventElapsedTime(ms, bpmf::g_log[which].ev[index][0],
-                                       bpmf::g_log[which].ev[index][1]));
+    const bpmf::ProfilePair& pr = bpmf::g_log[which].rec[index];
+    if (!pr.closed) {
+        bpmf::set_error("bpmf_profile_get_ms: launch %d of kernel %d has no stop edge", index, which);
+        return -1;
+    }
+    BPMF_HIP_CHECK(hipEventSynchronize(pr.ev[1]));
+    BPMF_HIP_CHECK(hipEventElapsedTime(ms, pr.ev[0], pr.ev[1]));
     return 0;
+}
+
+// the device launch `index` of kernel `which` ran on (-1: no such launch)
+extern "C" int bpmf_profile_get_device(int which, int index)
+{
+    std::lock_guard<std::mutex> lock(bpmf::g_profile_mutex);
+    if (which < 0 || which >= BPMF_KERNEL_COUNT || index < 0 ||
+        (size_t)index >= bpmf::g_log[which].rec.size())
+        return -1;
+    return bpmf::g_log[which].rec[index].device;
 }
 
 extern "C" const char* bpmf_last_error(void) { return bpmf::last_error_buf(); }

@@ -35,7 +35,8 @@ def shard_bounds(n, world):
 
 def shard_bounds_weighted(costs, world):
     """Contiguous partition of range(len(costs)) into `world` blocks with balanced total cost: block
-    r ends where the running cost first reaches (r + 1) / world of the total.  For the matched
+    r ends where the running cost first reaches (r + 1) / world of the total, and no block is empty
+    while there are at least `world` items.  For the matched
     filter the cost of a template is its number of channels with non-zero weight (zero-weight
     channels are skipped by the kernel), SURVEY.md section 8e."""
     import numpy as np
@@ -50,6 +51,11 @@ def shard_bounds_weighted(costs, world):
         k = int(np.searchsorted(cum, total * r / world, side="left"))
         cuts.append(min(max(k, cuts[-1]), n))
     cuts.append(n)
+    if n >= world:      # no empty block while there are as many items as blocks (csrc/multi.hip: weighted_bounds)
+        for r in range(1, world):
+            cuts[r] = max(cuts[r], cuts[r - 1] + 1)
+        for r in range(world - 1, 0, -1):
+            cuts[r] = min(cuts[r], n - (world - r))
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 

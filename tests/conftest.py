@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # BPMF_CRASH_BT=1: a process that dies of SIGSEGV / SIGABRT prints the C stack of the faulting thread
+    # first (tools/stress/crash_bt.c; stress sessions only -- xdist workers inherit the variable)
+    if os.environ.get("BPMF_CRASH_BT"):
+        import ctypes
+        sys.path.insert(0, os.path.join(ROOT, "tools", "stress"))
+        import stress_multi
+        handler = ctypes.CDLL(stress_multi.build_crash_lib())
+        handler.crash_bt_install(f"pytest-{os.environ.get('PYTEST_XDIST_WORKER', 'main')}".encode())
+        config._bpmf_crash_bt = handler
 
 
 @pytest.fixture(scope="session")

@@ -124,6 +124,19 @@ def test_weighted_template_sharding_balances_active_channels():
         loads = [costs[lo:hi].sum() for lo, hi in b]
         assert max(loads) <= costs.sum() / world + costs.max() + 1e-9
     assert parallel.shard_bounds_weighted(np.zeros(10), 3) == parallel.shard_bounds(10, 3)
+    # no rank (no GPU of bpmf_mf_run_multi) is left without a template while there are enough of them:
+    # one heavy template used to give (0,1),(1,1),(1,1),(1,4)
+    assert parallel.shard_bounds_weighted([100, 1, 1, 1], 4) == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert parallel.shard_bounds_weighted([1, 1, 1, 100], 4) == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert parallel.shard_bounds_weighted([1, 3], 2) == [(0, 1), (1, 2)]
+    for n, world in [(8, 8), (9, 8), (40, 8), (5, 2)]:
+        for trial in range(20):
+            costs = rng.integers(0, 4, n) * rng.integers(0, 50, n)
+            if costs.sum() == 0:
+                continue
+            b = parallel.shard_bounds_weighted(costs, world)
+            assert all(hi > lo for lo, hi in b), (costs, b)
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[r][1] == b[r + 1][0] for r in range(world - 1))
 
 
 def test_c_abi_and_python_shard_the_templates_identically():
@@ -135,12 +148,15 @@ def test_c_abi_and_python_shard_the_templates_identically():
     from seismic_bpmf_amd import _lib, parallel
     lib = _lib.lib()
     rng = np.random.default_rng(9)
-    for T, S, Cc, world in [(5000, 40, 3, 8), (500, 20, 3, 8), (17, 5, 3, 4), (3, 2, 1, 8), (64, 7, 3, 1), (9, 3, 3, 2)]:
-        for trial in range(4):
+    for T, S, Cc, world in [(5000, 40, 3, 8), (500, 20, 3, 8), (17, 5, 3, 4), (3, 2, 1, 8), (64, 7, 3, 1), (9, 3, 3, 2),
+                            (8, 6, 3, 8), (4, 9, 3, 4)]:
+        for trial in range(5):
             w = rng.random((T, S, Cc)).astype(np.float32)
-            w[rng.random((T, S, Cc)) < (0.0, 0.3, 0.7, 1.0)[trial]] = 0.0
+            w[rng.random((T, S, Cc)) < (0.0, 0.3, 0.7, 1.0, 0.9)[trial]] = 0.0
             if trial == 2:
                 w[: T // 2] = 0.0
+            if trial == 4:
+                w[T // 2] = 1.0            # one heavy template among nearly empty ones
             costs = (w.reshape(T, -1) != 0).sum(axis=1)
             want = parallel.shard_bounds_weighted(costs, world)
             got = (C.c_size_t * (world + 1))()

@@ -100,6 +100,14 @@ def test_bp_first_computed(oracle_lib, hip_opts, n_used, S, oob):
         bf.close()
         assert np.array_equal(b.cpu().numpy(), want[0]), (n_used, oob, fast, split)
         assert np.array_equal(a.cpu().numpy(), want[1]), (n_used, oob, fast, split)
+    # the host entry point with the grid split into several device blocks: every block keeps -inf where it
+    # computed nothing and the host finishes (0, first id) after the merge
+    from seismic_bpmf_amd import beamform
+    hip_opts.reset("bp.fast")
+    hip_opts.reset("bp.split")
+    for dev in (0, [0, 0, 0]):
+        b, a = beamform(f, tau, wp, ws, device="gpu", out_of_bounds=oob, device_id=dev)
+        assert np.array_equal(b, want[0]) and np.array_equal(a, want[1]), (n_used, oob, dev)
     hip_opts.reset("bp.compat_first_computed")
     bf = BeamformerGPU(tau, ws)
     b, a = bf.run(f, wp, "max", oob)

@@ -218,3 +218,74 @@ def test_mf_cfg2_all_500_templates_full_day():
                 q += 1
         exact += len(set(idx) & set(planted[t].tolist()))
     assert exact >= T * n_ev - 5, exact
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5_per_gpu"])
+def test_bp_dense_station_weights_full_day(oracle_lib, name):
+    """BASELINE's literal "x 20 / x 40 stations": EVERY station of every source weighted -- what
+    `_weights_sources_closest` returns for num_closest_stations >= n_stations
+    (BPMF/template_search.py:779-798).  These grids run the station-count classes of bp_fast.hip (17-32
+    stations: tile 256, two records per source; 33-64: two LDS residencies per group) that the
+    10-closest-station workloads never touch.  Full size: configs[2] (50 000 sources x 20 stations, 1 day
+    @ 50 Hz) and one GPU's share of configs[4] (125 000 sources x 40 stations, 1 day @ 100 Hz) --
+    all sources against the oracle over three 150-sample windows (one around a planted event, one at
+    the start of the day where sources begin to enter, one random), the 2-"rank" packed-key merge
+    equal to the single pass bit for bit, determinism, the zero tail of the day."""
+    import torch
+    from seismic_bpmf_amd import BeamformerGPU, parallel, synthetic as syn
+    cfg = syn.BP_CONFIGS[name]
+    S, C, P, N = cfg["S"], cfg["C"], cfg["P"], cfg["N"]
+    geo = syn.make_bp_geometry(cfg["grid"], S, P, cfg["sr"])
+    tau = geo["moveouts"]
+    K = tau.shape[0]
+    ws = np.full((K, S), 1.0 / S, dtype=np.float32)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(61)
+    feat = torch.randn((S, C, N), device="cuda", generator=g).abs_()
+    rng = np.random.default_rng(62)
+    sig = 0.2 * cfg["sr"]
+    half = int(4 * sig)
+    bump = torch.as_tensor(8.0 * np.exp(-0.5 * (np.arange(-half, half + 1) / sig) ** 2),
+                           dtype=torch.float32, device="cuda")
+    planted = []
+    for _ in range(6):
+        k0, t0 = int(rng.integers(0, K)), int(rng.integers(20_000, N - 20_000))
+        for s in range(S):
+            for c in range(C):
+                x = t0 + int(tau[k0, s, 0 if c == 0 else 1])
+                feat[s, c, x - half:x + half + 1] += bump
+        planted.append((k0, t0))
+    wp = syn.phase_weights(S, C, P)
+    full = BeamformerGPU(tau, ws)
+    info = full.plan_info()
+    assert info["gather_bytes"] == 8 and info["n_classes"] >= 1 and info["stations_max"] == S, info
+    beam, arg = full.run(feat, wp, "max", "strict")
+    b2, a2 = full.run(feat, wp, "max", "strict")
+    assert torch.equal(beam, b2) and torch.equal(arg, a2)
+    del b2, a2
+    k_half = K // 2 + 17
+    r0 = BeamformerGPU(tau[:k_half], ws[:k_half], source_id_offset=0)
+    r1 = BeamformerGPU(tau[k_half:], ws[k_half:], source_id_offset=k_half)
+    p0 = parallel.pack_max_keys(*r0.run(feat, wp, "max", "strict"))
+    p1 = parallel.pack_max_keys(*r1.run(feat, wp, "max", "strict"))
+    mb, ma = parallel.unpack_max_keys(torch.maximum(p0, p1))
+    assert torch.equal(mb, beam) and torch.equal(ma, arg)
+    del p0, p1, mb, ma
+    maxbeam, sources = beam.cpu().numpy(), arg.cpu().numpy()
+    tail = N - int(tau.max(axis=(1, 2)).min())
+    assert not maxbeam[tail:].any() and not sources[tail:].any() and maxbeam[tail - 1] > 0
+    tmax = int(tau.max())
+    W = 150
+    for i0 in (planted[0][1] - 60, 0, int(rng.integers(0, N - tmax - 1000)), N - tmax - W - 1):
+        seg = feat[:, :, i0:i0 + W + tmax + 1].cpu().numpy()
+        ob, oa = oracle_lib.beamform(seg, tau, wp, ws, "strict", "max")
+        assert np.array_equal(maxbeam[i0:i0 + W], ob[:W]), (name, i0)
+        assert np.array_equal(sources[i0:i0 + W], oa[:W]), (name, i0)
+    # every planted event is the day's maximum in its neighbourhood, located at a source whose beam
+    # equals the planted source's
+    for k0, t0 in planted:
+        lo = t0 - 200
+        assert abs(lo + int(np.argmax(maxbeam[lo:t0 + 200])) - t0) <= 3, (k0, t0)
+        assert maxbeam[t0] >= 8.0
+    for b in (full, r0, r1):
+        b.close()

@@ -77,3 +77,100 @@ def test_hot_paths_from_concurrent_threads(oracle_lib):
         for j, ((cc, mb, ma, pk), (wcc, wmb, wma, wpk)) in enumerate(zip(got, want)):
             assert np.array_equal(cc, wcc) and np.array_equal(mb, wmb) and np.array_equal(ma, wma), j
             assert np.array_equal(pk[0], wpk[0]) and np.array_equal(pk[1], wpk[1]), j
+
+
+def test_multi_device_calls_from_competing_processes():
+    """4 processes x 40 iterations of ~16 host-pointer calls each with the same GPU listed 2-6 times
+    (tools/stress/stress_multi.py: every result compared bit for bit with the single-device call of the same
+    inputs).  Rounds 2-3 ran every listed device on its own host thread, each creating streams, events
+    and allocations per call, and lost about one process per 500 calls to SIGSEGV / SIGABRT when 8
+    processes competed for the GPU; the per-device context (csrc/context.h) takes all of that out."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "stress_test")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "stress", "stress_multi.py"), "--procs", "4",
+                          "--threads", "1", "--calls", "40", "--out", out, "--timeout", "600"],
+                         capture_output=True, text=True, timeout=700)
+    assert res.returncode == 0, res.stdout[-4000:] + res.stderr[-2000:]
+    assert "exit codes [0, 0, 0, 0]" in res.stdout, res.stdout[-2000:]
+
+
+def test_eight_threads_of_one_process_drive_multi_device_calls(oracle_lib):
+    """One process, 8 Python threads, each calling beamform(device_id=[0] * 6) and
+    matched_filter(device=[0] * 4) in a loop: the calls of one device take turns inside the library."""
+    from seismic_bpmf_amd import beamform, matched_filter
+    rng = np.random.default_rng(77)
+    jobs = []
+    for j in range(8):
+        T, S, C, L, N = 5, 2, 2, int(rng.choice([16, 64, 300])), 3_000 + 256 * j
+        tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+        d = rng.standard_normal((S, C, N)).astype(np.float32)
+        mv = rng.integers(-30, 200, (T, S, C)).astype(np.int32)
+        w = rng.random((T, S, C)).astype(np.float32)
+        K, Sb, Nb = 60 + 30 * j, 4, 2_500 + 300 * j
+        f = np.round(np.abs(rng.standard_normal((Sb, 2, Nb))) * 2).astype(np.float32)
+        tau = rng.integers(0, 150, (K, Sb, 2)).astype(np.int32)
+        wp = rng.random((Sb, 2, 2)).astype(np.float32)
+        ws = rng.random((K, Sb)).astype(np.float32)
+        jobs.append((tp, mv, w, d, f, tau, wp, ws, oracle_lib.matched_filter(tp, mv, w, d, 1),
+                     oracle_lib.beamform(f, tau, wp, ws, "strict", "max")))
+
+    def one(job):
+        tp, mv, w, d, f, tau, wp, ws, wcc, (wmb, wma) = job
+        for _ in range(6):
+            cc = matched_filter(tp, mv, w, d, 1, arch="gpu", device=[0] * 4, check_zeros=False)
+            mb, ma = beamform(f, tau, wp, ws, device="gpu", device_id=[0] * 6)
+            if not (np.array_equal(cc, wcc) and np.array_equal(mb, wmb) and np.array_equal(ma, wma)):
+                return False
+        return True
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        assert all(pool.map(one, jobs))
+
+
+def test_profile_log_pairs_edges_per_thread_and_device():
+    """With kernel timing on, beamform(device_id=[0, 0, 0]) logs three launches of the beam kernel, each
+    with a positive duration and its device; edges recorded by concurrent threads never pair up."""
+    from seismic_bpmf_amd import _lib, beamform
+    rng = np.random.default_rng(8)
+    K, S, N = 90, 5, 40_000
+    f = np.abs(rng.standard_normal((S, 2, N))).astype(np.float32)
+    tau = rng.integers(0, 150, (K, S, 2)).astype(np.int32)
+    wp = rng.random((S, 2, 2)).astype(np.float32)
+    ws = rng.random((K, S)).astype(np.float32)
+    _lib.profile_enable(True)
+    try:
+        beamform(f, tau, wp, ws, device="gpu", device_id=[0, 0, 0])
+        ms = _lib.profile_times_ms(_lib.KERNEL_BP_BEAM)
+        assert len(ms) == 3 and all(m > 0 for m in ms), ms
+        assert _lib.profile_devices(_lib.KERNEL_BP_BEAM) == [0, 0, 0]
+        # concurrent threads, each its own call: as many well-formed pairs as calls
+        _lib.profile_enable(True)
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            list(pool.map(lambda _: beamform(f, tau, wp, ws, device="gpu", device_id=0), range(8)))
+        ms = _lib.profile_times_ms(_lib.KERNEL_BP_BEAM)
+        assert len(ms) == 8 and all(0 < m < 1000 for m in ms), ms
+    finally:
+        _lib.profile_enable(False)
+
+
+def test_host_calls_keep_and_release_their_working_set():
+    """The host-pointer calls keep a device working set and two pinned pieces per device between calls
+    (no allocation per call); bpmf_release_device_memory gives them back; the next call re-creates them."""
+    from seismic_bpmf_amd import _lib, matched_filter
+    rng = np.random.default_rng(9)
+    tp = rng.standard_normal((3, 2, 2, 64)).astype(np.float32)
+    d = rng.standard_normal((2, 2, 30_000)).astype(np.float32)
+    mv = np.zeros((3, 2, 2), np.int32)
+    w = np.ones((3, 2, 2), np.float32)
+    first = matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    dev_b, pin_b = _lib.device_memory_held(0)
+    assert dev_b > 0 and pin_b > 0
+    again = matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert _lib.device_memory_held(0) == (dev_b, pin_b) and np.array_equal(first, again)
+    _lib.release_device_memory(0)
+    assert _lib.device_memory_held(0) == (0, 0)
+    assert np.array_equal(matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False), first)
+    assert _lib.device_memory_held(0)[0] > 0
