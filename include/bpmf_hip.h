@@ -312,7 +312,12 @@ int bpmf_row_median_mad_dev(const float *d_x, size_t rows, size_t n, int skip_ze
  * (rows, n_windows) receives centre + num_dev * deviation after the two neighbour-maximum
  * passes; d_thr_full (rows, n), if not NULL, the threshold of every sample.  Row r replaces its
  * zeros, in order, by white_noise[0 .. n_zeros(r)) * deviation0 + centre0; -1 if a row holds
- * more zeros than n_noise. */
+ * more zeros than n_noise (checked with one small D2H and a stream synchronise when n_noise < n:
+ * hand over n values, as the reference draws them, to stay asynchronous).
+ * Limits: rows <= 65535 per call (gridDim.y; callers with more rows chunk them -- ThresholdGPU
+ * does), n < 2^31.  The workspace holds a zero-filled COPY of the series, rows * n floats, besides
+ * the small per-row arrays (bpmf_tdt_mad_workspace_bytes: ~17 GB for 500 rows of a day at 100 Hz):
+ * bound it by calling with fewer rows at a time. */
 size_t bpmf_tdt_mad_num_windows(size_t n, size_t window, size_t shift);
 size_t bpmf_tdt_mad_workspace_bytes(size_t rows, size_t n, size_t window, size_t shift);
 int bpmf_tdt_mad_dev(const float *d_series, const float *d_white_noise, size_t n_noise,
@@ -322,7 +327,7 @@ int bpmf_tdt_mad_dev(const float *d_series, const float *d_white_noise, size_t n
 
 /* scipy.stats.kurtosis(row) (Fisher, biased: m4 / m2^2 - 3, NaN for a constant row) of every row,
  * float32 with NumPy's pairwise summation order: the `sanity_check` of
- * MatchedFilter._find_detections_t (BPMF/similarity_search.py:633-642). */
+ * MatchedFilter._find_detections_t (BPMF/similarity_search.py:633-642).  rows <= 65535 per call. */
 size_t bpmf_row_kurtosis_workspace_bytes(size_t rows, size_t n);
 int bpmf_row_kurtosis_dev(const float *d_x, size_t rows, size_t n, void *d_workspace,
                           size_t workspace_bytes, bpmf_stream_t stream, float *d_kurtosis);

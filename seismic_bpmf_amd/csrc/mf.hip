@@ -541,6 +541,27 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // hour-long series with a handful of templates, BASELINE configs[0]: 704 waves of 1024 lags on 1024
 // SIMDs, each wave alone with its serial work; at 256 lags per wave 2816 waves share the matrix pipes
 // three to a SIMD).  The hand-placed operand reads and their counted waits follow NTILE.
+// Cycle accounting (tools/phase/build_phase_lib.py builds a second library with -DBPMF_PHASE_CYCLES; the
+// shipping library carries none of it): s_memtime at the phase boundaries of a channel, summed per wave
+// over its channels; the workgroup of (template 0, lag block 3) overwrites out[row 0, LAGS_WG * 3 + 8 *
+// wave + i] with {staging writes, norm loads + staging issue, K loop, epilogue, channels} -- cycles as
+// floats; those CC values are garbage in such a build (tools/phase/mf_phase.py reads them).
+#ifdef BPMF_PHASE_CYCLES
+#define MF_PHASE_DECL unsigned long long ph_last_ = 0, ph_acc_[4] = {0, 0, 0, 0}; unsigned ph_n_ = 0;
+#define MF_PHASE_START() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last_) :: "memory")
+#define MF_PHASE(i)                                                                                \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");              \
+        ph_acc_[i] += t_ - ph_last_;                                                               \
+        ph_last_ = t_;                                                                             \
+    } while (0)
+#else
+#define MF_PHASE_DECL
+#define MF_PHASE_START() do {} while (0)
+#define MF_PHASE(i) do {} while (0)
+#endif
+
 template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
@@ -582,6 +603,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const bool wave_valid = rg.x <= rg.y && !(lag0 > rg.y || lag0 + LAGS_W - 1 < rg.x);   // empty range: first > last
     const bool wave_inside = lag0 >= rg.x && lag0 + LAGS_W - 1 <= rg.y;
     const long long lag_w = lag0 + 16 * a + 4 * kq;
+    MF_PHASE_DECL
 
     if (wave_valid) {
         float* tp = smem + wv * wave_floats;  // tp[15 + l] = tmpl[l], zeros around
@@ -629,9 +651,11 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         int4 rec1 = recs[1];
         int ri = 0;
         if (rec.x >= 0) issue_stage(rec.x, rec.y);
+        MF_PHASE_START();
         while (rec.x >= 0) {
             const int ch = rec.x;
             write_stage();  // in place: this wave finished reading the previous channel
+            MF_PHASE(0);
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
@@ -659,6 +683,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 }
             }
             if (rec1.x >= 0) issue_stage(rec1.x, rec1.y);
+            MF_PHASE(1);
 
             f32x4 acc[NTILE];
 #pragma unroll
@@ -716,6 +741,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #undef MF_MFMA
 #undef MF_REQ
 #undef MF_STEP
+            MF_PHASE(2);
             if (NETWORK_SUM && STEP1 && wave_inside) {
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
                 // but the first and last tiles of a day): no per-lag range tests
@@ -750,6 +776,10 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             rec = rec1;
             rec1 = rec2;
             ++ri;
+            MF_PHASE(3);
+#ifdef BPMF_PHASE_CYCLES
+            ++ph_n_;
+#endif
         }
     }
     if (NETWORK_SUM) {
@@ -769,6 +799,16 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
         }
     }
+#ifdef BPMF_PHASE_CYCLES
+    if (NETWORK_SUM && t == 0 && lag_block == 3) {
+        __builtin_amdgcn_s_barrier();
+        if (lane == 0) {
+            float* dbg = out + (size_t)LAGS_WG * 3 + 8 * wv;
+            for (int i = 0; i < 4; ++i) dbg[i] = (float)ph_acc_[i];
+            dbg[4] = (float)ph_n_;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------ generic (any step) kernel ---

@@ -33,6 +33,7 @@ class ThresholdGPU:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.lib = _lib.lib()
         self._ws = None
+        self.mad_workspace_limit = 4 << 30      # bytes of zero-filled copy per call of the MAD threshold
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -90,18 +91,24 @@ class ThresholdGPU:
         if white_noise is None:
             white_noise = np.random.normal(size=n).astype("float32")
         wn = t.as_tensor(np.ascontiguousarray(white_noise, dtype=np.float32), device=self.device)
-        nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(rows, n, W, shift)
+        # rows go through the library in chunks: at most 65535 per call (its gridDim.y), and few enough
+        # that the zero-filled copy of the chunk in the workspace (rows * n floats) stays under
+        # `mad_workspace_limit` bytes (4 GiB by default; one row always goes)
+        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, 4 * n))))
+        nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(chunk, n, W, shift)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
         thr_win = t.empty((rows, n_win), dtype=t.float32, device=self.device)
         full = t.empty((rows, n), dtype=t.float32, device=self.device) if (expand or single) else None
         with t.cuda.device(self.device):
-            rc = self.lib.bpmf_tdt_mad_dev(x.data_ptr(), wn.data_ptr() if wn.numel() else None, wn.numel(),
-                                           float(num_dev), rows, n, W, shift, self._ws.data_ptr(),
-                                           self._ws.numel(), self._stream(), thr_win.data_ptr(),
-                                           full.data_ptr() if full is not None else None, None)
-        _lib.check(rc, "bpmf_tdt_mad_dev")
+            for r0 in range(0, rows, chunk):
+                nr = min(chunk, rows - r0)
+                rc = self.lib.bpmf_tdt_mad_dev(x[r0:].data_ptr(), wn.data_ptr() if wn.numel() else None, wn.numel(),
+                                               float(num_dev), nr, n, W, shift, self._ws.data_ptr(),
+                                               self._ws.numel(), self._stream(), thr_win[r0:].data_ptr(),
+                                               full[r0:].data_ptr() if full is not None else None, None)
+                _lib.check(rc, "bpmf_tdt_mad_dev")
         self._keep = (x, wn)
         return full[0] if single else (thr_win, full)
 

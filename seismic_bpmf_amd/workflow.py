@@ -58,12 +58,15 @@ def row_excess_kurtosis(cc):
         return np.zeros(0, dtype=np.float32)
     lib = _lib.lib()
     out = torch.empty(rows, dtype=torch.float32, device=x.device)
-    ws = torch.empty(lib.bpmf_row_kurtosis_workspace_bytes(rows, n), dtype=torch.uint8, device=x.device)
+    chunk = min(rows, 65535)                   # rows per call of the library (its gridDim.y)
+    ws = torch.empty(lib.bpmf_row_kurtosis_workspace_bytes(chunk, n), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.bpmf_row_kurtosis_dev(C.c_void_p(x.data_ptr()), rows, n, C.c_void_p(ws.data_ptr()), ws.numel(),
-                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
-                                       C.c_void_p(out.data_ptr()))
-    _lib.check(rc, "bpmf_row_kurtosis_dev")
+        for r0 in range(0, rows, chunk):
+            rc = lib.bpmf_row_kurtosis_dev(C.c_void_p(x[r0:].data_ptr()), min(chunk, rows - r0), n,
+                                           C.c_void_p(ws.data_ptr()), ws.numel(),
+                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
+                                           C.c_void_p(out[r0:].data_ptr()))
+            _lib.check(rc, "bpmf_row_kurtosis_dev")
     return out.cpu().numpy()
 
 
@@ -101,6 +104,11 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
         thr_win, _ = th.time_dependent_threshold(cc, window, n_dev, overlap=overlap,
                                                  white_noise=white_noise)
     elif threshold_type == "mad":                                               # :1079-1113
+        # The reference fills the zeros of a series with white_noise[:n_zeros] and draws one value per
+        # sample; a shorter array (the 500 values the RMS variant cycles through) is repeated up to
+        # the series length here -- the reference itself would fail to broadcast it.
+        if white_noise is not None and len(white_noise) < cc.shape[-1]:
+            white_noise = np.resize(np.asarray(white_noise, dtype=np.float32), cc.shape[-1])
         thr_win, _ = th.time_dependent_threshold_mad(cc, window, n_dev, overlap=overlap,
                                                      white_noise=white_noise, expand=False)
     else:
@@ -118,7 +126,7 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
         mine = cand[cand["row"] == t]
         win = search_window(mv[t].reshape(mv.shape[1], -1), min_iet, step)
         idx = merge_candidates(mine["index"], mine["cc"], win)
-        if remove_edges and data_buffer_sec is not None:
+        if remove_edges:                        # (data_buffer_sec is given: checked on entry)
             samples = idx * step
             idx = idx[samples >= pp.sec_to_samp(data_buffer_sec, sr)]
             if data_duration_sec is not None:
