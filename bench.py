@@ -556,6 +556,25 @@ def main():
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     peak = float(cc[0].max().item())
     detect = detection_stage(cc, planted, local_rank, dist, device, t_offset=rank * T)
+    # untimed extra: the same step under option mf.compat_sqrt_norm (cc = num / sqrtf(E_t * E_d) in the
+    # epilogue of the MFMA kernel: an IEEE square root and divide per channel and lag)
+    compat = None
+    if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
+        with _lib.options(**{"mf.compat_sqrt_norm": 1}):
+            mf_step()
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            t0 = time.perf_counter()
+            mf_step()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            _lib.profile_enable(False)
+            kms = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_MF_MAIN)))
+        mf._prepared_for = None
+        compat = {"mf.compat_sqrt_norm": {"ms_per_step": round(wall * 1e3, 2), "kernel_ms": round(kms, 2),
+                                          "kernel_ms_default": round(k_ms, 2),
+                                          "slowdown": round(kms / k_ms, 4),
+                                          "frac_of_fp32_peak": round(flop_per_launch / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
     del cc, mf
     torch.cuda.empty_cache()
     # End to end through the host-pointer entry point (what the reference's call site sees:
@@ -893,7 +912,7 @@ def main():
                                        if world > 1 else "single GPU"),
                        "row0_peak_cc": round(peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "mf_shapes": mf_shapes, "bp": bp_obj,
-            "detection": detect, "shares": shares,
+            "detection": detect, "shares": shares, "compat": compat,
         }
     if dist is not None:
         dist.destroy_process_group()

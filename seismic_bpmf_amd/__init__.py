@@ -13,6 +13,6 @@ The package has no CPU implementation: without ``lib/libbpmf_hip.so`` (built by
 """
 from ._lib import BpmfHipError, device_count, device_info  # noqa: F401
 from .beampower import BeamformerGPU, beamform  # noqa: F401
-from .matched_filter import MatchedFilterGPU, matched_filter  # noqa: F401
+from .matched_filter import MatchedFilterGPU, accept_cpu_arch, matched_filter  # noqa: F401
 
 __version__ = "0.1.0"

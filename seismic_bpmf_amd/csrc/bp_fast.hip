@@ -96,12 +96,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define BPF_LOADX2(dst, vz, sptr, o) \
     asm volatile("global_load_dwordx2 %0, %1, %2 offset:" #o : "=v"(dst) : "v"(vz), "s"(sptr))
 
-// ---- cycle accounting (tools/phase_cycles.sh builds a second library with -DBPMF_PHASE_CYCLES; the
-// shipping library carries none of it).  s_memtime at the phase boundaries of a group entry, summed per
-// wave over all entries; the workgroup of tile 3 overwrites out_arg[3 * TILE + 8 * wave + i] with
-// {barrier wait, descriptor read + copy issue, copy latency + second barrier (single-residency kernels),
-// records + gathers, entries} in units of 64 cycles -- the RESULT of that tile is garbage in such a build.
+// ---- cycle accounting (tools/phase/build_phase_lib.py builds a second library with -DBPMF_PHASE_CYCLES;
+// the shipping library carries none of it).  s_memtime at the phase boundaries of a group entry, summed
+// per wave over all entries and, at the end of the kernel, over all waves of the launch into
+// g_bpf_phase[age group of the wave (wave / 4)][{barrier wait, descriptor read + copy issue, copy latency
+// + second barrier (single-residency kernels), records + gathers, entries}] -- read and reset through
+// bpmf_phase_read_bp (exported by such a build only; tools/phase/bp_phase.py).
 #ifdef BPMF_PHASE_CYCLES
+__device__ unsigned long long g_bpf_phase[4][8];
 #define BPF_PHASE_DECL unsigned long long ph_last_ = 0, ph_acc_[4] = {0, 0, 0, 0}; unsigned ph_n_ = 0;
 #define BPF_PHASE_START() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last_) :: "memory")
 #define BPF_PHASE(i)                                                                               \
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass, int stage_cfg)
 {
     // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
     // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel);
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     // kernel at cfg3, this one 2 %.  The copies count in vmcnt; __syncthreads() waits for them
     // (vmcnt(0)) before the barrier.  `dsc`: the descriptors {row, first sample relative to t0, LDS
     // float offset, floats} of the entry, in LDS.
-    auto stage_windows = [&](const i32x4* dsc, int n_win) {
-        for (int wi = wv; wi < n_win; wi += WPB) {
+    auto stage_windows = [&](const i32x4* dsc, int n_win, int n_stagers) {
+        for (int wi = wv; wi < n_win; wi += n_stagers) {
             const i32x4 d = dsc[wi];
             const int row = __builtin_amdgcn_readfirstlane(d[0]), gofs = __builtin_amdgcn_readfirstlane(d[1]);
             const int dst0 = __builtin_amdgcn_readfirstlane(d[2]), len = __builtin_amdgcn_readfirstlane(d[3]);
@@ -247,22 +249,32 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     // opens entry g (every wave has left entry g - 1, whose half they overwrite) and have the whole
     // gather phase to land before the barrier that opens entry g + 1.  Round 3 staged a whole-LDS
     // residency between two barriers with nothing else running: ~8 000 of ~25 000 cycles per entry
-    // (profiles/r03_bp_fast_phase_cycles.txt).  The descriptors travel two entries ahead through two
-    // slabs of BPF_HALVES_DESC windows (wave 0 copies them).
+    // (profiles/r03_bp_fast_phase_cycles.txt).  Only the BPF_HALVES_STAGERS oldest waves issue copies:
+    // the hardware serves the oldest wave of a SIMD first, so those waves finish their gathers thousands
+    // of cycles before the youngest ones and used to wait at the barrier -- now they spend that time on
+    // the copies while the other eight start gathering at once and the LDS never idles (with all 16
+    // waves issuing copies behind the barrier the LDS stood still for ~2 500 cycles per entry: measured,
+    // profiles/r04_bp_fast_phase_cycles.txt).  The descriptors travel two entries ahead through two slabs
+    // of BPF_HALVES_DESC windows (waves 0 and 1 copy them); the group headers one entry ahead in SGPRs.
     auto prefetch_descriptors_h = [&](int first_win, int slab) {
-        if (wv == 0) {
-            const BpWindow* src = wins + first_win + lane;               // the table is padded by BPF_DESC_MAX
-            float* dst = lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * slab;
+        if (wv < BPF_HALVES_DESC / 64) {
+            const BpWindow* src = wins + first_win + 64 * wv + lane;     // the table is padded by BPF_DESC_MAX
+            float* dst = lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * slab + 256 * wv;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
+    BpFastGroup grp_next = {0, 0, 0, 0}, grp_next2 = {0, 0, 0, 0};      // headers of entries g + 1, g + 2
+    const int n_stagers = stage_cfg & 31;            // waves that issue window copies (the oldest ones)
+    const bool stage_late = (stage_cfg & 32) != 0;   // behind their gathers instead of in front
     if constexpr (HALVES) {
         if (g_hi > g_lo) {
-            prefetch_descriptors_h(groups[g_lo].first_win, 0);
-            if (g_lo + 1 < g_hi) prefetch_descriptors_h(groups[g_lo + 1].first_win, 1);
+            grp_next = groups[g_lo];
+            if (g_lo + 1 < g_hi) grp_next2 = groups[g_lo + 1];
+            prefetch_descriptors_h(grp_next.first_win, 0);
+            if (g_lo + 1 < g_hi) prefetch_descriptors_h(grp_next2.first_win, 1);
             __syncthreads();
-            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), groups[g_lo].n_win);
+            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), grp_next.n_win, WPB);
         }
     } else {
         if (g_hi > g_lo) prefetch_descriptors(groups[g_lo].first_win);
@@ -271,17 +283,25 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     BPF_PHASE_DECL
     BPF_PHASE_START();
     for (int g = g_lo; g < g_hi; ++g) {
-        const BpFastGroup grp = groups[g];
+        BpFastGroup grp;
+        if constexpr (HALVES) {
+            grp = grp_next;                                   // loaded one entry ago
+            grp_next = grp_next2;
+            if (g + 2 < g_hi) grp_next2 = groups[g + 2];      // (its latency runs under this entry)
+        } else {
+            grp = groups[g];
+        }
         __syncthreads();  // previous group's gathers are done, this group's descriptors (HALVES: windows) are in LDS
         BPF_PHASE(0);
         if constexpr (HALVES) {
-            if (g + 1 < g_hi)
-                stage_windows((const i32x4*)(lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * ((g + 1 - g_lo) & 1)), groups[g + 1].n_win);
+            if (!stage_late && g + 1 < g_hi && wv < n_stagers)
+                stage_windows((const i32x4*)(lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * ((g + 1 - g_lo) & 1)), grp_next.n_win,
+                              n_stagers);
             // (slab of entry g: read one barrier ago, when entry g's copies were issued)
-            if (g + 2 < g_hi) prefetch_descriptors_h(groups[g + 2].first_win, (g - g_lo) & 1);
+            if (g + 2 < g_hi) prefetch_descriptors_h(grp_next2.first_win, (g - g_lo) & 1);
             BPF_PHASE(1);
         } else {
-            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), grp.n_win);
+            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), grp.n_win, WPB);
             BPF_PHASE(1);
             __syncthreads();
             if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
@@ -802,6 +822,15 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             }
         }
         BPF_PHASE(3);
+        if constexpr (HALVES) {
+            // stage_late: the oldest waves have finished their gathers thousands of cycles before the youngest
+            // ones (the hardware serves the oldest wave of a SIMD first) and would wait at the barrier: they
+            // issue the copies of the next entry now, while the others still gather
+            if (stage_late && g + 1 < g_hi && wv < n_stagers)
+                stage_windows((const i32x4*)(lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * ((g + 1 - g_lo) & 1)), grp_next.n_win,
+                              n_stagers);
+            BPF_PHASE(1);
+        }
 #ifdef BPMF_PHASE_CYCLES
         ++ph_n_;
 #endif
@@ -829,11 +858,10 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
         if (t < N) { out_beam[t] = b; out_arg[t] = a; }
     }
 #ifdef BPMF_PHASE_CYCLES
-    __syncthreads();
-    if (tile == 3 && blockIdx.y == 0 && lane == 0) {
-        int* dbg = out_arg + 3 * TILE + 8 * wv;
-        for (int i = 0; i < 4; ++i) dbg[i] = (int)(ph_acc_[i] >> 6);
-        dbg[4] = (int)ph_n_;
+    if (lane == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_bpf_phase[wv >> 2][i], ph_acc_[i]);
+        atomicAdd(&g_bpf_phase[wv >> 2][4], (unsigned long long)ph_n_);
+        atomicAdd(&g_bpf_phase[wv >> 2][5], 1ull);
     }
 #endif
 }
@@ -848,6 +876,9 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)std::max(1, n_split));  // x: multiple of 8 (XCD-aware tile order)
     // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
     const int desc_waves = fc.desc_waves;
+    // option bp.halves_stage: which waves issue the window copies of a multi-residency class, and when
+    int stage_cfg = (int)option(OPT_BP_HALVES_STAGE);
+    if ((stage_cfg & 31) != 4 && (stage_cfg & 31) != 8 && (stage_cfg & 31) != 16) stage_cfg = (stage_cfg & 32) | 8;
 #define BPF_LAUNCH(...)                                                                            \
     do {                                                                                           \
         auto kern = bp_beam_fast_kernel<__VA_ARGS__>;                                              \
@@ -857,7 +888,7 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
             fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0,   \
-            fc.halves ? fc.n_pass : 1);                                                               \
+            fc.halves ? fc.n_pass : 1, stage_cfg);                                                    \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
     else if (fc.tile == 256 && fc.halves) { if (fc.uniform) BPF_LAUNCH(true, 4, true); else BPF_LAUNCH(false, 4, true); }
@@ -869,3 +900,17 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
 }
 
 }  // namespace bpmf
+
+#ifdef BPMF_PHASE_CYCLES
+// 4 age groups x {4 phase sums, entries, waves, -, -}; reset != 0 clears the counters afterwards
+extern "C" int bpmf_phase_read_bp(unsigned long long* out32, int reset)
+{
+    BPMF_HIP_CHECK(hipDeviceSynchronize());
+    BPMF_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(bpmf::g_bpf_phase), sizeof(bpmf::g_bpf_phase)));
+    if (reset) {
+        unsigned long long z[4][8] = {};
+        BPMF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bpmf::g_bpf_phase), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif

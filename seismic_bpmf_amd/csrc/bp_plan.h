@@ -38,7 +38,8 @@ struct BpFastGroup { int first_run, n_run, first_win, n_win; };
 // Two-residency groups (sources with 33-64 stations at tile 256, see bp_fast.hip): flags in n_run
 constexpr int BPF_GROUP_LOAD = 1 << 16, BPF_GROUP_STORE = 1 << 17;
 constexpr int BPF_HALVES_SLOTS = 9;      // sources per wave of a multi-residency group (16 waves: 144 per group)
-constexpr int BPF_HALVES_DESC = 64;      // window descriptors per slab of a multi-residency class (two slabs)
+constexpr int BPF_HALVES_DESC = 128;     // window descriptors per slab of a multi-residency class (two slabs)
+constexpr int BPF_HALVES_STAGERS = 8;    // waves of a workgroup that issue the window copies (the oldest two of every SIMD)
 // one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
 // offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
 struct BpWindow { int row, gofs, dst, len; };

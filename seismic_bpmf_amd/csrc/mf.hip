@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict__ tmpl, const int* __restrict__ mv,
                                                          const float* __restrict__ w, int T, int n_ch, long long step,
                                                          long long L, long long N, long long n_corr, int exclusive_last,
-                                                         float* __restrict__ e_t, int2* __restrict__ range,
+                                                         int sqrt_norm, float* __restrict__ e_t, int2* __restrict__ range,
                                                          int4* __restrict__ chan_rec)
 {
     const int t = blockIdx.x;
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict
         const float* x = tmpl + ((size_t)t * n_ch + ch) * (size_t)L;
         float acc = 0.0f;
         for (int l = 0; l < (int)L; ++l) acc = __fmaf_rn(x[l], x[l], acc);
-        e_t[(size_t)t * n_ch + ch] = 1.0f / sqrtf(acc);  // reciprocal norm r_t (Inf for an all-zero template)
+        // reciprocal norm r_t (Inf for an all-zero template); mf.compat_sqrt_norm: the energy itself
+        e_t[(size_t)t * n_ch + ch] = sqrt_norm ? acc : 1.0f / sqrtf(acc);
     }
     __syncthreads();       // (workgroup-scope release / acquire: thread 0 reads what the others stored)
     if (threadIdx.x != 0) return;
@@ -176,7 +177,7 @@ __global__ void mf_csum_offsets_kernel(const double* __restrict__ tot, size_t n_
 // csum[n] = off[chunk(n-1)] + local[n-1].
 __global__ void mf_window_energy_kernel(const double* __restrict__ local,
                                         const double* __restrict__ off, size_t n_ch, size_t N,
-                                        size_t nq, size_t L, size_t nwin,
+                                        size_t nq, size_t L, size_t nwin, int sqrt_norm,
                                         float* __restrict__ e_d)
 {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,7 +189,8 @@ __global__ void mf_window_energy_kernel(const double* __restrict__ local,
     double hi = of[nh / CSUM_CHUNK] + lo[nh];
     double low = 0.0;
     if (j > 0) low = of[(j - 1) / CSUM_CHUNK] + lo[j - 1];
-    e_d[ch * nwin + j] = 1.0f / sqrtf((float)(hi - low));  // reciprocal norm r_d
+    const float e = (float)(hi - low);
+    e_d[ch * nwin + j] = sqrt_norm ? e : 1.0f / sqrtf(e);  // reciprocal norm r_d (mf.compat_sqrt_norm: the energy E_d)
 }
 
 // --------------------------------------------------------------- MFMA main kernel ---
@@ -208,6 +210,23 @@ __global__ void mf_window_energy_kernel(const double* __restrict__ local,
 //   after it, one barrier per channel.
 // LDS data layout: dw[x + (x >> 4)] = data[g0 + x]  (one pad float per 16) so that the 16
 // tile columns of a B read (stride 16 floats) fall on 16 different banks.
+
+// One channel's CC from its numerator and the two stored norms.  Default: the norms are RECIPROCALS
+// (r_t = 1 / sqrtf(E_t), r_d = 1 / sqrtf(E_d)): cc = num * (r_t * r_d), 0 where the product is not below
+// 1000.  SQRT_NORM (option mf.compat_sqrt_norm, the form upstream is recollected to use): the stored
+// norms are the ENERGIES E_t and E_d, cc = num / sqrtf(E_t * E_d) where the product exceeds 1e-6, else 0
+// -- an IEEE square root and an IEEE divide per channel and lag.
+template <bool SQRT_NORM>
+__device__ __forceinline__ float mf_cc_of(float num, float nt, float nd)
+{
+    if constexpr (SQRT_NORM) {
+        const float den2 = nt * nd;
+        return den2 > 1.0e-6f ? num / sqrtf(den2) : 0.0f;
+    } else {
+        const float nrm = nt * nd;
+        return nrm < MAX_NORM ? num * nrm : 0.0f;
+    }
+}
 
 constexpr int MF_THREADS = 256;
 constexpr int MF_LAGS_PER_WAVE = 1024;
@@ -291,7 +310,7 @@ __device__ __forceinline__ void mf_stage_band(float (&rt)[NR], __amdgpu_buffer_r
                                               rs, idx * 4 + (STRIDE * r - 15) * 4, 0, 0));
 }
 
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1>
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, bool SQRT_NORM = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
@@ -479,8 +498,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                 for (int u = 0; u < 4; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float nrm = et * ed[u][r];  // r_t * r_d
-                        const float cc = nrm < MAX_NORM ? acc[u][r] * nrm : 0.0f;
+                        const float cc = mf_cc_of<SQRT_NORM>(acc[u][r], et, ed[u][r]);
                         sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                     }
                 }
@@ -494,8 +512,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
                     const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
                     if (ok) {
-                        const float nrm = et * ed[u][r];  // r_t * r_d
-                        if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
+                        cc = mf_cc_of<SQRT_NORM>(acc[u][r], et, ed[u][r]);
                         if (!NETWORK_SUM)
                             out[((size_t)t * n_corr + (STEP1 ? lag : (long long)((unsigned)lag / (unsigned)step))) * n_ch + ch] = cc;
                     }
@@ -543,10 +560,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 // three to a SIMD).  The hand-placed operand reads and their counted waits follow NTILE.
 // Cycle accounting (tools/phase/build_phase_lib.py builds a second library with -DBPMF_PHASE_CYCLES; the
 // shipping library carries none of it): s_memtime at the phase boundaries of a channel, summed per wave
-// over its channels; the workgroup of (template 0, lag block 3) overwrites out[row 0, LAGS_WG * 3 + 8 *
-// wave + i] with {staging writes, norm loads + staging issue, K loop, epilogue, channels} -- cycles as
-// floats; those CC values are garbage in such a build (tools/phase/mf_phase.py reads them).
+// over its channels and, at the end of the kernel, over all waves of the launch into g_mf_phase[{staging
+// writes, norm loads + staging issue, K loop, epilogue, channels, waves}] -- read and reset through
+// bpmf_phase_read_mf (exported by such a build only; tools/phase/mf_phase.py).
 #ifdef BPMF_PHASE_CYCLES
+__device__ unsigned long long g_mf_phase[8];
 #define MF_PHASE_DECL unsigned long long ph_last_ = 0, ph_acc_[4] = {0, 0, 0, 0}; unsigned ph_n_ = 0;
 #define MF_PHASE_START() asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_last_) :: "memory")
 #define MF_PHASE(i)                                                                                \
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
 #define MF_PHASE(i) do {} while (0)
 #endif
 
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4>
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4, bool SQRT_NORM = false>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
@@ -749,8 +767,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                 for (int u = 0; u < NTILE; ++u) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float nrm = et * ed[u][r];  // r_t * r_d
-                        const float cc = nrm < MAX_NORM ? acc[u][r] * nrm : 0.0f;
+                        const float cc = mf_cc_of<SQRT_NORM>(acc[u][r], et, ed[u][r]);
                         sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                     }
                 }
@@ -764,8 +781,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
                     const bool ok = lag >= rg.x && lag <= rg.y && (STEP1 || (unsigned)lag % (unsigned)step == 0);
                     float cc = 0.0f;
                     if (ok) {
-                        const float nrm = et * ed[u][r];  // r_t * r_d
-                        if (nrm < MAX_NORM) cc = acc[u][r] * nrm;
+                        cc = mf_cc_of<SQRT_NORM>(acc[u][r], et, ed[u][r]);
                         if (!NETWORK_SUM)
                             out[((size_t)t * n_corr + (STEP1 ? lag : (long long)((unsigned)lag / (unsigned)step))) * n_ch + ch] = cc;
                     }
@@ -800,13 +816,10 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         }
     }
 #ifdef BPMF_PHASE_CYCLES
-    if (NETWORK_SUM && t == 0 && lag_block == 3) {
-        __builtin_amdgcn_s_barrier();
-        if (lane == 0) {
-            float* dbg = out + (size_t)LAGS_WG * 3 + 8 * wv;
-            for (int i = 0; i < 4; ++i) dbg[i] = (float)ph_acc_[i];
-            dbg[4] = (float)ph_n_;
-        }
+    if (lane == 0 && ph_n_) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_mf_phase[i], ph_acc_[i]);
+        atomicAdd(&g_mf_phase[4], (unsigned long long)ph_n_);
+        atomicAdd(&g_mf_phase[5], 1ull);
     }
 #endif
 }
@@ -956,8 +969,11 @@ extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N,
     mf_csum_offsets_kernel<<<dim3((unsigned)((n_ch + 63) / 64)), dim3(64), 0, stream>>>(
         ws.tot, n_ch, nq, ws.off);
     BPMF_LAUNCH_CHECK();
+    // (option mf.compat_sqrt_norm decides what the norm arrays hold: a caller of the *_dev entry points
+    // that switches it prepares the data again -- MatchedFilterGPU keys its prepared state by it)
     mf_window_energy_kernel<<<dim3((unsigned)((nwin + 255) / 256), (unsigned)n_ch), dim3(256), 0,
-                              stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin, ws.e_d);
+                              stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin,
+                                        option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_d);
     BPMF_LAUNCH_CHECK();
     return 0;
 }
@@ -989,7 +1005,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         // template norms, lag ranges, channel records: one launch, one workgroup per template
         mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(
             d_templates, d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
-            (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
+            (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0,
+            option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
         BPMF_LAUNCH_CHECK();
     }
     if (!network_sum)
@@ -1006,17 +1023,21 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);  // beyond this (64) the direct kernel wins
     // (the MFMA kernels address the data through buffer descriptors with 32-bit byte offsets:
     // traces of 2^30 samples or more take the generic kernel)
-    const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;     // generic kernel only
-    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !sqrt_norm && need_r <= 24 &&
+    // option mf.compat_sqrt_norm: num / sqrtf(E_t * E_d) in the epilogue of the MFMA kernels too (network
+    // sums; per-channel output with the switch on takes the generic kernel)
+    const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;
+    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !(sqrt_norm && !network_sum) && need_r <= 24 &&
                           need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
                           N < ((size_t)1 << 30) - 8192;
     if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks / 8) lag blocks x T templates (mf_tile_of_block)
         dim3 grid((unsigned)(T * 8 * ((n_lag_blocks + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
-#define BPMF_MF_LAUNCH2(NS, R, TT, S1)                                                            \
+#define BPMF_MF_LAUNCH2(NS, R, TT, S1) \
+    do { if (NS && sqrt_norm) BPMF_MF_LAUNCH3(NS, R, TT, S1, NS); else BPMF_MF_LAUNCH3(NS, R, TT, S1, false); } while (0)
+#define BPMF_MF_LAUNCH3(NS, R, TT, S1, SQ)                                                        \
     do {                                                                                              \
-        auto kfn = mf_mfma_kernel<NS, R, TT, S1>;                                                     \
+        auto kfn = mf_mfma_kernel<NS, R, TT, S1, SQ>;                                                 \
         if (big_lds)                                                                                  \
             BPMF_HIP_CHECK(hipFuncSetAttribute((const void*)kfn,                                      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -1043,10 +1064,12 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             }
             dim3 grid_w((unsigned)(T * 8 * ((n_blocks_w + 7) / 8)));
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256;
-#define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT)                                                     \
-    mf_mfma_wave_kernel<NS, R, 5, S1, NT><<<grid_w, dim3(MF_THREADS), wl, stream>>>(            \
+#define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ)                                                 \
+    mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ><<<grid_w, dim3(MF_THREADS), wl, stream>>>(        \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
         (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w)
+#define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT) \
+    do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false); } while (0)
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
     do {                                                                                         \
         if (ntile == 4) BPMF_MF_WAVE_LAUNCH3(NS, S1, 20, 4);                                     \
@@ -1059,6 +1082,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             else BPMF_MF_WAVE_LAUNCH(false, false);
 #undef BPMF_MF_WAVE_LAUNCH
 #undef BPMF_MF_WAVE_LAUNCH3
+#undef BPMF_MF_WAVE_LAUNCH4
         } else if (need_r <= 17 && need_t <= 2) {   // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041
@@ -1068,6 +1092,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         }
 #undef BPMF_MF_LAUNCH
 #undef BPMF_MF_LAUNCH2
+#undef BPMF_MF_LAUNCH3
     } else {
         dim3 grid((unsigned)((n_corr + 255) / 256), (unsigned)T);
         if (T > 65535) {
@@ -1226,3 +1251,17 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
 #undef MF_TRY
     return rc;
 }
+
+#ifdef BPMF_PHASE_CYCLES
+// {4 phase sums, channels, waves, -, -}; reset != 0 clears the counters afterwards
+extern "C" int bpmf_phase_read_mf(unsigned long long* out8, int reset)
+{
+    BPMF_HIP_CHECK(hipDeviceSynchronize());
+    BPMF_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(bpmf::g_mf_phase), sizeof(bpmf::g_mf_phase)));
+    if (reset) {
+        unsigned long long z[8] = {};
+        BPMF_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bpmf::g_mf_phase), z, sizeof(z)));
+    }
+    return 0;
+}
+#endif

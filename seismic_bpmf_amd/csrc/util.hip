@@ -48,6 +48,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"bp.fast_tile", 0, 0, 512, true},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
     {"bp.halves", 1, 0, 1, true},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
     {"bp.direct", 0, 0, 1, true},             // 1: every plan takes the global-memory path of bp_direct.hip (tests)
+    {"bp.halves_stage", 40, 0, 63, false},    // multi-residency kernel: waves that issue the window copies (low 5 bits: 4 / 8 / 16) + 32: behind their gathers instead of in front
     {"mf.wave_kernel", 1, 0, 1, false},        // independent-wave kernel for L <= 257
     {"mf.max_mfma_step", 64, 0, 1 << 20, false},  // larger steps take the generic kernel
     {"mf.host_batch_kb", 0, 0, 1L << 30, false},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)
@@ -55,7 +56,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.verbose", 0, 0, 1, false},
     {"mf.tiles_per_wave", 0, 0, 4, false},     // 16x16 tiles per wave of the L <= 257 kernel: 0 = by problem size, 1 / 2 / 4
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
-    {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (generic kernel; default: num * r_t * r_d)
+    {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))
 };
 std::atomic<long> g_options[OPT_COUNT];

@@ -15,34 +15,40 @@ Two levels:
     as device buffers).
 """
 import ctypes as C
-import os
 
 import numpy as np
 
 from . import _lib
 
 GPU_ARCHS = ("gpu", "hip", "mi355x")
-_cpu_arch_notice = [False]
+_accept_cpu_arch = [False, False]        # [opted in, notice printed]
+
+
+def accept_cpu_arch(accept=True):
+    """Opt in to serving calls that ask for arch / device = "cpu" ON THE MI355X (one notice on stderr):
+    the reference's call sites default to "cpu" (BPMF/similarity_search.py:476, 729;
+    template_search.py:512), and a BPMF run that cannot be edited to pass "gpu" calls this once from
+    its driver script.  There is still no CPU path.  (Rounds 2-3 read an environment variable for
+    this; the package, like the library, takes no input from the process's variables now.)"""
+    _accept_cpu_arch[0] = bool(accept)
 
 
 def require_gpu_arch(value, keyword):
-    """The reference's call sites default to arch / device = "cpu" (BPMF/similarity_search.py:476, 729;
-    template_search.py:512).  This package has no CPU implementation and never falls back to one:
-    anything but a GPU name raises -- unless the user opted in with BPMF_AMD_ACCEPT_CPU_ARCH=1, which
-    serves such calls ON THE MI355X (one notice on stderr), so that an unedited BPMF run with its
-    default arguments works through the shims."""
+    """This package has no CPU implementation and never falls back to one: anything but a GPU name
+    raises -- unless the user opted in with :func:`accept_cpu_arch`, which serves such calls on the
+    MI355X, so that an unedited BPMF run with its default arguments works through the shims."""
     if str(value).lower() in GPU_ARCHS:
         return
-    if os.environ.get("BPMF_AMD_ACCEPT_CPU_ARCH", "0") not in ("", "0"):
-        if not _cpu_arch_notice[0]:
-            _cpu_arch_notice[0] = True
+    if _accept_cpu_arch[0]:
+        if not _accept_cpu_arch[1]:
+            _accept_cpu_arch[1] = True
             import sys
-            print(f"seismic_bpmf_amd: {keyword}={value!r} requested, BPMF_AMD_ACCEPT_CPU_ARCH is set: "
+            print(f"seismic_bpmf_amd: {keyword}={value!r} requested, accept_cpu_arch() is on: "
                   "running on the MI355X (this package has no CPU path)", file=sys.stderr)
         return
     raise ValueError(
         f"{keyword}={value!r}: seismic_bpmf_amd only implements the MI355X path ({keyword}='gpu'); "
-        "it has no CPU implementation (set BPMF_AMD_ACCEPT_CPU_ARCH=1 to serve such calls on the GPU)")
+        "it has no CPU implementation (seismic_bpmf_amd.accept_cpu_arch() serves such calls on the GPU)")
 
 FLAG_DATA_PREPARED = 1
 FLAG_FORCE_DIRECT = 2
@@ -215,7 +221,8 @@ class MatchedFilterGPU:
         nbytes = self.lib.bpmf_mf_workspace_bytes(L, N, T, S, Cc)
         ws = self._workspace(nbytes)
         flags = FLAG_FORCE_DIRECT if force_direct else 0
-        key = (self.data.data_ptr(), int(N), int(L), ws.data_ptr())
+        # (the prepared norm arrays hold energies under mf.compat_sqrt_norm, reciprocal norms otherwise)
+        key = (self.data.data_ptr(), int(N), int(L), ws.data_ptr(), _lib.get_option("mf.compat_sqrt_norm")[0])
         if self._prepared_for == key:
             flags |= FLAG_DATA_PREPARED
         stream = t.cuda.current_stream(self.device).cuda_stream

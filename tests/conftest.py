@@ -19,6 +19,17 @@ def pytest_configure(config):
         handler = ctypes.CDLL(stress_multi.build_crash_lib())
         handler.crash_bt_install(f"pytest-{os.environ.get('PYTEST_XDIST_WORKER', 'main')}".encode())
         config._bpmf_crash_bt = handler
+    # BPMF_STRESS_OLD_LIB=path: run the suite against an OLDER build of the library (the round-3 build kept
+    # beside the stress tools, to reproduce its crash with native backtraces): symbols that build lacks
+    # are dropped from the binding's list
+    old = os.environ.get("BPMF_STRESS_OLD_LIB")
+    if old:
+        import ctypes
+        from seismic_bpmf_amd import _lib
+        _lib.LIBPATH = os.path.join(ROOT, old)
+        have = ctypes.CDLL(_lib.LIBPATH)
+        for name in [n for n in _lib.SIGNATURES if not hasattr(have, n)]:
+            del _lib.SIGNATURES[name]
 
 
 @pytest.fixture(scope="session")

@@ -58,8 +58,16 @@ def test_mf_sqrt_norm(oracle_lib, hip_opts, step, network_sum):
     assert not np.array_equal(base, want) and np.abs(base - want).max() < 2e-6
     assert np.array_equal(base == 0, want == 0)
     hip_opts("mf.compat_sqrt_norm", 1)
-    got = matched_filter(*args, arch="gpu", network_sum=network_sum, check_zeros=False)
-    assert np.array_equal(got, want), (step, network_sum)
+    # round 4: the MFMA kernels carry the form in their epilogue (network sums; per-channel output takes
+    # the generic kernel): the independent-wave kernel at 1 / 2 / 4 tiles per wave, the workgroup kernel,
+    # the generic kernel
+    for wave, ntile in ((1, 0), (1, 1), (1, 2), (1, 4), (0, 0)):
+        hip_opts("mf.wave_kernel", wave)
+        hip_opts("mf.tiles_per_wave", ntile)
+        got = matched_filter(*args, arch="gpu", network_sum=network_sum, check_zeros=False)
+        assert np.array_equal(got, want), (step, network_sum, wave, ntile)
+    hip_opts("mf.max_mfma_step", 0)
+    assert np.array_equal(matched_filter(*args, arch="gpu", network_sum=network_sum, check_zeros=False), want)
     # both MF switches together
     hip_opts("mf.compat_exclusive_last_lag", 1)
     with oracle_lib.compat(oracle_lib.COMPAT_SQRT_NORM | oracle_lib.COMPAT_EXCLUSIVE_LAST_LAG):
@@ -122,3 +130,27 @@ def test_unknown_option_and_range_are_errors():
     with pytest.raises(_lib.BpmfHipError, match="outside"):
         _lib.set_option("bp.compat_first_computed", 2)
     assert _lib.get_option("mf.compat_sqrt_norm") == (0, 0)
+
+
+@pytest.mark.parametrize("L", [100, 256, 300, 1100])
+def test_mf_sqrt_norm_mfma_kernels_resident(oracle_lib, hip_opts, L):
+    """The resident engine under mf.compat_sqrt_norm: every MFMA kernel size (L <= 257 wave kernel, the
+    workgroup kernels of L <= 273 / 1041 / 2065), the prepared energies re-made when the switch flips
+    between two runs on the same data (the norm arrays hold energies with the switch on, reciprocal norms
+    with it off)."""
+    import torch
+    from seismic_bpmf_amd import MatchedFilterGPU, synthetic as syn
+    m = syn.make_mf_inputs(T=3, S=3, C=2, L=L, N=14_000, seed=L, max_moveout=150, n_events=1)
+    m["data"][1, 0, 5000:5000 + L + 40] = 0.0
+    args = (m["templates"], m["moveouts"], m["weights"], m["data"], 1)
+    base = oracle_lib.matched_filter(*args)
+    with oracle_lib.compat(oracle_lib.COMPAT_SQRT_NORM):
+        want = oracle_lib.matched_filter(*args)
+    mf = MatchedFilterGPU()
+    mf.set_data(m["data"])
+    assert np.array_equal(mf.run(m["templates"], m["moveouts"], m["weights"], 1).cpu().numpy(), base)
+    hip_opts("mf.compat_sqrt_norm", 1)
+    assert np.array_equal(mf.run(m["templates"], m["moveouts"], m["weights"], 1).cpu().numpy(), want)
+    assert np.array_equal(mf.run(m["templates"], m["moveouts"], m["weights"], 1).cpu().numpy(), want)
+    hip_opts.reset("mf.compat_sqrt_norm")
+    assert np.array_equal(mf.run(m["templates"], m["moveouts"], m["weights"], 1).cpu().numpy(), base)

@@ -19,16 +19,23 @@ def test_shims_resolve_to_the_hip_call_surface():
             sys.modules.pop(m, None)
 
 
-def test_cpu_arch_is_refused_unless_the_user_opts_in(monkeypatch):
+def test_cpu_arch_is_refused_unless_the_user_opts_in():
     """The reference's defaults are arch / device = "cpu"; the package has no CPU path and says so --
-    or, with BPMF_AMD_ACCEPT_CPU_ARCH=1, serves the call on the MI355X (never on a CPU)."""
+    or, after seismic_bpmf_amd.accept_cpu_arch(), serves the call on the MI355X (never on a CPU).  The
+    package reads nothing from the environment."""
     import pytest
     import importlib
+    import inspect
+    import seismic_bpmf_amd
     mfm = importlib.import_module("seismic_bpmf_amd.matched_filter")
-    monkeypatch.delenv("BPMF_AMD_ACCEPT_CPU_ARCH", raising=False)
+    seismic_bpmf_amd.accept_cpu_arch(False)
     for kw, v in (("arch", "cpu"), ("device", "cpu"), ("arch", "precise")):
         with pytest.raises(ValueError, match="no CPU implementation"):
             mfm.require_gpu_arch(v, kw)
     mfm.require_gpu_arch("gpu", "arch")
-    monkeypatch.setenv("BPMF_AMD_ACCEPT_CPU_ARCH", "1")
-    mfm.require_gpu_arch("cpu", "arch")            # accepted: the caller proceeds to the HIP library
+    seismic_bpmf_amd.accept_cpu_arch(True)
+    try:
+        mfm.require_gpu_arch("cpu", "arch")            # accepted: the caller proceeds to the HIP library
+    finally:
+        seismic_bpmf_amd.accept_cpu_arch(False)
+    assert "os.environ" not in inspect.getsource(mfm) and "getenv" not in inspect.getsource(mfm)

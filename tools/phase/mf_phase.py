@@ -29,26 +29,29 @@ def run(L, T=32, S=20, C=3, N=8_640_000):
     mf.set_data(data)
     cc = mf.run(tmpl, mv, w, 1)
     torch.cuda.synchronize()
+    import ctypes
+    _lib.lib().bpmf_phase_read_mf((ctypes.c_ulonglong * 8)(), 1)      # clear the warm-up launch
     _lib.profile_enable(True)
     cc = mf.run(tmpl, mv, w, 1, out=cc)
     torch.cuda.synchronize()
     _lib.profile_enable(False)
     ms = _lib.profile_times_ms(_lib.KERNEL_MF_MAIN)[0]
-    row = cc[0, 4096 * 3: 4096 * 3 + 64].cpu().numpy()
-    per_wave = []
-    for wv in range(4):
-        v = row[8 * wv: 8 * wv + 5].astype(np.float64)
-        per_wave.append(v[:4] / max(1.0, v[4]))
-    c = np.mean(per_wave, axis=0)
-    # sustained shader clock: a wave's cycles per channel x channels x rounds of workgroups = kernel time
-    n_wg = T * ((N - L + 1 + 4095) // 4096)
-    rounds = n_wg / (256 * 4)                     # 4 workgroups (16 waves) per CU
-    ghz = rounds * S * C * c.sum() / (ms * 1e-3) / 1e9
+    import ctypes
+    raw = (ctypes.c_ulonglong * 8)()
+    assert _lib.lib().bpmf_phase_read_mf(raw, 1) == 0
+    v = np.array(list(raw), dtype=np.float64)
+    c = v[:4] / max(1.0, v[4])                    # cycles per channel and wave, mean over every wave of the launch
+    # sustained shader clock: the cycles all waves counted / (waves resident at a time x kernel time);
+    # 16 waves per CU are resident (128 VGPRs), the tail of the launch makes this a slight underestimate
+    ghz = v[:4].sum() / (256 * 16) / (ms * 1e-3) / 1e9
     flop = 2.0 * L * S * C * T * (N - L + 1)
+    kpad = (L + 15 + 15) // 16 * 16
+    pipe = 4 * (kpad // 16) * 16 * 32             # cycles the matrix pipe of a SIMD needs per channel for its 4 waves
     print(f"L = {L:4d}: " + "  ".join(f"{n} {x:8.0f}" for n, x in zip(NAMES, c)) +
-          f"   total {c.sum():8.0f} cycles per channel and wave; kernel {ms:.1f} ms "
+          f"   total {c.sum():8.0f} cycles per channel and wave (matrix pipe of the SIMD: {pipe} for its 4 waves = "
+          f"{pipe / c.sum() * 100:.0f} % busy); kernel {ms:.1f} ms "
           f"({flop / (ms * 1e-3) / 1e12 / 157.3 * 100:.1f} % of the fp32-MFMA peak, instrumented build); "
-          f"sustained clock {ghz:.2f} GHz")
+          f"sustained clock ~{ghz:.2f} GHz", flush=True)
 
 
 if __name__ == "__main__":

@@ -146,12 +146,16 @@ def main():
     ap.add_argument("--no-torch", action="store_true")
     ap.add_argument("--timeout", type=int, default=1500)
     ap.add_argument("--child", type=int, default=-1)
+    ap.add_argument("--hogs", type=int, default=0,
+                    help="busy-loop processes beside the workers (CPU oversubscription: what 8 xdist workers x 16 idle-"
+                         "spinning OpenMP threads of the oracle did to the round-3 sessions that crashed)")
     args = ap.parse_args()
     if args.child >= 0:
         return child(args)
     build_crash_lib()
     os.makedirs(args.out, exist_ok=True)
     procs = []
+    hogs = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(args.hogs)]
     t0 = time.time()
     for p in range(args.procs):
         log = open(os.path.join(args.out, f"proc{p}.log"), "w")
@@ -168,6 +172,9 @@ def main():
             pr.kill()
             rcs.append("timeout")
         log.close()
+    for h in hogs:                 # (exact PIDs of processes this script started)
+        h.kill()
+        h.wait()
     dead = [(p, rc) for p, rc in enumerate(rcs) if rc != 0]
     print(f"stress {os.path.basename(args.lib)} procs={args.procs} threads={args.threads} calls={args.calls}: "
           f"exit codes {rcs} in {time.time() - t0:.1f} s; {len(dead)} abnormal")
