@@ -700,8 +700,10 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 BPS_WAIT(A)
                 f32x2 X[RING][4];
                 BPS_ISSUE(A, 0, 0) BPS_ISSUE(A, 1, 1)
-                f32x2 ac[RPT];
-                auto part = [&](auto& cur, auto& nxt, auto ph_c) __attribute__((always_inline)) {
+                // `ac`: the partial beams of the slot's source -- the slot's `carry` registers themselves (no copy
+                // in or out: at 10 stations per record the moves were a tenth of the VALU work of a slot, and the
+                // VALU pipe, not the LDS, is what a tile-256 slot saturates first)
+                auto part = [&](auto& cur, auto& nxt, auto ph_c, f32x2 (&ac)[RPT]) __attribute__((always_inline)) {
                     constexpr int PH = decltype(ph_c)::value;
                     p = (const int*)((const char*)p + rec_stride);
                     BPS_LOAD(nxt)                    // (the table is padded by one round of records: no clamp)
@@ -739,17 +741,14 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 };
                 auto slot_step = [&](auto sc) __attribute__((always_inline)) {
                     constexpr int SLOT = decltype(sc)::value;
-                    (void)&carry; (void)&ac; (void)&A; (void)&B;
+                    (void)&carry; (void)&A; (void)&B;
+                    if (!g_load) {                               // first residency: the chains start from +0
 #pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
-                        ac[r][1] = g_load ? carry[SLOT][r][1] : 0.0f;
+                        for (int r = 0; r < RPT; ++r) carry[SLOT][r] = (f32x2){0.0f, 0.0f};
                     }
                     // one record per source and residency; the two SGPR buffers alternate from slot to slot
-                    if constexpr (SLOT % 2 == 0) part(A, B, std::integral_constant<int, (SLOT * NU) % RING>{});
-                    else part(B, A, std::integral_constant<int, (SLOT * NU) % RING>{});
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) carry[SLOT][r] = ac[r];      // (dead in the last residency)
+                    if constexpr (SLOT % 2 == 0) part(A, B, std::integral_constant<int, (SLOT * NU) % RING>{}, carry[SLOT]);
+                    else part(B, A, std::integral_constant<int, (SLOT * NU) % RING>{}, carry[SLOT]);
                 };
                 bpf_for_each(slot_step, std::make_integer_sequence<int, NSLOT>{});
                 // the units issued past the wave's last part (they read whatever record follows: valid LDS
