@@ -1196,13 +1196,10 @@ bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& orde
 
 // Multi-residency plan (bp_fast.hip, HALVES): dual windows at `tile`, groups of at most `max_group`
 // sources, the weighted stations of every source dealt to residencies of `per` stations each (in
-// station order: the first `per`, the next `per`, ...).  A residency owns HALF of the LDS behind the
-// zero slab and the descriptor slabs -- consecutive entries alternate between the two halves, so that
-// the kernel copies the windows of entry e + 1 into one half while it gathers entry e from the other --
-// and a group is closed when any residency's windows would exceed that half.  Every group becomes
-// ph.n_pass consecutive entries of ph.groups (same sources, the chunks of one residency each, LDS
-// offsets inside the entry's half); ph.off holds the offsets of a source's terms inside the residency
-// they belong to.
+// station order: the first `per`, the next `per`, ...); a group is closed when any residency's windows
+// would exceed `hard_floats` of LDS.  Every group becomes ph.n_pass consecutive entries of ph.groups
+// (same sources, the chunks of one residency each); ph.off holds the offsets of a source's terms inside
+// the residency they belong to.
 bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int>& order_in, size_t S, size_t P,
                        int tile, int chunk, const size_t hard_floats, int max_group, int32_t id_offset,
                        int per, int n_pass, int slots, PlanHost& ph)
@@ -1213,9 +1210,7 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     std::vector<int> order = order_in;
     const size_t K = order.size();
     const size_t zero_slab = (size_t)BPF_ZERO_SLAB;
-    const size_t slab_extra = (size_t)4 * 2 * BPF_HALVES_DESC;      // two descriptor slabs of 64 windows
-    if (hard_floats < zero_slab + slab_extra + 2 * 4096) return false;
-    const size_t half_cap = (hard_floats - zero_slab - slab_extra) / 2 & ~(size_t)3;   // floats of one half
+    const size_t slab_extra = (size_t)4 * std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64);
     size_t max_terms = 1;
     ph = PlanHost();
     ph.n_pass = n_pass;
@@ -1249,19 +1244,16 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     struct RowUpdate { int h; size_t row; int lo, hi; };
     std::vector<RowUpdate> upd;
     std::vector<size_t> need(n_pass), need2(n_pass);
-    std::vector<int> nrow(n_pass), nrow2(n_pass);       // rows staged per residency (two windows each)
     size_t first = 0;
     while (first < K) {
         for (int h = 0; h < n_pass; ++h) {
             std::fill(used[h].begin(), used[h].end(), 0);
-            need[h] = 0;
-            nrow[h] = 0;
+            need[h] = zero_slab + slab_extra;
         }
         size_t q = first;
         for (; q < K && (int)(q - first) < max_group; ++q) {
             const size_t k = (size_t)order[q];
             need2 = need;
-            nrow2 = nrow;
             upd.clear();
             int ord = 0;
             for (size_t s = 0; s < S; ++s) {
@@ -1278,7 +1270,6 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
                         need2[h] += row_cost(hi - lo) - row_cost(gmax[h][r] - gmin[h][r]);
                     } else {
                         need2[h] += row_cost(0);
-                        ++nrow2[h];
                     }
                     upd.push_back(RowUpdate{h, r, lo, hi});
                     // (a row may appear in several residencies of a GROUP -- different sources count a
@@ -1286,10 +1277,7 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
                 }
             }
             bool fits = true;
-            // (a residency's windows are listed in one descriptor slab of BPF_HALVES_DESC entries, two per
-            // (station, phase) row: sources that count their stations differently can bring more than
-            // `per` stations into one residency of the group)
-            for (int h = 0; h < n_pass; ++h) fits = fits && need2[h] <= half_cap && 2 * nrow2[h] <= BPF_HALVES_DESC;
+            for (int h = 0; h < n_pass; ++h) fits = fits && need2[h] <= hard_floats;
             if (!fits) {
                 if (q == first) return false;
                 break;
@@ -1300,14 +1288,12 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
                 gmax[u.h][u.row] = u.hi;
             }
             need = need2;
-            nrow = nrow2;
         }
         std::sort(order.begin() + first, order.begin() + q);          // ascending ids inside the group
         for (size_t qq = first; qq < q; ++qq) ph.srcs[qq] = src_of((size_t)order[qq]);
         for (int h = 0; h < n_pass; ++h) {
             BpGroup g{(int)first, (int)(q - first), (int)ph.chunks.size(), 0};
-            // entries alternate between the two halves, whatever the number of residencies per group
-            size_t o = zero_slab + slab_extra + (ph.groups.size() & 1) * half_cap;
+            size_t o = zero_slab + slab_extra;
             for (size_t r = 0; r < SP; ++r) {
                 base[h][r] = -1;
                 if (!used[h][r]) continue;
@@ -1412,11 +1398,10 @@ double plan_cost(const PlanHost& ph, int tile)
         double terms = 0.0;
         for (int q = g.first_src; q < g.first_src + g.n_src; ++q) terms += ph.srcs[q].nterm;
         // an entry of a multi-residency plan is one residency: `per` stations of every source (padded
-        // records), and a short group is padded to 16 x BPF_HALVES_SLOTS sources; the window copies of the
-        // next entry run beside the gathers (the other half of the LDS): what is left between the gathers
-        // of two entries is the barrier and the first record
+        // records), and a short group is padded to 16 x BPF_HALVES_SLOTS sources; ~8800 cycles between the
+        // gathers of two entries were measured there (cfg5's share, 40 stations)
         if (ph.n_pass > 1) terms = 2.0 * ph.per * 16 * ph.slots;
-        cycles += (ph.n_pass > 1 ? 2500.0 : 6000.0) + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
+        cycles += (ph.n_pass > 1 ? 8800.0 : 6000.0) + terms * (double)tile * 4.0 / (256.0 * eff);   // 4 gathered bytes per term and sample
     }
     return cycles / tile;
 }
@@ -1511,7 +1496,7 @@ bool build_fast_host(const PlanHost& ph, int tile, bool allow_uniform, FastHost&
 
 // Tables of a multi-residency class (build_plan_halves): per group ph.n_pass BpFastGroup entries, each
 // with ONE run that lists all the group's sources (ascending id: wave w owns sources w, w + 16, ... in
-// every residency -- the slots of the kernel's `carry` registers) as exactly one record of ph.per
+// every residency -- the slots of the kernel's `carry` registers) as exactly two records of ph.per / 2
 // stations.
 bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform)
 {
@@ -1532,7 +1517,7 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
             else if (b != w0) fh.uniform = false;
         }
     }
-    const int tp = ph.per, np = 1, WPB = 16, full = WPB * ph.slots;
+    const int tp = ph.per / 2, np = 2, WPB = 16, full = WPB * ph.slots;
     if ((tp != 6 && tp != 8 && tp != 10) || fh.n_sources == 0) return false;
     const int rec_dw = (2 + 2 * tp + 3) / 4 * 4;
     fh.rec_dw = rec_dw;
@@ -1551,7 +1536,7 @@ bool build_fast_host_halves(const PlanHost& ph, FastHost& fh, bool allow_uniform
                 fh.fw.push_back(BpWindow{ck.row, ck.gofs, ck.dst, ck.n});
         }
         f.n_win = (int)fh.fw.size() - f.first_win;
-        if (f.n_win > BPF_HALVES_DESC) return false;      // one descriptor slab
+        if (f.n_win > BPF_DESC_MAX) return false;
         const size_t first_rec = fh.rec.size() / rec_dw;
         // every wave walks exactly ph.slots sources (the kernel's slots are straight-line code):
         // a short group is padded with records of weight 0 at LDS offset 0 and id -1 (never a maximum)
@@ -1702,19 +1687,20 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
                 // groups of hundreds of sources: a smaller tile cannot win
                 if ((double)members.size() / (double)best.ph.groups.size() >= 256.0 && best.tile == cand[c][i]) break;
             }
-            // 33-64 stations: several LDS residencies per group at tile 256 (<= 10 stations of every source
-            // each, partial beams carried in registers, the two halves of the LDS double-buffered)
-            // against one residency at tile 128
+            // 33-64 stations: two LDS residencies per group at tile 256 (the station halves of every
+            // source, partial beams carried in registers) against one at tile 128
             if (c == 2 && (!forced_tile || forced_tile == 256) && option(OPT_BP_HALVES) != 0) {
                 ClassHost ch;
                 ch.tile = 256;
                 ch.halves = true;
+                // 2-4 residencies of at most 20 stations, every source as two records of 6 / 8 / 10 stations in
+                // each of them
                 int cmax = 0;
                 for (int m : members) cmax = std::max(cmax, nsta[m]);
-                const int n_pass = std::max(2, (cmax + 9) / 10);
-                const int per = std::max(6, ((cmax + n_pass - 1) / n_pass + 1) / 2 * 2);   // stations per residency: 6 / 8 / 10
+                const int n_pass = std::max(2, (cmax + 19) / 20);
+                const int tp_h = std::max(6, (((cmax + n_pass - 1) / n_pass + 1) / 2 + 1) / 2 * 2), per = 2 * tp_h;
                 const int slots = BPF_HALVES_SLOTS;
-                if (per <= 10 &&
+                if (tp_h <= 10 &&
                     build_plan_halves(moveouts, w_sources, members, S, P, 256, chunk, hard,
                                       std::min(max_group, 16 * slots), source_id_offset, per, n_pass, slots, ch.ph) &&
                     build_fast_host_halves(ch.ph, ch.fh, option(OPT_BP_FAST_UNIFORM) != 0)) {
@@ -1881,7 +1867,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
             fc.lds_bytes = ch.ph.lds_floats * sizeof(float);
             fc.n_sources = ch.fh.n_sources;
             fc.max_stations = ch.fh.max_sta;
-            fc.desc_waves = ch.halves ? 1 : (int)std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64) / 64;
+            fc.desc_waves = (int)std::min<size_t>(BPF_DESC_MAX, (2 * S * P + 63) / 64 * 64) / 64;
             ++pl->n_classes;
             if ((rc = upload(ch.fh.fg, &fc.d_groups)) || (rc = upload(ch.fh.fr, &fc.d_runs)) ||
                 (rc = upload(ch.fh.fw, &fc.d_wins)) || (rc = upload(ch.fh.rec, &fc.d_recs)))
@@ -2600,7 +2586,7 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
         set_error("bpmf_bp_run: %s failed: %s", what, hipGetErrorString(err));
         rc = -2;
     };
-    if ((e = hipMemcpyAsync(base + o_f, features, b_f, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D features");
+    rc = ctx->upload(base + o_f, features, b_f, "features");     // (pinned pieces, a few host threads: context.h)
     if (!rc && (e = hipMemcpyAsync(base + o_wp, w_phases, b_wp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights_phases");
     if (!rc && reduce == BPMF_BP_REDUCE_NONE &&
         (e = hipMemsetAsync(base + o_beam, 0, b_beam, stream)) != hipSuccess) fail(e, "memset");

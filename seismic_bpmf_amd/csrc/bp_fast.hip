@@ -152,17 +152,14 @@ __device__ __forceinline__ void bpf_for_each(F&& f, std::integer_sequence<int, I
 //
 // HALVES (tile 256 only): sources with 33-64 weighted stations.  Their dual windows do not fit the
 // LDS at tile 256 (80 rows x 2 copies x 256 floats = 164 KB), and tile 128 stops at 0.35 of the gather
-// rate.  So a group of at most 144 sources (BPF_HALVES_SLOTS = 9 per wave) is computed in several LDS
-// RESIDENCIES at tile 256, each holding the windows of <= 10 stations of every source in HALF of the
-// LDS: the first leaves the partial beams of the wave's 9 sources in registers (`carry`, 36 VGPRs,
-// statically indexed: the source loop is unrolled over the slots), the next ones continue the same
-// fmaf chains, the last one updates the running maximum.  Consecutive residencies alternate between
-// the two halves and the copies of the next one run beside the gathers of the current one (round 4;
-// round 3 held <= 20 stations in the whole LDS and staged between two barriers with nothing else
-// running: 0.61 of the gather rate).  The plan lists the residencies as consecutive groups with the
-// same sources in the same order, every source as exactly one record per residency (short groups
-// padded with records of weight 0 and id -1: no branch on the slot count); BPF_GROUP_STORE /
-// BPF_GROUP_LOAD in the group's run count tell the kernel where it is.
+// rate.  So a group of at most 144 sources (BPF_HALVES_SLOTS = 9 per wave) is computed in two to four
+// LDS RESIDENCIES at tile 256: the first stages the windows of every source's first <= 20 stations and
+// leaves the partial beams of the wave's 9 sources in registers (`carry`, 36 VGPRs, statically indexed:
+// the source loop is unrolled over the slots), the next ones stage the following stations and continue
+// the same fmaf chains, the last one updates the running maximum.  The plan lists the residencies as
+// consecutive groups with the same sources in the same order, every source as exactly two records per
+// residency (short groups padded with records of weight 0 and id -1: no branch on the slot count);
+// BPF_GROUP_STORE / BPF_GROUP_LOAD in the group's run count tell the kernel where it is.
 // Registers decide the shape: 128 VGPRs at the 4 waves per SIMD the LDS rate needs.  With the records
 // in VGPRs (rounds of this kernel before walk_s) six carried sources fit: 0.52; with the records in
 // SGPRs nine: 0.61.
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass, int stage_cfg)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass)
 {
     // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
     // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel);
@@ -182,7 +179,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     out_arg += (size_t)blockIdx.y * (size_t)split_stride;
     extern __shared__ float lds[];
     static_assert(TPW == 8 || TPW == 4 || TPW == 2, "tile 512, 256 or 128");
-    static_assert(!HALVES || TPW == 4, "multi-residency groups run at tile 256");
+    static_assert(!HALVES || TPW == 4, "two-residency groups run at tile 256");
     constexpr int NSLOT = BPF_HALVES_SLOTS;      // HALVES: sources per wave and group
     f32x2 carry[HALVES ? NSLOT : 1][HALVES ? TPW / 2 : 1];       // partial beams between the residencies
     constexpr int TILE = 64 * TPW, WPB = BPF_WPB, NTHREADS = BPF_THREADS;
@@ -220,93 +217,41 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
-    // ---- staging by LDS-DMA: a window (tile + moveout spread floats of one prestacked row) goes
-    // global -> LDS in pieces of 256 floats, ONE instruction per piece and wave (16 bytes per
-    // lane, destination = wave-uniform base + 16 * lane; an unaligned global source is fine),
-    // without staging registers and without ds_write_b128 (13 cycles each).  Wave w takes the
-    // windows w, w + 16, ...; all its copies are in flight together.  The register-staged
-    // version of round 1 paid two dependent round trips per 8 chunks per wave: 5.5 % of the
-    // kernel at cfg3, this one 2 %.  The copies count in vmcnt; __syncthreads() waits for them
-    // (vmcnt(0)) before the barrier.  `dsc`: the descriptors {row, first sample relative to t0, LDS
-    // float offset, floats} of the entry, in LDS.
-    auto stage_windows = [&](const i32x4* dsc, int n_win, int n_stagers) {
-        for (int wi = wv; wi < n_win; wi += n_stagers) {
-            const i32x4 d = dsc[wi];
-            const int row = __builtin_amdgcn_readfirstlane(d[0]), gofs = __builtin_amdgcn_readfirstlane(d[1]);
-            const int dst0 = __builtin_amdgcn_readfirstlane(d[2]), len = __builtin_amdgcn_readfirstlane(d[3]);
-            // interior tile: every sample of every window lies inside [0, N)
-            const float* src = U + (size_t)row * (size_t)N + (t0 + gofs) + 4 * lane;
-            for (int x0 = 0; x0 < len; x0 += 256) {
-                if (x0 + 4 * lane < len)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + x0),
-                                                     (__attribute__((address_space(3))) void*)(lds + dst0 + x0), 16, 0, 0);
-            }
-        }
-    };
-    // HALVES: the entries alternate between the two halves of the LDS (the plan bakes the half into the
-    // LDS offsets of descriptors and records), and the windows of entry g + 1 are copied into their half
-    // WHILE entry g is gathered from the other one: the copies are issued right behind the barrier that
-    // opens entry g (every wave has left entry g - 1, whose half they overwrite) and have the whole
-    // gather phase to land before the barrier that opens entry g + 1.  Round 3 staged a whole-LDS
-    // residency between two barriers with nothing else running: ~8 000 of ~25 000 cycles per entry
-    // (profiles/r03_bp_fast_phase_cycles.txt).  Only the BPF_HALVES_STAGERS oldest waves issue copies:
-    // the hardware serves the oldest wave of a SIMD first, so those waves finish their gathers thousands
-    // of cycles before the youngest ones and used to wait at the barrier -- now they spend that time on
-    // the copies while the other eight start gathering at once and the LDS never idles (with all 16
-    // waves issuing copies behind the barrier the LDS stood still for ~2 500 cycles per entry: measured,
-    // profiles/r04_bp_fast_phase_cycles.txt).  The descriptors travel two entries ahead through two slabs
-    // of BPF_HALVES_DESC windows (waves 0 and 1 copy them); the group headers one entry ahead in SGPRs.
-    auto prefetch_descriptors_h = [&](int first_win, int slab) {
-        if (wv < BPF_HALVES_DESC / 64) {
-            const BpWindow* src = wins + first_win + 64 * wv + lane;     // the table is padded by BPF_DESC_MAX
-            float* dst = lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * slab + 256 * wv;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    BpFastGroup grp_next = {0, 0, 0, 0}, grp_next2 = {0, 0, 0, 0};      // headers of entries g + 1, g + 2
-    const int n_stagers = stage_cfg & 31;            // waves that issue window copies (the oldest ones)
-    const bool stage_late = (stage_cfg & 32) != 0;   // behind their gathers instead of in front
-    if constexpr (HALVES) {
-        if (g_hi > g_lo) {
-            grp_next = groups[g_lo];
-            if (g_lo + 1 < g_hi) grp_next2 = groups[g_lo + 1];
-            prefetch_descriptors_h(grp_next.first_win, 0);
-            if (g_lo + 1 < g_hi) prefetch_descriptors_h(grp_next2.first_win, 1);
-            __syncthreads();
-            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), grp_next.n_win, WPB);
-        }
-    } else {
-        if (g_hi > g_lo) prefetch_descriptors(groups[g_lo].first_win);
-    }
+    if (g_hi > g_lo) prefetch_descriptors(groups[g_lo].first_win);
 
     BPF_PHASE_DECL
     BPF_PHASE_START();
     for (int g = g_lo; g < g_hi; ++g) {
-        BpFastGroup grp;
-        if constexpr (HALVES) {
-            grp = grp_next;                                   // loaded one entry ago
-            grp_next = grp_next2;
-            if (g + 2 < g_hi) grp_next2 = groups[g + 2];      // (its latency runs under this entry)
-        } else {
-            grp = groups[g];
-        }
-        __syncthreads();  // previous group's gathers are done, this group's descriptors (HALVES: windows) are in LDS
+        const BpFastGroup grp = groups[g];
+        __syncthreads();  // previous group's gathers are done, this group's descriptors are in LDS
         BPF_PHASE(0);
-        if constexpr (HALVES) {
-            if (!stage_late && g + 1 < g_hi && wv < n_stagers)
-                stage_windows((const i32x4*)(lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * ((g + 1 - g_lo) & 1)), grp_next.n_win,
-                              n_stagers);
-            // (slab of entry g: read one barrier ago, when entry g's copies were issued)
-            if (g + 2 < g_hi) prefetch_descriptors_h(grp_next2.first_win, (g - g_lo) & 1);
-            BPF_PHASE(1);
-        } else {
-            stage_windows((const i32x4*)(lds + BPF_DESC_OFS), grp.n_win, WPB);
-            BPF_PHASE(1);
-            __syncthreads();
-            if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
-            BPF_PHASE(2);
+        // ---- staging by LDS-DMA: a window (tile + moveout spread floats of one prestacked row) goes
+        // global -> LDS in pieces of 256 floats, ONE instruction per piece and wave (16 bytes per
+        // lane, destination = wave-uniform base + 16 * lane; an unaligned global source is fine),
+        // without staging registers and without ds_write_b128 (13 cycles each).  Wave w takes the
+        // windows w, w + 16, ...; all its copies are in flight together.  The register-staged
+        // version of round 1 paid two dependent round trips per 8 chunks per wave: 5.5 % of the
+        // kernel at cfg3, this one 2 %.  The copies count in vmcnt; __syncthreads() waits for them
+        // (vmcnt(0)) before the barrier.
+        {
+            const i32x4* dsc = (const i32x4*)(lds + BPF_DESC_OFS);
+            for (int wi = wv; wi < grp.n_win; wi += WPB) {
+                const i32x4 d = dsc[wi];                       // {row, first sample relative to t0, LDS float offset, floats}
+                const int row = __builtin_amdgcn_readfirstlane(d[0]), gofs = __builtin_amdgcn_readfirstlane(d[1]);
+                const int dst0 = __builtin_amdgcn_readfirstlane(d[2]), len = __builtin_amdgcn_readfirstlane(d[3]);
+                // interior tile: every sample of every window lies inside [0, N)
+                const float* src = U + (size_t)row * (size_t)N + (t0 + gofs) + 4 * lane;
+                for (int x0 = 0; x0 < len; x0 += 256) {
+                    if (x0 + 4 * lane < len)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + x0),
+                                                         (__attribute__((address_space(3))) void*)(lds + dst0 + x0), 16, 0, 0);
+                }
+            }
         }
+        BPF_PHASE(1);
+        __syncthreads();
+        if (g + 1 < g_hi) prefetch_descriptors(groups[g + 1].first_win);
+        BPF_PHASE(2);
 
         const bool g_load = HALVES && (grp.n_run & BPF_GROUP_LOAD) != 0;     // second residency: continue the chains
         const bool g_store = HALVES && (grp.n_run & BPF_GROUP_STORE) != 0;   // first residency: park them, no max update
@@ -655,16 +600,16 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
 #undef BPG_ADDR
 #undef BPG_ISSUE
             };
-            // ---- HALVES: the records live in SGPRs.  A record {id, weight, 2 TP LDS byte addresses} is
-            // wave-uniform; as vector loads (walk) every quad of it costs 16 cycles of the vector memory path
-            // -- 18 000 cycles per group entry against 15 000 of LDS gathers, 7-10 % of the kernel at every
-            // tile (profiles/r03_bp_fast_phase_cycles.txt) -- and a 20-register ring in VGPRs.  Here the
-            // wave's NEXT record is fetched with s_load_dwordx8 at the start of a part into the spare one of
-            // two SGPR buffers and waited for once, where the look-ahead first needs it (lgkmcnt(0): scalar
-            // loads return out of order, so that wait also drains the wave's gathers -- one bubble per
-            // record, covered by the other 15 waves).  The addresses reach v_add_u32 as SGPR operands, id and
-            // weight need no v_readfirstlane, and the 20 VGPRs go to three more carried sources per wave (9
-            // instead of 6: 144 sources per group entry).  One part = one source's record of this residency.
+            // ---- HALVES with uniform weights: the records live in SGPRs.  A record {id, weight, 2 TP LDS
+            // byte addresses} is wave-uniform; as vector loads (walk) every quad of it costs 16 cycles of
+            // the vector memory path -- 18 000 cycles per group entry against 15 000 of LDS gathers, 7-10 %
+            // of the kernel at every tile (profiles/r03_bp_fast_phase_cycles.txt) -- and a 20-register
+            // ring in VGPRs.  Here the wave's NEXT record is fetched with s_load_dwordx8 at the start of a
+            // part into the spare one of two SGPR buffers and waited for once, where the look-ahead first
+            // needs it (lgkmcnt(0): scalar loads return out of order, so that wait also drains the wave's
+            // gathers -- one bubble per record, covered by the other 15 waves).  The addresses reach
+            // v_add_u32 as SGPR operands, id and weight need no v_readfirstlane, and the 20 VGPRs go to
+            // four more carried sources per wave (10 instead of 6: 160 sources per group entry).
             auto walk_s = [&](auto tp_c) {
                 constexpr int TP = decltype(tp_c)::value;
                 constexpr int NTERM = 2 * TP, NU = NTERM / TPU, AH = 2, RING = AH + 1;
@@ -700,11 +645,10 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 BPS_WAIT(A)
                 f32x2 X[RING][4];
                 BPS_ISSUE(A, 0, 0) BPS_ISSUE(A, 1, 1)
-                // `ac`: the partial beams of the slot's source -- the slot's `carry` registers themselves (no copy
-                // in or out: at 10 stations per record the moves were a tenth of the VALU work of a slot, and the
-                // VALU pipe, not the LDS, is what a tile-256 slot saturates first)
-                auto part = [&](auto& cur, auto& nxt, auto ph_c, f32x2 (&ac)[RPT]) __attribute__((always_inline)) {
+                f32x2 ac[RPT];
+                auto part = [&](auto& cur, auto& nxt, auto ph_c, auto upd_c) __attribute__((always_inline)) {
                     constexpr int PH = decltype(ph_c)::value;
+                    constexpr int UPD = decltype(upd_c)::value;
                     p = (const int*)((const char*)p + rec_stride);
                     BPS_LOAD(nxt)                    // (the table is padded by one round of records: no clamp)
                     i32x2 sp;
@@ -728,27 +672,33 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                             for (int r = 0; r < RPT; ++r) BPF_PKFMA(ac[r], sp, X[SL_USE][k * RPT + r]);
                     };
                     bpf_for_each(unit_step, std::make_integer_sequence<int, NU>{});
-                    const int sid = BPS_DW(cur, 0);
-                    if (!g_store && sid >= 0) {              // last residency (id -1: the padding of a short group)
+                    if constexpr (UPD == 2) {
+                        const int sid = BPS_DW(cur, 0);
+                        if (!g_store && sid >= 0) {              // (id -1: the padding of a short group)
 #pragma unroll
-                        for (int j = 0; j < TPW; ++j) {
-                            const float a = ac[j >> 1][j & 1];
-                            const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
-                            best[j] = take ? a : best[j];
-                            arg[j] = take ? sid : arg[j];
+                            for (int j = 0; j < TPW; ++j) {
+                                const float a = ac[j >> 1][j & 1];
+                                const bool take = (a > best[j]) | ((a == best[j]) & (sid < arg[j]));
+                                best[j] = take ? a : best[j];
+                                arg[j] = take ? sid : arg[j];
+                            }
                         }
                     }
                 };
+                using ic1 = std::integral_constant<int, 1>;
+                using ic2 = std::integral_constant<int, 2>;
                 auto slot_step = [&](auto sc) __attribute__((always_inline)) {
                     constexpr int SLOT = decltype(sc)::value;
-                    (void)&carry; (void)&A; (void)&B;
-                    if (!g_load) {                               // first residency: the chains start from +0
+                    (void)&carry; (void)&ac; (void)&A; (void)&B;
 #pragma unroll
-                        for (int r = 0; r < RPT; ++r) carry[SLOT][r] = (f32x2){0.0f, 0.0f};
+                    for (int r = 0; r < RPT; ++r) {
+                        ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
+                        ac[r][1] = g_load ? carry[SLOT][r][1] : 0.0f;
                     }
-                    // one record per source and residency; the two SGPR buffers alternate from slot to slot
-                    if constexpr (SLOT % 2 == 0) part(A, B, std::integral_constant<int, (SLOT * NU) % RING>{}, carry[SLOT]);
-                    else part(B, A, std::integral_constant<int, (SLOT * NU) % RING>{}, carry[SLOT]);
+                    part(A, B, std::integral_constant<int, (2 * SLOT * NU) % RING>{}, ic1{});
+                    part(B, A, std::integral_constant<int, ((2 * SLOT + 1) * NU) % RING>{}, ic2{});
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) carry[SLOT][r] = ac[r];      // (dead in the last residency)
                 };
                 bpf_for_each(slot_step, std::make_integer_sequence<int, NSLOT>{});
                 // the units issued past the wave's last part (they read whatever record follows: valid LDS
@@ -757,7 +707,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                              : "+v"(X[0][0]), "+v"(X[0][1]), "+v"(X[0][2]), "+v"(X[0][3]), "+v"(X[1][0]), "+v"(X[1][1]),
                                "+v"(X[1][2]), "+v"(X[1][3]), "+v"(X[2][0]), "+v"(X[2][1]), "+v"(X[2][2]), "+v"(X[2][3])
                              :: "memory");
-                if constexpr (NSLOT % 2 == 0) { BPS_WAIT(A) } else { BPS_WAIT(B) }
+                BPS_WAIT(A)
 #undef BPS_LOAD
 #undef BPS_WAIT
 #undef BPS_DW
@@ -821,15 +771,6 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
             }
         }
         BPF_PHASE(3);
-        if constexpr (HALVES) {
-            // stage_late: the oldest waves have finished their gathers thousands of cycles before the youngest
-            // ones (the hardware serves the oldest wave of a SIMD first) and would wait at the barrier: they
-            // issue the copies of the next entry now, while the others still gather
-            if (stage_late && g + 1 < g_hi && wv < n_stagers)
-                stage_windows((const i32x4*)(lds + BPF_DESC_OFS + 4 * BPF_HALVES_DESC * ((g + 1 - g_lo) & 1)), grp_next.n_win,
-                              n_stagers);
-            BPF_PHASE(1);
-        }
 #ifdef BPMF_PHASE_CYCLES
         ++ph_n_;
 #endif
@@ -875,9 +816,6 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
     dim3 grid((unsigned)((n_tiles + 7) / 8 * 8), (unsigned)std::max(1, n_split));  // x: multiple of 8 (XCD-aware tile order)
     // waves that copy descriptors = KB of the LDS slab the plan left free (16 bytes per window)
     const int desc_waves = fc.desc_waves;
-    // option bp.halves_stage: which waves issue the window copies of a multi-residency class, and when
-    int stage_cfg = (int)option(OPT_BP_HALVES_STAGE);
-    if ((stage_cfg & 31) != 4 && (stage_cfg & 31) != 8 && (stage_cfg & 31) != 16) stage_cfg = (stage_cfg & 32) | 8;
 #define BPF_LAUNCH(...)                                                                            \
     do {                                                                                           \
         auto kern = bp_beam_fast_kernel<__VA_ARGS__>;                                              \
@@ -887,7 +825,7 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
             fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0,   \
-            fc.halves ? fc.n_pass : 1, stage_cfg);                                                    \
+            fc.halves ? fc.n_pass : 1);                                                               \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
     else if (fc.tile == 256 && fc.halves) { if (fc.uniform) BPF_LAUNCH(true, 4, true); else BPF_LAUNCH(false, 4, true); }

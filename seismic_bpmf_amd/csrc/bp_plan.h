@@ -38,8 +38,6 @@ struct BpFastGroup { int first_run, n_run, first_win, n_win; };
 // Two-residency groups (sources with 33-64 stations at tile 256, see bp_fast.hip): flags in n_run
 constexpr int BPF_GROUP_LOAD = 1 << 16, BPF_GROUP_STORE = 1 << 17;
 constexpr int BPF_HALVES_SLOTS = 9;      // sources per wave of a multi-residency group (16 waves: 144 per group)
-constexpr int BPF_HALVES_DESC = 128;     // window descriptors per slab of a multi-residency class (two slabs)
-constexpr int BPF_HALVES_STAGERS = 8;    // waves of a workgroup that issue the window copies (the oldest two of every SIMD)
 // one staged window of the fast path: `len` floats of row `row` starting at t0 + gofs -> LDS float
 // offset dst (len a multiple of 4, dst a multiple of 4: the LDS-DMA copies move 16 bytes per lane)
 struct BpWindow { int row, gofs, dst, len; };
@@ -52,7 +50,7 @@ constexpr int BPF_ZERO_SLAB = 512, BPF_DESC_OFS = 512, BPF_DESC_MAX = 256;
 struct BpFastClass {
     int tile = 512;              // 512 / 256 / 128 time samples per workgroup
     bool uniform = false;        // every source's non-zero weights are equal: ready-made addresses
-    bool halves = false;         // groups of <= 144 sources computed in 2-7 LDS residencies (<= 10 stations each, half the LDS each)
+    bool halves = false;         // groups of <= 144 sources computed in 2-4 LDS residencies (<= 20 stations each)
     int n_pass = 1;              // halves: consecutive entries of d_groups per group of sources
     int rec_dw = 0;              // dwords per record
     int n_groups = 0;

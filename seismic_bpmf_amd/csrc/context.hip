@@ -3,6 +3,9 @@
 #include "../../include/bpmf_hip.h"
 
 #include <algorithm>
+#include <cstring>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace bpmf {
@@ -74,6 +77,59 @@ int DeviceContext::reserve_pinned(size_t bytes)
         }
     }
     pinned_cap = bytes;
+    return 0;
+}
+
+void parallel_copy(char* dst, const char* src, size_t bytes)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
+    if (bytes < (8u << 20) || nth == 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = (bytes / nth + 4095) & ~(size_t)4095;
+    for (size_t i = 0; i < nth; ++i) {
+        const size_t o = i * per;
+        if (o >= bytes) break;
+        auto piece = [=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); };
+        try {
+            th.emplace_back(piece);
+        } catch (const std::system_error&) {
+            piece();               // no thread to be had (process / cgroup limit): this piece is copied here
+        }
+    }
+    for (auto& t : th) t.join();
+}
+
+int DeviceContext::upload(void* dst_device, const void* src_host, size_t bytes, const char* what)
+{
+    constexpr size_t PIECE = (size_t)64 << 20, DIRECT_BELOW = (size_t)32 << 20;
+    auto fail = [&](hipError_t e) {
+        set_error("H2D %s failed: %s", what, hipGetErrorString(e));
+        return -2;
+    };
+    if (bytes == 0) return 0;
+    if (bytes < DIRECT_BELOW) {
+        hipError_t e = hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, s_run);
+        return e == hipSuccess ? 0 : fail(e);
+    }
+    if (int rc = reserve_pinned(PIECE)) return rc;
+    const size_t n_piece = (bytes + PIECE - 1) / PIECE;
+    hipError_t e = hipSuccess;
+    for (size_t q = 0; q < n_piece; ++q) {
+        const size_t o = q * PIECE, len = std::min(PIECE, bytes - o);
+        // the piece's previous transfer (two pieces ago) has left the pinned buffer
+        if (q >= 2 && (e = hipEventSynchronize(ev_piece[q & 1])) != hipSuccess) return fail(e);
+        parallel_copy(pinned[q & 1], (const char*)src_host + o, len);
+        if ((e = hipMemcpyAsync((char*)dst_device + o, pinned[q & 1], len, hipMemcpyHostToDevice, s_copy)) != hipSuccess)
+            return fail(e);
+        if ((e = hipEventRecord(ev_piece[q & 1], s_copy)) != hipSuccess) return fail(e);
+    }
+    // what follows on s_run starts behind the last piece; the pinned buffers are free again once it is over
+    // (a later D2H through them is enqueued on s_copy, behind these transfers)
+    if ((e = hipStreamWaitEvent(s_run, ev_piece[(n_piece - 1) & 1], 0)) != hipSuccess) return fail(e);
     return 0;
 }
 

@@ -1119,30 +1119,6 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
 // second stream drains the previous batch in 64 MB pieces into two pinned buffers, from which a
 // few host threads copy into the caller's array while the next piece is in flight: the call takes
 // about max(compute, transfer) instead of their sum.
-namespace {
-void parallel_copy(char* dst, const char* src, size_t bytes)
-{
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
-    if (bytes < (8u << 20) || nth == 1) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    std::vector<std::thread> th;
-    const size_t per = (bytes / nth + 4095) & ~(size_t)4095;
-    for (size_t i = 0; i < nth; ++i) {
-        const size_t o = i * per;
-        if (o >= bytes) break;
-        auto piece = [=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); };
-        try {
-            th.emplace_back(piece);
-        } catch (const std::system_error&) {
-            piece();               // no thread to be had (process / cgroup limit): this piece is copied here
-        }
-    }
-    for (auto& t : th) t.join();
-}
-}  // namespace
 
 extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, const float* weights,
                            const float* data, size_t step, size_t L, size_t N, size_t T, size_t S,
@@ -1195,7 +1171,7 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
-    if (!rc) MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
+    if (!rc) rc = ctx->upload(base + o_d, data, b_d, "data");     // (pinned pieces, a few host threads: context.h)
     if (!rc)
         rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
     auto launch = [&](size_t b) {

@@ -48,7 +48,6 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"bp.fast_tile", 0, 0, 512, true},        // 0: the cost model picks each class's tile; 512 / 256 / 128: only that one
     {"bp.halves", 1, 0, 1, true},             // 33-64 stations: two LDS residencies per group at tile 256 where cheaper
     {"bp.direct", 0, 0, 1, true},             // 1: every plan takes the global-memory path of bp_direct.hip (tests)
-    {"bp.halves_stage", 40, 0, 63, false},    // multi-residency kernel: waves that issue the window copies (low 5 bits: 4 / 8 / 16) + 32: behind their gathers instead of in front
     {"mf.wave_kernel", 1, 0, 1, false},        // independent-wave kernel for L <= 257
     {"mf.max_mfma_step", 64, 0, 1 << 20, false},  // larger steps take the generic kernel
     {"mf.host_batch_kb", 0, 0, 1L << 30, false},  // host-pointer call: output per batch (0 = 1 GB, >= 8 templates)

@@ -470,10 +470,6 @@ def test_bp_multi_residency_class_on_a_short_series_is_cut_between_groups(oracle
     never inside one."""
     from seismic_bpmf_amd import BeamformerGPU
     hip_opts("bp.split", split)
-    # (every source uses its own 38-52 of the 56 stations, so a residency of a group spans many more rows
-    # than one source's 10: left to itself the cost model may prefer tile 128 for such a grid -- the
-    # multi-residency kernel is what this test is about)
-    hip_opts("bp.fast_tile", 256)
     rng = np.random.default_rng(900 + n_used + split)
     K, S, C, P, N = 1100, 56, 2, 2, 3300
     f = np.round(np.abs(rng.standard_normal((S, C, N))) * 4).astype(np.float32) / 4
