@@ -2478,7 +2478,7 @@ size_t plan_cache_capacity()
 }
 }  // namespace
 
-extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const float* w_phases,
+static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, const float* w_phases,
                            const float* w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
                            int out_of_bounds, int reduce, int device, float* beam_out,
                            int32_t* arg_out)
@@ -2586,7 +2586,10 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
         set_error("bpmf_bp_run: %s failed: %s", what, hipGetErrorString(err));
         rc = -2;
     };
-    rc = ctx->upload(base + o_f, features, b_f, "features");     // (pinned pieces, a few host threads: context.h)
+    // (pageable memory through the runtime's own staging, on the private stream: a hand-made pipeline through
+    // the context's pinned pieces filled by 8 host threads measured SLOWER -- cfg3 end to end 194 ms against
+    // 176 ms -- the host-side memcpy into the pinned pieces is the bottleneck on the 16 CPUs a box grants)
+    if ((e = hipMemcpyAsync(base + o_f, features, b_f, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D features");
     if (!rc && (e = hipMemcpyAsync(base + o_wp, w_phases, b_wp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights_phases");
     if (!rc && reduce == BPMF_BP_REDUCE_NONE &&
         (e = hipMemsetAsync(base + o_beam, 0, b_beam, stream)) != hipSuccess) fail(e, "memset");
@@ -2603,6 +2606,24 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
     return rc;
+}
+
+extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const float* w_phases,
+                           const float* w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
+                           int out_of_bounds, int reduce, int device, float* beam_out,
+                           int32_t* arg_out)
+{
+    // nothing may cross the C boundary as an exception (std::bad_alloc from the host-side planning, a
+    // std::system_error): it becomes status -3 with its text
+    try {
+        return bpmf_bp_run_impl(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds, reduce, device, beam_out, arg_out);
+    } catch (const std::exception& e) {
+        set_error("bpmf_bp_run: exception: %s", e.what());
+        return -3;
+    } catch (...) {
+        set_error("bpmf_bp_run: unknown exception");
+        return -3;
+    }
 }
 
 extern "C" int bpmf_bp_pack_max_dev(const float* d_beam, const int32_t* d_arg, size_t N,

@@ -32,19 +32,17 @@ struct DeviceContext {
     std::atomic<size_t> dev_cap{0};
     char* pinned[2] = {nullptr, nullptr};
     std::atomic<size_t> pinned_cap{0};
+    int small_streak = 0;             // consecutive calls that needed less than a quarter of a >= 1 GiB block
 
     // At least `bytes` of device memory (256-byte aligned base).  A larger request frees the old
-    // block first (after the streams have drained).  nullptr + error text on failure.
+    // block first (after the streams have drained); a block of 1 GiB or more is given back after four
+    // consecutive calls that needed less than a quarter of it (a workflow that alternates a large and a
+    // small call keeps the large block).  nullptr + error text on failure.
     char* reserve_device(size_t bytes);
     // Two pinned host pieces of at least `bytes` each.  0 on success.
     int reserve_pinned(size_t bytes);
     // Frees the device working set and the pinned pieces (the streams and events stay).
     void release_memory();
-    // Pageable host memory -> device, ordered in front of whatever is enqueued on s_run afterwards.
-    // Large transfers go through the two pinned pieces (a few host threads fill one piece while the
-    // other one is on its way over PCIe: ~2x the rate of the runtime's own staging of pageable
-    // memory); small ones are a plain copy on s_run.  0 on success.
-    int upload(void* dst_device, const void* src_host, size_t bytes, const char* what);
 };
 
 // memcpy on a few host threads (large blocks) -- dst / src pageable or pinned host memory

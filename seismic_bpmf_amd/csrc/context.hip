@@ -15,7 +15,8 @@ std::vector<DeviceContext*> g_contexts;     // by device index; entries live unt
 
 constexpr size_t DEV_GRANULE = (size_t)2 << 20;
 constexpr size_t SHRINK_ABOVE = (size_t)1 << 30;   // a cached block this large is given back ...
-constexpr size_t SHRINK_RATIO = 4;                 // ... when a call needs less than 1/4 of it
+constexpr size_t SHRINK_RATIO = 4;                 // ... when calls need less than 1/4 of it ...
+constexpr int SHRINK_STREAK = 4;                   // ... four times in a row
 
 void drain(DeviceContext* c)
 {
@@ -29,8 +30,11 @@ char* DeviceContext::reserve_device(size_t bytes)
 {
     bytes = std::max<size_t>(bytes, 256);
     const bool too_small = bytes > dev_cap;
-    const bool too_large = dev_cap >= SHRINK_ABOVE && bytes < dev_cap / SHRINK_RATIO;
+    const bool oversized = dev_cap >= SHRINK_ABOVE && bytes < dev_cap / SHRINK_RATIO;
+    small_streak = oversized ? small_streak + 1 : 0;
+    const bool too_large = oversized && small_streak >= SHRINK_STREAK;
     if (dev_buf && !too_small && !too_large) return dev_buf;
+    small_streak = 0;
     if (dev_buf) {
         drain(this);
         (void)hipFree(dev_buf);
@@ -101,36 +105,6 @@ void parallel_copy(char* dst, const char* src, size_t bytes)
         }
     }
     for (auto& t : th) t.join();
-}
-
-int DeviceContext::upload(void* dst_device, const void* src_host, size_t bytes, const char* what)
-{
-    constexpr size_t PIECE = (size_t)64 << 20, DIRECT_BELOW = (size_t)32 << 20;
-    auto fail = [&](hipError_t e) {
-        set_error("H2D %s failed: %s", what, hipGetErrorString(e));
-        return -2;
-    };
-    if (bytes == 0) return 0;
-    if (bytes < DIRECT_BELOW) {
-        hipError_t e = hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, s_run);
-        return e == hipSuccess ? 0 : fail(e);
-    }
-    if (int rc = reserve_pinned(PIECE)) return rc;
-    const size_t n_piece = (bytes + PIECE - 1) / PIECE;
-    hipError_t e = hipSuccess;
-    for (size_t q = 0; q < n_piece; ++q) {
-        const size_t o = q * PIECE, len = std::min(PIECE, bytes - o);
-        // the piece's previous transfer (two pieces ago) has left the pinned buffer
-        if (q >= 2 && (e = hipEventSynchronize(ev_piece[q & 1])) != hipSuccess) return fail(e);
-        parallel_copy(pinned[q & 1], (const char*)src_host + o, len);
-        if ((e = hipMemcpyAsync((char*)dst_device + o, pinned[q & 1], len, hipMemcpyHostToDevice, s_copy)) != hipSuccess)
-            return fail(e);
-        if ((e = hipEventRecord(ev_piece[q & 1], s_copy)) != hipSuccess) return fail(e);
-    }
-    // what follows on s_run starts behind the last piece; the pinned buffers are free again once it is over
-    // (a later D2H through them is enqueued on s_copy, behind these transfers)
-    if ((e = hipStreamWaitEvent(s_run, ev_piece[(n_piece - 1) & 1], 0)) != hipSuccess) return fail(e);
-    return 0;
 }
 
 void DeviceContext::release_memory()

@@ -1120,7 +1120,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
 // few host threads copy into the caller's array while the next piece is in flight: the call takes
 // about max(compute, transfer) instead of their sum.
 
-extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, const float* weights,
+static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, const float* weights,
                            const float* data, size_t step, size_t L, size_t N, size_t T, size_t S,
                            size_t C, size_t n_corr, int network_sum, int flags, int device,
                            float* cc_out)
@@ -1171,7 +1171,7 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
-    if (!rc) rc = ctx->upload(base + o_d, data, b_d, "data");     // (pinned pieces, a few host threads: context.h)
+    if (!rc) MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
     if (!rc)
         rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
     auto launch = [&](size_t b) {
@@ -1226,6 +1226,24 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
     return rc;
+}
+
+extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, const float* weights,
+                           const float* data, size_t step, size_t L, size_t N, size_t T, size_t S,
+                           size_t C, size_t n_corr, int network_sum, int flags, int device,
+                           float* cc_out)
+{
+    // nothing may cross the C boundary as an exception (std::bad_alloc from the host-side planning, a
+    // std::system_error): it becomes status -3 with its text
+    try {
+        return bpmf_mf_run_impl(templates, moveouts, weights, data, step, L, N, T, S, C, n_corr, network_sum, flags, device, cc_out);
+    } catch (const std::exception& e) {
+        set_error("bpmf_mf_run: exception: %s", e.what());
+        return -3;
+    } catch (...) {
+        set_error("bpmf_mf_run: unknown exception");
+        return -3;
+    }
 }
 
 #ifdef BPMF_PHASE_CYCLES
