@@ -1011,6 +1011,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     }
     if (!network_sum)
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
+    else if (option(OPT_DEBUG_POISON_OUTPUT) != 0)      // tests: a CC sum that no kernel writes comes back as NaN
+        BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0xFF, T * n_corr * sizeof(float), stream));
 
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     const size_t lds = mf_lds_bytes((int)L);

@@ -60,3 +60,21 @@ def hip_opts():
     yield set_
     for name in touched:
         reset(name)
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _poisoned_outputs(request):
+    """GPU sessions run with option debug.poison_output on: the max-beam / arg-max / CC-sum outputs are
+    filled with 0xFF bytes before the kernels run, so a sample that no kernel writes fails its comparison
+    whatever the buffer held before (round 4: the last partial tile of a series was left unwritten when
+    every used moveout was negative, and passed whenever the allocator handed back a buffer that already
+    held the right values)."""
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from seismic_bpmf_amd import _lib
+    _lib.set_option("debug.poison_output", 1)
+    yield
+    _lib.set_option("debug.poison_output", 0)
+

@@ -607,3 +607,33 @@ def test_bp_short_series_split_into_group_ranges(oracle_lib, N, hip_opts):
                 assert np.array_equal(bf.run(f, wp, "none", "strict").cpu().numpy(), full), (N, split)
     finally:
         bf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1500, 3000, 3072, 5000, 12_345])
+@pytest.mark.parametrize("tau_hi", [-9, -86, -1100])
+def test_bp_all_used_moveouts_negative(oracle_lib, N, tau_hi):
+    """Every USED moveout negative (tmax_all < -8): the sources stay inside the trace up to its very last
+    sample, so the interior range of the fast kernel would end past N -- it must end at the last whole
+    tile, and the last partial tile belongs to the edge launch.  Rounds 2-3 left the samples of that tile
+    unwritten (found by the 150 000-case fuzz session of round 4)."""
+    from seismic_bpmf_amd import BeamformerGPU, beamform
+    rng = np.random.default_rng(N - tau_hi)
+    K, S, C, P = 40, 6, 2, 2
+    f = np.abs(rng.standard_normal((S, C, N))).astype(np.float32)
+    tau = rng.integers(tau_hi - 200, tau_hi + 1, (K, S, P)).astype(np.int32)
+    tau[:, 0] = 50                                   # an UNUSED station with positive moveouts
+    wp = rng.random((S, C, P)).astype(np.float32)
+    ws = rng.random((K, S)).astype(np.float32)
+    ws[:, 0] = 0.0
+    for oob in ("strict", "flexible"):
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+        assert ob[-1] > 0                             # the last sample does hold a beam
+        bf = BeamformerGPU(tau, ws)
+        junk = bf.torch.full((N,), -7.0, device="cuda")          # the output buffer starts out as junk
+        junk_a = bf.torch.full((N,), -7, device="cuda", dtype=bf.torch.int32)
+        b, a = bf.run(f, wp, "max", oob, out=(junk, junk_a))
+        assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(a.cpu().numpy(), oa), (N, tau_hi, oob)
+        bf.close()
+        hb, ha = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds=oob)
+        assert np.array_equal(hb, ob) and np.array_equal(ha, oa), (N, tau_hi, oob)
