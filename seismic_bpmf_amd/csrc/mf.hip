@@ -585,7 +585,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int n_lag_blocks)
+    float* __restrict__ out, int n_lag_blocks, int prio)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -743,6 +743,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     if constexpr (NTILE > 2) { MF_LDS_READ(sb[req][2 % NTILE], bp, (boff) + 2304); MF_LDS_READ(sb[req][3 % NTILE], bp, (boff) + 3456); } \
     __builtin_amdgcn_sched_barrier(0)
             __builtin_amdgcn_sched_barrier(0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
@@ -755,6 +756,16 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // option mf.boundary_prio (default 1): a wave outside its K loop (epilogue, staging writes, norm loads,
+            // the next channel's loads) asks for a higher issue priority than the waves that stream MFMAs -- its
+            // ~250 instructions per channel otherwise wait 40-65 cycles each for a slot behind the other waves'
+            // MFMAs (tools/phase/mf_phase.py), and the sooner it is back in its K loop the fewer cycles the matrix
+            // pipe idles: 85.0 -> 86.0 % at L = 256, 76.6 -> 77.8 % at L = 128, 62.6 -> 64.6 % at L = 64, same
+            // bits (tools/probe_mf_prio.py, round 4).  Round 3 had tried the opposite -- a higher priority INSIDE
+            // the K loop -- without effect.
+            if (prio == 1) __builtin_amdgcn_s_setprio(1);
+            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 3) __builtin_amdgcn_s_setprio(3);
 #undef MF_LDS_READ
 #undef MF_MFMA
 #undef MF_REQ
@@ -1069,7 +1080,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
 #define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ)                                                 \
     mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ><<<grid_w, dim3(MF_THREADS), wl, stream>>>(        \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w)
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO))
 #define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT) \
     do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false); } while (0)
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
