@@ -315,7 +315,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int n_lag_blocks)
+    float* __restrict__ out, int n_lag_blocks, int prio)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -475,6 +475,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             // (a scalar load may still be in flight here -- the next-but-one channel record; it
             // only makes the counted waits stricter, never laxer: LDS returns in order)
             __builtin_amdgcn_sched_barrier(0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
             MF_REQ(0, 0, 0);
             MF_REQ(1, 16, 16);
             for (int q = 0; q < nq; ++q) {
@@ -487,6 +488,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // drain the two k-steps read ahead
             __builtin_amdgcn_sched_barrier(0);
+            // (option mf.boundary_prio, see mf_mfma_wave_kernel.  Measured without effect here -- L = 400 / 800 /
+            // 1024: 85.7 / 90.6 / 91.6 % of the peak at every level -- the waves of a workgroup reach their channel
+            // boundary together, behind one barrier; kept so that the option means the same in both kernels)
+            if (prio == 1) __builtin_amdgcn_s_setprio(1);
+            else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+            else if (prio == 3) __builtin_amdgcn_s_setprio(3);
 #undef MF_LDS_READ
 #undef MF_MFMA
 #undef MF_REQ
@@ -1056,7 +1063,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         kfn<<<grid, dim3(MF_THREADS), lds, stream>>>(                                                 \
             d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,         \
-            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks);                     \
+            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks,                      \
+            (int)option(OPT_MF_BOUNDARY_PRIO));                                                        \
     } while (0)
 #define BPMF_MF_LAUNCH(NS, R, TT) \
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
