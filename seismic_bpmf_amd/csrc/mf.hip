@@ -255,17 +255,23 @@ __host__ inline size_t mf_lds_bytes(int L) { return ((size_t)2 * mf_buf_floats(L
 // to the 8 XCDs, each with its own L2.  With the plain order (template fastest) every XCD walks
 // ALL lag blocks and streams the whole day of data and norms from HBM itself (8 x 4 GB at cfg2,
 // plus what the ~60 resident workgroups per XCD re-fetch as they drift apart).  XCD-aware order:
-// XCD x owns the contiguous lag blocks [x * per_xcd, (x + 1) * per_xcd); inside an XCD the template
-// index is fastest, so the workgroups in flight on one L2 share one or two lag blocks' windows.
-// The grid is 8 * per_xcd * T workgroups; the ones past the last lag block exit at once.
+// the (lag block, template) pairs -- template fastest -- are cut into 8 contiguous runs of equal
+// length, one per XCD, so that the workgroups in flight on one L2 share one or two lag blocks'
+// windows AND every XCD gets the same number of workgroups to within one.  (Rounds 1-3 gave every XCD
+// ceil(blocks / 8) whole lag blocks: on an hour-long series -- 44 blocks -- XCD 7 then owned 2 blocks
+// where the others owned 6, and the launch lasted 6 / 5.5 of what it had to: 0.78 -> 0.83 of the peak
+// for 256 templates of 256 samples on configs[0]'s hour, tools/probe_mf_ntile_T.py, round 4.)
+// The grid is 8 * ceil(blocks * T / 8) workgroups; the ones past the last pair exit at once.
 __device__ __forceinline__ bool mf_tile_of_block(unsigned bid, int T, int n_lag_blocks, int& t,
                                                  long long& lag_block)
 {
     const unsigned xcd = bid & 7u, i = bid >> 3;
-    const int per_xcd = (n_lag_blocks + 7) >> 3;
-    t = (int)(i % (unsigned)T);
-    lag_block = (long long)xcd * per_xcd + (long long)(i / (unsigned)T);
-    return lag_block < n_lag_blocks;
+    const unsigned total = (unsigned)n_lag_blocks * (unsigned)T;       // (< 2^31: checked on the host)
+    const unsigned per_xcd = (total + 7u) >> 3;
+    const unsigned flat = xcd * per_xcd + i;
+    t = (int)(flat % (unsigned)T);
+    lag_block = (long long)(flat / (unsigned)T);
+    return i < per_xcd && flat < total;
 }
 
 // Zero-padded staging loads.  A raw buffer load returns 0 for a lane whose byte offset lies outside
@@ -692,7 +698,8 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             // slack around the array -- and those lanes are masked in the epilogue (`ok`).  The wave-
             // uniform test first: all but the first and last waves of a template take the loads without
             // a lane mask (every instruction outside the K loop waits for an issue slot behind the MFMAs
-            // of the other waves).
+            // of the other waves).  (Requesting the norms of channel c + 1 in front of the K loop of channel
+            // c -- for the small problems, whose K loops are short -- changed nothing: round 4.)
             if (wave_inside) {
 #pragma unroll
                 for (int u = 0; u < NTILE; ++u) ed[u] = *(const f32x4u*)(edc + lag_w + 256 * u + mvc);
@@ -1050,8 +1057,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                           need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
                           N < ((size_t)1 << 30) - 8192;
     if (use_mfma) {
-        // 8 XCDs x ceil(n_lag_blocks / 8) lag blocks x T templates (mf_tile_of_block)
-        dim3 grid((unsigned)(T * 8 * ((n_lag_blocks + 7) / 8)));
+        // 8 XCDs x ceil(n_lag_blocks x T / 8) (lag block, template) pairs (mf_tile_of_block)
+        dim3 grid((unsigned)(8 * ((T * n_lag_blocks + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
 #define BPMF_MF_LAUNCH2(NS, R, TT, S1) \
     do { if (NS && sqrt_norm) BPMF_MF_LAUNCH3(NS, R, TT, S1, NS); else BPMF_MF_LAUNCH3(NS, R, TT, S1, false); } while (0)
@@ -1072,8 +1079,11 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             // tiles (of 256 lags) per wave: 4 unless the problem is too small to give every SIMD ~4 waves
             // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
+            // (calibrated on an hour-long series with 4 .. 256 templates, tools/probe_mf_ntile_T.py,
+            // profiles/r04_mf_ntile_T.txt: 4 tiles from two full rounds of 4 waves per SIMD on, 2 tiles -- 5 waves
+            // per SIMD at 83-90 VGPRs -- from one wave per SIMD on, 1 tile below)
             const size_t waves4 = T * ((n_offsets + 4095) / 4096) * 4;
-            int ntile = waves4 >= 4096 ? 4 : (2 * waves4 >= 4096 ? 2 : 1);
+            int ntile = waves4 >= 8192 ? 4 : (waves4 >= 1024 ? 2 : 1);
             const long forced = option(OPT_MF_TILES_PER_WAVE);
             if (forced == 1 || forced == 2 || forced == 4) ntile = (int)forced;
             const int Kp = mf_kpad((int)L), Ww = 256 * ntile - 16 + Kp;
@@ -1083,7 +1093,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                 set_error("bpmf_mf_run_dev: grid too large");
                 return -1;
             }
-            dim3 grid_w((unsigned)(T * 8 * ((n_blocks_w + 7) / 8)));
+            dim3 grid_w((unsigned)(8 * ((T * n_blocks_w + 7) / 8)));
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256;
 #define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ)                                                 \
     mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ><<<grid_w, dim3(MF_THREADS), wl, stream>>>(        \

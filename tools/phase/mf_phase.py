@@ -51,9 +51,13 @@ def run(L, T=32, S=20, C=3, N=8_640_000):
           f"   total {c.sum():8.0f} cycles per channel and wave (matrix pipe of the SIMD: {pipe} for its 4 waves = "
           f"{pipe / c.sum() * 100:.0f} % busy); kernel {ms:.1f} ms "
           f"({flop / (ms * 1e-3) / 1e12 / 157.3 * 100:.1f} % of the fp32-MFMA peak, instrumented build); "
-          f"sustained clock ~{ghz:.2f} GHz", flush=True)
+          f"sustained clock ~{ghz:.2f} GHz (both derived figures assume 4 tiles per wave and 16 resident waves per CU for "
+          f"the whole launch); {v[5]:.0f} waves counted, {v[4] / max(1.0, v[5]):.1f} channels each", flush=True)
 
 
 if __name__ == "__main__":
-    for L in [int(x) for x in sys.argv[1:]] or [64, 128, 192, 256]:
-        run(L)
+    if len(sys.argv) > 1 and sys.argv[1] == "configs0":      # BASELINE configs[0]: 1 h @ 50 Hz, 4 templates, 8 x 3 channels
+        run(128, T=4, S=8, C=3, N=180_000)
+    else:
+        for L in [int(x) for x in sys.argv[1:]] or [64, 128, 192, 256]:
+            run(L)
