@@ -28,6 +28,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------ preparation ---
 
+// Valid CC indices [first, last] of a template whose used channels have moveouts mv_min .. mv_max
+// (first > last: none).
+__device__ __forceinline__ int2 mf_lag_range(bool any, long long mv_min, long long mv_max, long long step,
+                                             long long L, long long N, long long n_corr, int exclusive_last)
+{
+    int2 r = make_int2(1, 0);
+    if (any && N >= L) {
+        long long first = mv_min < 0 ? (-mv_min + step - 1) / step : 0;
+        long long room = N - L - mv_max;
+        // compat (option mf.compat_exclusive_last_lag): data offsets i * step < room only -- the loop
+        // bound `i < stop_i`, stop_i = N - L - max_moveout, that upstream is recollected to use
+        if (exclusive_last) room -= 1;
+        if (room >= 0) {
+            long long last = room / step;
+            if (last > n_corr - 1) last = n_corr - 1;
+            if (first <= last) r = make_int2((int)first, (int)last);
+        }
+    }
+    return r;
+}
+
 // Per template, one workgroup: r_t[t,s,c] = 1 / sqrtf(E_t), E_t = the fmaf chain of tmpl^2 over l
 // ascending (the threads take the channels); then thread 0 writes the valid lag range [first, last]
 // (first > last = empty) and the template's compact list of used channels, one int4 {channel, moveout,
@@ -68,20 +89,7 @@ __global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict
     }
     rec[n_used] = make_int4(-1, 0, 0, 0);
     rec[n_used + 1] = make_int4(-1, 0, 0, 0);
-    int2 r = make_int2(1, 0);
-    if (any && N >= L) {
-        long long first = mv_min < 0 ? (-mv_min + step - 1) / step : 0;
-        long long room = N - L - mv_max;
-        // compat (option mf.compat_exclusive_last_lag): data offsets i * step < room only -- the loop
-        // bound `i < stop_i`, stop_i = N - L - max_moveout, that upstream is recollected to use
-        if (exclusive_last) room -= 1;
-        if (room >= 0) {
-            long long last = room / step;
-            if (last > n_corr - 1) last = n_corr - 1;
-            if (first <= last) r = make_int2((int)first, (int)last);
-        }
-    }
-    range[t] = r;
+    range[t] = mf_lag_range(any, mv_min, mv_max, step, L, N, n_corr, exclusive_last);
 }
 
 // Chunk-local prefix sums of data^2 in double (one thread per 1024-sample chunk).
@@ -558,6 +566,79 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     }
 }
 
+// What mf_prologue_kernel computes for template t, by the 256 threads of a workgroup of the wave kernel
+// itself and into LDS (FUSED variants: small problems, where a second launch costs as much as the
+// correlation; option mf.fused_prologue).  Thread c owns channel c (n_ch <= 256): its weight, its moveout
+// and -- the same sequential fmaf chain -- its template's energy; the used channels are compacted in
+// channel order (ballot + per-wave counts) into l_rec[0 .. n_used), two terminators behind them; the lag
+// range of the template comes back in registers.  l_part: 12 ints of LDS scratch.  Two barriers: every
+// thread of the workgroup calls this.
+template <bool SQRT_NORM>
+__device__ __forceinline__ int2 mf_fused_prologue(const float* __restrict__ tmpl, const int* __restrict__ mv,
+                                                  const float* __restrict__ w, int t, int n_ch, long long step, int L,
+                                                  long long N, long long n_corr, int exclusive_last,
+                                                  int4* l_rec, int* l_part)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float wc = 0.0f, nt = 0.0f;
+    int m = 0;
+    bool used = false;
+    if (tid < n_ch) {
+        wc = w[(size_t)t * n_ch + tid];
+        used = !(wc == 0.0f);
+    }
+    if (used) {
+        m = mv[(size_t)t * n_ch + tid];
+        const float* x = tmpl + ((size_t)t * n_ch + tid) * (size_t)L;
+        float acc = 0.0f;
+        int l = 0;
+        for (; l + 16 <= L; l += 16) {             // 4 loads in flight per trip; the chain itself stays in sample order
+            const f32x4u v0 = *(const f32x4u*)(x + l), v1 = *(const f32x4u*)(x + l + 4);
+            const f32x4u v2 = *(const f32x4u*)(x + l + 8), v3 = *(const f32x4u*)(x + l + 12);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __fmaf_rn(v0[i], v0[i], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __fmaf_rn(v1[i], v1[i], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __fmaf_rn(v2[i], v2[i], acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __fmaf_rn(v3[i], v3[i], acc);
+        }
+        for (; l < L; ++l) acc = __fmaf_rn(x[l], x[l], acc);
+        nt = SQRT_NORM ? acc : 1.0f / sqrtf(acc);
+    }
+    const unsigned long long mask = __ballot(used);
+    const int idx = __popcll(mask & ((1ull << lane) - 1ull));
+    int mn = used ? m : 0x7fffffff, mx = used ? m : (int)0x80000000;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o));
+        mx = max(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) {
+        l_part[wv] = __popcll(mask);
+        l_part[4 + wv] = mn;
+        l_part[8 + wv] = mx;
+    }
+    __syncthreads();
+    int base = 0, n_used = 0, mv_min_i = 0x7fffffff, mv_max_i = (int)0x80000000;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = l_part[i];
+        if (i < wv) base += c;
+        n_used += c;
+        mv_min_i = min(mv_min_i, l_part[4 + i]);
+        mv_max_i = max(mv_max_i, l_part[8 + i]);
+    }
+    if (used) l_rec[base + idx] = make_int4(tid, m, __float_as_int(wc), __float_as_int(nt));
+    if (tid == 0) {
+        l_rec[n_used] = make_int4(-1, 0, 0, 0);
+        l_rec[n_used + 1] = make_int4(-1, 0, 0, 0);
+    }
+    __syncthreads();
+    return mf_lag_range(n_used > 0, mv_min_i, mv_max_i, step, L, N, n_corr, exclusive_last);
+}
+
 // ------------------------------------------------- MFMA kernel, independent waves ---
 // Same tile algebra and arithmetic as mf_mfma_kernel, different ownership of LDS: every wave
 // stages ITS OWN data window (1008 + Kpad floats) and its own copy of the band, so no wave ever
@@ -593,12 +674,16 @@ __device__ unsigned long long g_mf_phase[8];
 #define MF_PHASE(i) do {} while (0)
 #endif
 
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4, bool SQRT_NORM = false>
+// FUSED (option mf.fused_prologue, NTILE < 4 and n_ch <= 256): no mf_prologue_kernel ran -- chan_rec and range
+// are not read, every workgroup works its template's channel records and lag range out itself
+// (mf_fused_prologue, from mv / wts) and walks the records in LDS.
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4, bool SQRT_NORM = false, bool FUSED = false>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int n_lag_blocks, int prio)
+    float* __restrict__ out, int n_lag_blocks, int prio, const int* __restrict__ mv,
+    const float* __restrict__ wts, int exclusive_last)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -622,7 +707,17 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     // 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for 1 / 2 / 4 / 8 blocks, profiles/r02_mf_nsub.txt;
     // the loop also cost 7 spilled registers.  One block per workgroup.)
     if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
-    const int2 rgi = range[t];
+    int2 rgi;
+    int4* l_rec = nullptr;
+    if constexpr (FUSED) {
+        int* l_part = (int*)(smem + 4 * wave_floats + 64);        // behind the waves' buffers and their read slack
+        l_rec = (int4*)(l_part + 16);
+        const int2 r = mf_fused_prologue<SQRT_NORM>(tmpl, mv, wts, t, n_ch, (long long)step, L, N, n_corr, exclusive_last,
+                                                    l_rec, l_part);
+        rgi = make_int2(__builtin_amdgcn_readfirstlane(r.x), __builtin_amdgcn_readfirstlane(r.y));
+    } else {
+        rgi = range[t];
+    }
     const long long lag0 = lag_block * LAGS_WG + (long long)wv * LAGS_W;
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
@@ -641,7 +736,19 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         float* dw = tp + tp_len;              // dw[pad(x)] = data[g0 + x]
         const int a_base = 15 - a + kq;
         const int b_base = 18 * a + kq;  // window padded 2 floats per 16: conflict-free B reads
-        const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
+        const int4* __restrict__ recs = FUSED ? nullptr : chan_rec + (size_t)t * (n_ch + 2);
+        // FUSED: the records are in LDS; one broadcast read, and the four fields back into SGPRs (the channel
+        // number goes into buffer descriptors, the tests on it are scalar branches).  The read is issued in
+        // front of a K loop's operand reads and lands before them (one wave's LDS operations return in order).
+        auto ld_rec = [&](int i) -> int4 {
+            if constexpr (FUSED) {
+                const int4 v = l_rec[i];
+                return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                                 __builtin_amdgcn_readfirstlane(v.z), __builtin_amdgcn_readfirstlane(v.w));
+            } else {
+                return recs[i];
+            }
+        };
 
         float rd[MAXR], rt[MAXT];
         auto issue_stage = [&](int ch, int mvc) {
@@ -678,8 +785,8 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #undef MF_WD
         };
 
-        int4 rec = recs[0];
-        int4 rec1 = recs[1];
+        int4 rec = ld_rec(0);
+        int4 rec1 = ld_rec(1);
         int ri = 0;
         if (rec.x >= 0) issue_stage(rec.x, rec.y);
         MF_PHASE_START();
@@ -690,7 +797,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
-            const int4 rec2 = recs[ri + 2];
+            const int4 rec2 = ld_rec(ri + 2);
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
             f32x4 ed[NTILE];
             // One 16-byte load per group of 4 lags.  A group that straddles an end of the valid range
@@ -1026,20 +1133,6 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                                               stream_))
             return rc;
     }
-    {
-        // template norms, lag ranges, channel records: one launch, one workgroup per template
-        mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(
-            d_templates, d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
-            (long long)n_corr, option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0,
-            option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
-        BPMF_LAUNCH_CHECK();
-    }
-    if (!network_sum)
-        BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
-    else if (option(OPT_DEBUG_POISON_OUTPUT) != 0)      // tests: a CC sum that no kernel writes comes back as NaN
-        BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0xFF, T * n_corr * sizeof(float), stream));
-
-    profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     const size_t lds = mf_lds_bytes((int)L);
     // the MFMA kernels evaluate every data-sample offset and keep the multiples of `step`
     const size_t n_offsets = (n_corr - 1) * step + 1;
@@ -1056,6 +1149,34 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !(sqrt_norm && !network_sum) && need_r <= 24 &&
                           need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
                           N < ((size_t)1 << 30) - 8192;
+    const bool wave_kernel = use_mfma && option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
+    // tiles (of 256 lags) per wave of that kernel: 4 unless the problem is too small to give every SIMD ~4 waves
+    // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
+    // (calibrated on an hour-long series with 4 .. 256 templates, tools/probe_mf_ntile_T.py,
+    // profiles/r04_mf_ntile_T.txt: 4 tiles from two full rounds of 4 waves per SIMD on, 2 tiles -- 5 waves
+    // per SIMD at 83-90 VGPRs -- from one wave per SIMD on, 1 tile below)
+    const size_t waves4 = T * ((n_offsets + 4095) / 4096) * 4;
+    int ntile = waves4 >= 8192 ? 4 : (waves4 >= 1024 ? 2 : 1);
+    {
+        const long forced = option(OPT_MF_TILES_PER_WAVE);
+        if (forced == 1 || forced == 2 || forced == 4) ntile = (int)forced;
+    }
+    // small problems: the wave kernel does the per-template preparation itself (mf_fused_prologue)
+    const bool fused = wave_kernel && ntile < 4 && n_ch <= 256 && option(OPT_MF_FUSED_PROLOGUE) != 0;
+    const int exclusive_last = option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0;
+    if (!fused) {
+        // template norms, lag ranges, channel records: one launch, one workgroup per template
+        mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(
+            d_templates, d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
+            (long long)n_corr, exclusive_last, sqrt_norm ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
+        BPMF_LAUNCH_CHECK();
+    }
+    if (!network_sum)
+        BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
+    else if (option(OPT_DEBUG_POISON_OUTPUT) != 0)      // tests: a CC sum that no kernel writes comes back as NaN
+        BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0xFF, T * n_corr * sizeof(float), stream));
+
+    profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks x T / 8) (lag block, template) pairs (mf_tile_of_block)
         dim3 grid((unsigned)(8 * ((T * n_lag_blocks + 7) / 8)));
@@ -1075,17 +1196,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     } while (0)
 #define BPMF_MF_LAUNCH(NS, R, TT) \
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
-        const bool wave_kernel = option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
-            // tiles (of 256 lags) per wave: 4 unless the problem is too small to give every SIMD ~4 waves
-            // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
-            // (calibrated on an hour-long series with 4 .. 256 templates, tools/probe_mf_ntile_T.py,
-            // profiles/r04_mf_ntile_T.txt: 4 tiles from two full rounds of 4 waves per SIMD on, 2 tiles -- 5 waves
-            // per SIMD at 83-90 VGPRs -- from one wave per SIMD on, 1 tile below)
-            const size_t waves4 = T * ((n_offsets + 4095) / 4096) * 4;
-            int ntile = waves4 >= 8192 ? 4 : (waves4 >= 1024 ? 2 : 1);
-            const long forced = option(OPT_MF_TILES_PER_WAVE);
-            if (forced == 1 || forced == 2 || forced == 4) ntile = (int)forced;
             const int Kp = mf_kpad((int)L), Ww = 256 * ntile - 16 + Kp;
             const size_t lags_wg = (size_t)4 * 256 * ntile;
             const size_t n_blocks_w = (n_offsets + lags_wg - 1) / lags_wg;
@@ -1094,18 +1205,23 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                 return -1;
             }
             dim3 grid_w((unsigned)(8 * ((T * n_blocks_w + 7) / 8)));
-            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256;
-#define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ)                                                 \
-    mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ><<<grid_w, dim3(MF_THREADS), wl, stream>>>(        \
+            // (+ 256: slack for the operand prefetch one k-step past the end; FUSED: 16 ints + the channel records)
+            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256 +
+                              (fused ? 64 + (n_ch + 2) * sizeof(int4) : 0);
+#define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ, FU)                                             \
+    mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ, FU><<<grid_w, dim3(MF_THREADS), wl, stream>>>(    \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
-        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO))
-#define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT) \
-    do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false); } while (0)
+        (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO), \
+        d_moveouts, d_weights, exclusive_last)
+#define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT, FU) \
+    do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS, FU); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false, FU); } while (0)
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
     do {                                                                                         \
-        if (ntile == 4) BPMF_MF_WAVE_LAUNCH3(NS, S1, 20, 4);                                     \
-        else if (ntile == 2) BPMF_MF_WAVE_LAUNCH3(NS, S1, 12, 2);                                \
-        else BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1);                                                 \
+        if (ntile == 4) BPMF_MF_WAVE_LAUNCH3(NS, S1, 20, 4, false);                              \
+        else if (ntile == 2 && fused) BPMF_MF_WAVE_LAUNCH3(NS, S1, 12, 2, true);                 \
+        else if (ntile == 2) BPMF_MF_WAVE_LAUNCH3(NS, S1, 12, 2, false);                         \
+        else if (fused) BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1, true);                                \
+        else BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1, false);                                          \
     } while (0)
             if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);

@@ -55,6 +55,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.verbose", 0, 0, 1, false},
     {"mf.tiles_per_wave", 0, 0, 4, false},     // 16x16 tiles per wave of the L <= 257 kernel: 0 = by problem size, 1 / 2 / 4
     {"mf.boundary_prio", 1, 0, 3, false},      // issue priority (s_setprio) of a wave of the L <= 257 kernel while it is outside its K loop (0: none; 1 measured +1.0-1.3 % at every L, 2 / 3 the same)
+    {"mf.fused_prologue", 1, 0, 1, false},     // small problems (fewer than 4 tiles per wave, <= 256 channels): template norms, channel records and lag range computed by every workgroup of the L <= 257 kernel itself -- one launch per call instead of two
     {"debug.poison_output", 0, 0, 1, false},   // tests: fill the (max-beam, arg-max) / CC-sum output with 0xFF bytes (NaN / -1) before the kernels run -- a sample no kernel writes then shows
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)

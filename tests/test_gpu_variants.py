@@ -75,6 +75,56 @@ def test_mf_tiles_per_wave(oracle_lib, ntile, L, hip_opts):
                       oracle_lib.matched_filter(tp, mv, w, d, step, ns), f"ntile={ntile} L={L} N={N} step={step} ns={ns}")
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("ntile", [1, 2])
+def test_mf_fused_prologue(oracle_lib, fused, ntile, hip_opts):
+    """mf.fused_prologue: with fewer than 4 tiles per wave and at most 256 channels the per-wave kernel works the
+    template norms, the compacted channel records and the lag range out itself (one launch); with the option
+    off, or beyond 256 channels, mf_prologue_kernel runs first.  Same bits either way: channel counts around
+    a wave (63 / 64 / 65) and at the limit (256 / 257), channels without weight in every position (first, last,
+    whole waves, all of a template), -0.0 weights, negative moveouts, template lengths around the 16-sample
+    trips of the energy loop, steps 1 and 3, both layouts, the two MF compat switches."""
+    from seismic_bpmf_amd import matched_filter
+    hip_opts("mf.tiles_per_wave", ntile)
+    hip_opts("mf.fused_prologue", fused)
+    rng = np.random.default_rng(900 + 10 * ntile + fused)
+    shapes = [(3, 1, 1, 5), (3, 7, 9, 16), (3, 8, 8, 33), (2, 13, 5, 47), (2, 64, 4, 15), (2, 257, 1, 31),
+              (4, 8, 3, 128), (3, 2, 1, 257), (3, 21, 3, 100)]
+    for T, S, C, L in shapes:
+        N = int(rng.integers(L + 300, 2600))
+        tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+        mv = rng.integers(-90, 250, (T, S, C)).astype(np.int32)
+        w = rng.random((T, S, C)).astype(np.float32)
+        w[rng.random((T, S, C)) < 0.3] = 0.0
+        w.reshape(T, -1)[0, 0] = 0.0
+        w.reshape(T, -1)[0, -1] = 0.0
+        w.reshape(T, -1)[1, : min(S * C, 70)] = 0.0            # a whole wave of threads without a used channel
+        if S * C > 2:
+            w.reshape(T, -1)[1, 1] = -0.0
+        w[-1] = 0.0                                             # a template without any used channel
+        d = rng.standard_normal((S, C, N)).astype(np.float32)
+        for step in (1, 3):
+            for ns in (True, False):
+                if not ns and T * S * C * N > 3_000_000:
+                    continue
+                _same(matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns),
+                      oracle_lib.matched_filter(tp, mv, w, d, step, ns),
+                      f"fused={fused} ntile={ntile} T={T} S={S} C={C} L={L} N={N} step={step} ns={ns}")
+    T, S, C, L, N = 3, 8, 3, 70, 1900
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    mv = rng.integers(-40, 200, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[1, 2] = 0.0
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    for opt, flag in (("mf.compat_exclusive_last_lag", oracle_lib.COMPAT_EXCLUSIVE_LAST_LAG),
+                      ("mf.compat_sqrt_norm", oracle_lib.COMPAT_SQRT_NORM)):
+        with oracle_lib.compat(flag):
+            want = oracle_lib.matched_filter(tp, mv, w, d, 1)
+        hip_opts(opt, 1)
+        _same(matched_filter(tp, mv, w, d, 1, check_zeros=False), want, f"fused={fused} ntile={ntile} {opt}")
+        hip_opts(opt, 0)
+
+
 def test_mf_small_problems_pick_fewer_lags_per_wave(oracle_lib):
     """BASELINE configs[0]'s shape (4 templates, one hour at 50 Hz) takes the one-tile kernel by itself
     and still equals the oracle; a day does not change kernels."""

@@ -18,7 +18,7 @@ import seismic_bpmf_amd as sb  # noqa: E402
 NAMES = ["staging writes", "norm loads + staging issue", "K loop", "epilogue"]
 
 
-def run(L, T=32, S=20, C=3, N=8_640_000):
+def run(L, T=32, S=20, C=3, N=8_640_000, small=False):
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     data = torch.randn((S, C, N), device="cuda", generator=g)
@@ -43,6 +43,11 @@ def run(L, T=32, S=20, C=3, N=8_640_000):
     c = v[:4] / max(1.0, v[4])                    # cycles per channel and wave, mean over every wave of the launch
     # sustained shader clock: the cycles all waves counted / (waves resident at a time x kernel time);
     # 16 waves per CU are resident (128 VGPRs), the tail of the launch makes this a slight underestimate
+    if small:           # fewer than 4 tiles per wave, not every SIMD full: the cycle counts only
+        print(f"T = {T}, {S} x {C} channels, L = {L}, N = {N}: " + "  ".join(f"{n} {x:8.0f}" for n, x in zip(NAMES, c)) +
+              f"   total {c.sum():8.0f} cycles per channel and wave; kernel {ms * 1e3:.1f} us (instrumented build); "
+              f"{v[5]:.0f} waves counted, {v[4] / max(1.0, v[5]):.1f} channels each", flush=True)
+        return
     ghz = v[:4].sum() / (256 * 16) / (ms * 1e-3) / 1e9
     flop = 2.0 * L * S * C * T * (N - L + 1)
     kpad = (L + 15 + 15) // 16 * 16
@@ -56,8 +61,8 @@ def run(L, T=32, S=20, C=3, N=8_640_000):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "configs0":      # BASELINE configs[0]: 1 h @ 50 Hz, 4 templates, 8 x 3 channels
-        run(128, T=4, S=8, C=3, N=180_000)
-    else:
-        for L in [int(x) for x in sys.argv[1:]] or [64, 128, 192, 256]:
-            run(L)
+    for arg in sys.argv[1:] or ["64", "128", "192", "256"]:
+        if arg == "configs0":                     # BASELINE configs[0]: 1 h @ 50 Hz, 4 templates, 8 x 3 channels
+            run(128, T=4, S=8, C=3, N=180_000, small=True)
+        else:
+            run(int(arg))

@@ -50,7 +50,7 @@ PYEOF
 # 6. cycle accounting of both hot kernels (second library with -DBPMF_PHASE_CYCLES)
 (cd $R && python tools/phase/build_phase_lib.py > /dev/null 2>&1 && \
   timeout 600 python tools/phase/bp_phase.py cfg3 10 cfg3 20 cfg5_per_gpu 40 > $R/profiles/${TAG}_bp_fast_phase_cycles.txt 2>&1 ; \
-  timeout 600 python tools/phase/mf_phase.py 64 128 192 256 > $R/profiles/${TAG}_mf_phase_cycles.txt 2>&1)
+  timeout 600 python tools/phase/mf_phase.py 64 128 192 256 configs0 > $R/profiles/${TAG}_mf_phase_cycles.txt 2>&1)
 cd $R && python tools/summarize_prof.py gpurun_out/prof_$TAG $TAG > /dev/null
 # profiles/ on the box is not merged back by gpurun, gpurun_out/ is: leave a copy there
 mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_bench.json $R/profiles/${TAG}_bench_under_rocprof.json \
