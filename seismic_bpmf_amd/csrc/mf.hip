@@ -848,6 +848,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 // the matrix pipe; a read placed there issues for free, a block of reads after the MFMAs would add
 // its issue time to every k-step.  On entry the reads of `cur` and of the k-step after it are
 // outstanding (2 (NTILE + 1)), LDS returns in order, so lgkmcnt(NTILE + 1) = "cur has landed".
+// (Reading 3 / 4 k-steps ahead in the 2- / 1-tile variants, whose k-steps are only 64 / 32 cycles long,
+// changed nothing on configs[0] and its neighbours -- 56.8 -> 56.3 us at L = 128, 91.1 -> 91.1 at L = 256:
+// round 4, profiles/r04_mf_fused_prologue.txt.  Those shapes are not waiting for operands.)
 #define MF_STEP(cur, req, aoff, boff)                                                \
     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NTILE + 1) : "memory");              \
     __builtin_amdgcn_sched_barrier(0);                                               \
