@@ -806,7 +806,15 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             // uniform test first: all but the first and last waves of a template take the loads without
             // a lane mask (every instruction outside the K loop waits for an issue slot behind the MFMAs
             // of the other waves).  (Requesting the norms of channel c + 1 in front of the K loop of channel
-            // c -- for the small problems, whose K loops are short -- changed nothing: round 4.)
+            // c -- for the small problems, whose K loops are short -- changed nothing: round 4.  Nor did the
+            // full version of that idea for the 1-tile variant: two register sets, windows / bands / norms of
+            // TWO channels in flight, every load unconditional so that the compiler's waits came out as
+            // vmcnt(15 .. 27) instead of the vmcnt(0) the epilogue below gets from the `if` around issue_stage --
+            // bit-exact, 87 instead of 52 VGPRs, and SLOWER: configs[0] 56 -> 61 us, 8 templates 107 -> 128 us
+            // (profiles/r04_mf_fused_prologue.txt).  The small shapes do not wait for memory -- an hour of data
+            // sits in the L2 -- but for their own ~400 serial boundary instructions per channel, 2.75 waves to
+            // a SIMD; the in-kernel counters, which put 6 600 of 11 300 cycles into the epilogue at configs[0],
+            // mostly measure their own s_memtime round trips at that scale.)
             if (wave_inside) {
 #pragma unroll
                 for (int u = 0; u < NTILE; ++u) ed[u] = *(const f32x4u*)(edc + lag_w + 256 * u + mvc);

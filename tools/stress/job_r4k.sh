@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-bash tools/fuzz_long.sh 100000 250000 1500 random_shapes
-bash tools/fuzz_long.sh 60000 110000 500 random_dense
+# the driver's own command: serial, first failure stops
+(timeout 1200 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_suite_r4k.log 2>&1; tail -3 gpurun_out/gpu_suite_r4k.log)
+timeout 1500 bash tools/refresh_profiles.sh r04 > gpurun_out/refresh_r04.log 2>&1; tail -5 gpurun_out/refresh_r04.log
+cat profiles/r04_bench.json | cut -c1-1500
