@@ -616,13 +616,21 @@ def main():
             mf2.set_data(d2)
             o2 = mf2.run(t2, m2, w2, 1)
             torch.cuda.synchronize()
-            reps = 20 if N2 < 1_000_000 else 3
+            reps = 50 if N2 < 1_000_000 else 3
+            # the whole call from the host clock over back-to-back resident calls (best of 3 rounds), then the
+            # kernel from the library's events in a round of its own (two event records per call are not part
+            # of a call, and at 60 us per call they show)
+            wall = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    mf2.run(t2, m2, w2, 1, out=o2)
+                torch.cuda.synchronize()
+                wall = min(wall, (time.perf_counter() - t0) / reps)
             _lib.profile_enable(True)
-            t0 = time.perf_counter()
             for _ in range(reps):
                 mf2.run(t2, m2, w2, 1, out=o2)
             torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) / reps
             _lib.profile_enable(False)
             kms = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_MF_MAIN)))
             flop = 2.0 * L2 * S2 * C2 * T2 * (N2 - L2 + 1)
