@@ -691,7 +691,11 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     static_assert(NTILE == 4 || NTILE == 2 || NTILE == 1, "tiles per wave");
     constexpr int LAGS_W = 256 * NTILE, LAGS_WG = 4 * LAGS_W;
     const int Ww = LAGS_W - 16 + Kpad;          // this wave's window
-    const int wave_floats = tp_len + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64;   // (+ 64: whole 64-lane chunks are written)
+    // FULLW (the 1- and 2-tile variants): the wave's buffer has room for ALL its staging registers (64 MAXR window
+    // floats), whatever the template length -- see write_stage
+    constexpr bool FULLW = NTILE < 4;
+    const int Wbuf = FULLW ? 64 * MAXR : Ww;
+    const int wave_floats = tp_len + (Wbuf + 2 * (Wbuf >> 4) + 2 + 63) / 64 * 64 + 64;   // (+ 64: whole 64-lane chunks are written)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -770,6 +774,21 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
         // profiles/r03_mf_phase_cycles.txt).
         const int rd_chunks = (Ww + 63) >> 6, rt_chunks = (tp_len + 63) >> 6;
         auto write_stage = [&]() {
+            if constexpr (FULLW) {
+                // The small problems' variants write EVERY staging register, needed or not: the band chunks past
+                // the end of the band land in the window, which is written after them, the window chunks past
+                // its end in the room the buffer has for them.  13 / 17 stores without a branch instead of the
+                // two jump tables below, which the compiler turns into ~50 scalar branches and ~100 flag moves
+                // per channel -- a fifth of what a wave of those shapes executes between two K loops.
+#pragma unroll
+                for (int r = 0; r < MAXT; ++r) tp[lane + 64 * r] = rt[r];
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int x = lane + 64 * r;
+                    dw[x + 2 * (x >> 4)] = rd[r];
+                }
+                return;
+            }
 #define MF_WT(r) case (r) + 1: if constexpr ((r) < MAXT) tp[lane + 64 * ((r) < MAXT ? (r) : 0)] = rt[(r) < MAXT ? (r) : 0]; [[fallthrough]];
             switch (rt_chunks) {
                 MF_WT(4) MF_WT(3) MF_WT(2) MF_WT(1) MF_WT(0)
@@ -1217,7 +1236,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             }
             dim3 grid_w((unsigned)(8 * ((T * n_blocks_w + 7) / 8)));
             // (+ 256: slack for the operand prefetch one k-step past the end; FUSED: 16 ints + the channel records)
-            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Ww + 2 * (Ww >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256 +
+            const int Wbuf = ntile < 4 ? 64 * (ntile == 2 ? 12 : 8) : Ww;      // (FULLW: room for every staging register)
+            const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Wbuf + 2 * (Wbuf >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256 +
                               (fused ? 64 + (n_ch + 2) * sizeof(int4) : 0);
 #define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ, FU)                                             \
     mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ, FU><<<grid_w, dim3(MF_THREADS), wl, stream>>>(    \
