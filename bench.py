@@ -549,9 +549,9 @@ def main():
                 "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
                 "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",
                 "frac_note": ("peak = 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz (nominal).  Cycle counters in the kernel "
-                              "(profiles/r03_mf_phase_cycles.txt, NOT measured in this run): at L = 256 the matrix pipe is "
-                              "busy 99 % of the cycles and the chip sustains 2.19 GHz under this instruction mix; "
-                              "L / (L + 16) = 0.941 of the issued MFMA flops are direct-form flops: 0.941 x 0.9125 x 0.99 = 0.85"),
+                              "(profiles/r04_mf_phase_cycles.txt, tools/phase/, NOT measured in this run): at L = 256 the matrix "
+                              "pipe is busy 95 % of the counted cycles and the chip sustains ~2.3 GHz under this instruction mix; "
+                              "L / (L + 16) = 0.941 of the issued MFMA flops are direct-form flops: 0.941 x 0.96 x 0.95 = 0.86"),
                 "hbm_frac_informational": round(
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     peak = float(cc[0].max().item())
