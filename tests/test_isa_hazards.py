@@ -148,3 +148,23 @@ def test_mf_kernels_touch_no_register_in_flight(tmp_path):
         assert any(t.startswith("v_mfma_f32_16x16x4") for t in body)
         bad = check_inflight.check_kernel(body)
         assert not bad, f"{n}: {bad[:4]}"
+    # the headline kernel (network sum, step 1, 4 tiles per wave, default epilogue): 4 waves per SIMD -- at most
+    # 128 VGPRs -- and nothing in scratch; 16 MFMAs per trip of its K loop
+    import re
+    text = out.read_text()
+    meta = text[text.index("amdhsa.kernels"):]
+    head = [b for b in meta.split("  - .agpr_count")[1:]
+            if re.search(r"mf_mfma_wave_kernelILb1ELi20ELi5ELb1ELi4ELb0ELb0E", b)]
+    assert len(head) == 1
+    assert int(re.search(r"\.vgpr_count:\s+(\d+)", head[0]).group(1)) <= 128
+    assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", head[0]).group(1)) == 0
+    assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", head[0]).group(1)) == 0
+    hname = [n for n in names if "mf_mfma_wave_kernelILb1ELi20ELi5ELb1ELi4ELb0ELb0E" in n][0]
+    assert sum(t.startswith("v_mfma_f32_16x16x4") for t in kernels[hname]) == 16
+    # the small problems' variants (1 / 2 tiles per wave) store their staging registers without jump tables:
+    # MAXR + MAXT ds_write_b32 in the channel loop and no scratch either
+    for key, n_writes in (("ILb1ELi8ELi5ELb1ELi1ELb0ELb0E", 13), ("ILb1ELi12ELi5ELb1ELi2ELb0ELb0E", 17)):
+        kn = [n for n in names if "mf_mfma_wave_kernel" + key in n][0]
+        stored = sum(2 if t.startswith("ds_write2") else 1 for t in kernels[kn] if t.startswith("ds_write"))
+        assert stored == n_writes, (kn, stored)       # (the compiler pairs some into ds_write2st64_b32)
+        assert not any("scratch_" in t for t in kernels[kn])
