@@ -551,6 +551,74 @@ def gibbs_weights(maxbeam, effective_kT=0.33):
     return np.exp(-(mb.max() - mb) / effective_kT)
 
 
+WGS84_A = 6378137.0                 # semi-major axis, m
+WGS84_F = 1.0 / 298.257223563       # flattening
+
+
+def geodesic_distance_m(lon0, lat0, lon, lat, max_iter=200, tol=1e-12):
+    """Length in metres of the WGS84 geodesics from (lon0, lat0) to every (lon[i], lat[i]), degrees in --
+    what ``cartopy.geodesic.Geodesic().inverse(...)[:, 0]`` returns in
+    Beamformer._compute_location_uncertainty (BPMF/template_search.py:1310-1320; cartopy wraps
+    GeographicLib on the same ellipsoid).  Vincenty's inverse iteration, vectorised: within a fraction of a
+    millimetre of GeographicLib for every pair that is not nearly antipodal (a source grid never is; a
+    pair the iteration does not converge for raises ValueError instead of returning a wrong length).
+    Host code (float64 NumPy): a domain has a few thousand sources."""
+    lon = np.atleast_1d(np.asarray(lon, dtype=np.float64))
+    lat = np.atleast_1d(np.asarray(lat, dtype=np.float64))
+    lon, lat = np.broadcast_arrays(lon, lat)
+    f, a = WGS84_F, WGS84_A
+    b = (1.0 - f) * a
+    u1 = np.arctan((1.0 - f) * np.tan(np.deg2rad(float(lat0))))
+    u2 = np.arctan((1.0 - f) * np.tan(np.deg2rad(lat)))
+    su1, cu1, su2, cu2 = np.sin(u1), np.cos(u1), np.sin(u2), np.cos(u2)
+    big_l = np.deg2rad((lon - float(lon0) + 180.0) % 360.0 - 180.0)     # longitude difference in [-180, 180)
+    def at(lam):
+        sl, cl = np.sin(lam), np.cos(lam)
+        sin_sig = np.hypot(cu2 * sl, cu1 * su2 - su1 * cu2 * cl)
+        cos_sig = su1 * su2 + cu1 * cu2 * cl
+        sig = np.arctan2(sin_sig, cos_sig)
+        sin_al = np.where(sin_sig > 0.0, cu1 * cu2 * sl / np.where(sin_sig > 0.0, sin_sig, 1.0), 0.0)
+        cos2_al = 1.0 - sin_al * sin_al
+        cos_2sm = np.where(cos2_al > 0.0, cos_sig - 2.0 * su1 * su2 / np.where(cos2_al > 0.0, cos2_al, 1.0), 0.0)
+        return sin_sig, cos_sig, sig, sin_al, cos2_al, cos_2sm
+
+    lam = big_l.copy()
+    done = np.zeros(lam.shape, dtype=bool)
+    # (a point that has converged is left alone, and the lengths come from one evaluation at the final
+    # longitudes: the result of a point does not depend on what else is in the call)
+    for _ in range(max_iter):
+        sin_sig, cos_sig, sig, sin_al, cos2_al, cos_2sm = at(lam)
+        c = f / 16.0 * cos2_al * (4.0 + f * (4.0 - 3.0 * cos2_al))
+        new = big_l + (1.0 - c) * f * sin_al * (
+            sig + c * sin_sig * (cos_2sm + c * cos_sig * (-1.0 + 2.0 * cos_2sm * cos_2sm)))
+        conv = np.abs(new - lam) < tol
+        lam = np.where(done, lam, new)
+        done = done | conv
+        if done.all():
+            break
+    if not done.all():
+        raise ValueError("geodesic_distance_m: no convergence (nearly antipodal points)")
+    sin_sig, cos_sig, sig, sin_al, cos2_al, cos_2sm = at(lam)
+    usq = cos2_al * (a * a - b * b) / (b * b)
+    big_a = 1.0 + usq / 16384.0 * (4096.0 + usq * (-768.0 + usq * (320.0 - 175.0 * usq)))
+    big_b = usq / 1024.0 * (256.0 + usq * (-128.0 + usq * (74.0 - 47.0 * usq)))
+    d_sig = big_b * sin_sig * (cos_2sm + big_b / 4.0 * (
+        cos_sig * (-1.0 + 2.0 * cos_2sm * cos_2sm)
+        - big_b / 6.0 * cos_2sm * (-3.0 + 4.0 * sin_sig * sin_sig) * (-3.0 + 4.0 * cos_2sm * cos_2sm)))
+    return b * big_a * (sig - d_sig)
+
+
+def compute_location_uncertainty(event_longitude, event_latitude, event_depth, likelihood,
+                                 source_longitude, source_latitude, source_depth):
+    """Beamformer._compute_location_uncertainty (BPMF/template_search.py:1269-1333) without cartopy:
+    (hunc, vunc) in km -- the likelihood-weighted mean geodesic distance of the domain's sources to the
+    event and their mean absolute depth difference.  `source_*`: the coordinates of the sources OF THE
+    DOMAIN (the reference indexes its grid with `domain`), `likelihood`: theirs."""
+    d_km = geodesic_distance_m(event_longitude, event_latitude, source_longitude, source_latitude) / 1000.0
+    depth_diff = np.abs(float(event_depth) - np.asarray(source_depth, dtype=np.float64))
+    return location_uncertainty(likelihood, d_km, depth_diff)
+
+
 def location_uncertainty(likelihood_domain, distances_km, depth_diff_km):
     """Beamformer._compute_location_uncertainty (BPMF/template_search.py:1269-1333) behind its geodesic
     call: likelihood-weighted mean epicentral distance and mean absolute depth difference of the

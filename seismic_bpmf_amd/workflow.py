@@ -266,8 +266,8 @@ def relocation_likelihood(beamformer, features, weights_phases, out_of_bounds="f
     float32 subtract / divide / clip, the operations NumPy performs, evaluated on the column where it
     lies.  Only `likelihood[domain]` (or the whole (K,) vector when `domain` is None) comes back.
 
-    Returns (src_idx, time_idx, likelihood): feed `likelihood` with the domain's geodesic distances
-    to postprocess.location_uncertainty for (hunc, vunc)."""
+    Returns (src_idx, time_idx, likelihood): feed `likelihood` and the domain's coordinates to
+    postprocess.compute_location_uncertainty for (hunc, vunc)."""
     import torch
     vol = beamformer.run(features, weights_phases, "none", out_of_bounds)
     first = int(torch.argmax(vol.reshape(-1)))

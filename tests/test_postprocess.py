@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from seismic_bpmf_amd import postprocess as pp
 from seismic_bpmf_amd import synthetic as syn
@@ -290,3 +291,42 @@ def test_relocation_likelihood_and_uncertainty_match_reference():
         hunc, vunc = pp.location_uncertainty(like[g[f"domain_{j}"]], g[f"distances_km_{j}"], g[f"depth_diff_{j}"])
         assert hunc == g[f"hunc_{j}"] and vunc == g[f"vunc_{j}"], j
         assert np.array_equal(pp.gibbs_weights(g[f"maxbeam_{j}"], float(g["effective_kT"])), g[f"gibbs_{j}"]), j
+
+
+def test_geodesic_distance_known_answers_and_location_uncertainty():
+    """postprocess.geodesic_distance_m stands in for cartopy's Geodesic().inverse(...)[:, 0] in
+    Beamformer._compute_location_uncertainty (BPMF/template_search.py:1310-1320; cartopy is not in this image,
+    so the reference's method cannot run here).  Pinned instead to published lengths on the same ellipsoid:
+    the WGS84 quarter meridian (10 001 965.729 m), an arc of the equator (a x dlambda exactly), Geoscience
+    Australia's Flinders Peak - Buninyong line (54 972.271 m; GRS80, whose flattening differs from WGS84's
+    in the 11th digit) and GeographicLib's JFK - LHR example (5 551 759.400 m).  Tolerance: 1 mm -- the
+    reference divides by 1000 and averages distances of kilometres."""
+    d = pp.geodesic_distance_m
+    assert abs(d(0.0, 0.0, 0.0, 90.0)[0] - 10_001_965.729) < 1e-3
+    assert abs(d(12.0, -90.0, 77.0, 0.0)[0] - 10_001_965.729) < 1e-3          # from the pole, any longitude
+    assert abs(d(0.0, 0.0, 10.0, 0.0)[0] - pp.WGS84_A * np.deg2rad(10.0)) < 1e-6
+    assert abs(d(175.0, 0.0, -175.0, 0.0)[0] - pp.WGS84_A * np.deg2rad(10.0)) < 1e-6   # across the date line
+    flinders = (144 + 25 / 60 + 29.52440 / 3600, -(37 + 57 / 60 + 3.72030 / 3600))
+    buninyong = (143 + 55 / 60 + 35.38390 / 3600, -(37 + 39 / 60 + 10.15610 / 3600))
+    assert abs(d(*flinders, *buninyong)[0] - 54_972.271) < 1e-3
+    assert abs(d(*buninyong, *flinders)[0] - 54_972.271) < 1e-3               # symmetric
+    assert abs(d(-73.8, 40.6, -0.5, 51.6)[0] - 5_551_759.400) < 1e-3
+    # a regional grid around an event: vectorised call == one call per source; zero at the event itself;
+    # close to the local flat-earth figure the reference's own _rectangular_domain uses (6371 km sphere)
+    rng = np.random.default_rng(3)
+    lon0, lat0 = 30.4, 40.7
+    lons = lon0 + rng.uniform(-0.5, 0.5, 200)
+    lats = lat0 + rng.uniform(-0.4, 0.4, 200)
+    lons[0], lats[0] = lon0, lat0
+    dist = d(lon0, lat0, lons, lats)
+    assert dist[0] == 0.0 and np.all(np.isfinite(dist)) and np.all(dist[1:] > 0)
+    assert np.array_equal(dist, np.concatenate([d(lon0, lat0, lons[i], lats[i]) for i in range(200)]))
+    flat = 6371.0e3 * np.hypot(np.deg2rad(lats - lat0), np.deg2rad(lons - lon0) * np.cos(np.deg2rad(lat0)))
+    assert np.all(np.abs(dist - flat) <= 0.006 * flat + 1.0)
+    depth = rng.uniform(0.0, 30.0, 200)
+    like = rng.random(200)
+    hunc, vunc = pp.compute_location_uncertainty(lon0, lat0, 12.5, like, lons, lats, depth)
+    assert hunc == np.sum(like * dist / 1000.0) / np.sum(like)
+    assert vunc == np.sum(like * np.abs(12.5 - depth)) / np.sum(like)
+    with pytest.raises(ValueError):
+        d(0.0, 0.0, 179.9, 0.05)                                              # nearly antipodal: no silent wrong answer
