@@ -330,3 +330,23 @@ def test_geodesic_distance_known_answers_and_location_uncertainty():
     assert vunc == np.sum(like * np.abs(12.5 - depth)) / np.sum(like)
     with pytest.raises(ValueError):
         d(0.0, 0.0, 179.9, 0.05)                                              # nearly antipodal: no silent wrong answer
+
+
+def test_geodesic_distance_properties():
+    """Symmetry, the triangle inequality and agreement with the meridian / equator closed forms over random
+    regional point sets (the geometry a source grid has: points within a few degrees of one another)."""
+    rng = np.random.default_rng(11)
+    d = pp.geodesic_distance_m
+    for _ in range(20):
+        lon_c, lat_c = rng.uniform(-180, 180), rng.uniform(-70, 70)
+        lon = lon_c + rng.uniform(-3, 3, 30)
+        lat = lat_c + rng.uniform(-3, 3, 30)
+        ab = d(lon[0], lat[0], lon[1:], lat[1:])
+        ba = np.concatenate([d(lon[i], lat[i], lon[0], lat[0]) for i in range(1, 30)])
+        assert np.all(np.abs(ab - ba) < 1e-6)
+        bc = d(lon[1], lat[1], lon[2:], lat[2:])
+        assert np.all(ab[1:] <= ab[0] + bc + 1e-6)
+        # same meridian: the length is the difference of two meridian arcs from the equator
+        m = d(lon_c, 0.0, [lon_c, lon_c], [lat_c, lat_c + 1.0])
+        signed = np.sign([lat_c, lat_c + 1.0]) * m           # (arcs south of the equator count negative)
+        assert abs(d(lon_c, lat_c, lon_c, lat_c + 1.0)[0] - abs(signed[1] - signed[0])) < 1e-5
