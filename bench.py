@@ -458,13 +458,47 @@ def detection_stage(cc, planted, local_rank, dist, device, t_offset=0):
 
 
 # ------------------------------------------------------------------------------- main ---
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.
+
+    The driver's documented N > 1 command wraps bench.py in `python -m torch.distributed.run`; a bare
+    `python bench.py --gpus 8` (the shape of the N = 1 command) used to run ONE rank and report n_gpus 1
+    without a word (round-4 review).  Now it re-executes itself under torch.distributed.run with
+    --nproc-per-node N on 127.0.0.1 and a free port, or fails loudly when fewer than N devices are visible.
+    BPMF_BENCH_FORCE_DIST=1 takes the same route for N = 1 (RCCL initialised with one rank)."""
+    import socket
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} HIP device(s) visible "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, "
+                         f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r}); refusing to run fewer ranks")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this host driver
+    env["BPMF_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.write(f"[bench] launching {args.gpus} rank(s): {' '.join(cmd)}\n")
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    force_dist = os.environ.get("BPMF_BENCH_FORCE_DIST") == "1"
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launched and (args.gpus > 1 or force_dist):
+        self_launch(args)                       # does not return
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     # Every N times the SAME per-GPU workload: the single-GPU configurations BASELINE.json quotes the metric
     # on (configs[1] / configs[2]) -- N ranks = N x 500 templates (N x 50 000 sources) against a replicated
     # day, so that value(N) / (N x value(1)) reads as weak-scaling efficiency.  (Rounds 1-3 switched to the
@@ -477,16 +511,36 @@ def main():
         args.bp_config = "cfg3"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     # BPMF_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (exercises the N > 1 code path on
     # a single-GPU box)
-    if world > 1 or os.environ.get("BPMF_BENCH_FORCE_DIST") == "1":
+    ranks_info = None
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        # who runs where: (rank, local device index, device name, PCI bus id) of every rank, and one
+        # all-reduce over RCCL that only comes out right when every rank took part
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "device": local_rank, "name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "pid": os.getpid()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones)
+        ranks_info = {"rccl_ranks": int(ones.item()), "backend": dist.get_backend(), "ranks": gathered,
+                      "self_launched": os.environ.get("BPMF_BENCH_SELF_LAUNCHED") == "1"}
+        if ranks_info["rccl_ranks"] != world:
+            raise SystemExit(f"RCCL all-reduce saw {ranks_info['rccl_ranks']} ranks, expected {world}")
+        if len({(g["device"]) for g in gathered}) != world:
+            raise SystemExit(f"two ranks share a device: {gathered}")
 
     import seismic_bpmf_amd as sb
     from seismic_bpmf_amd import _lib, synthetic as syn
@@ -907,7 +961,8 @@ def main():
     if rank == 0:
         line = {
             "metric": "million network-CC-samples/s (matched filter)",
-            "value": round(mf_value, 2), "unit": "M CC-samples/s", "n_gpus": world,
+            "value": round(mf_value, 2), "unit": "M CC-samples/s",
+            "n_gpus": (ranks_info["rccl_ranks"] if ranks_info else 1),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(mf_dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -921,6 +976,7 @@ def main():
                        "row0_peak_cc": round(peak, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "mf_shapes": mf_shapes, "bp": bp_obj,
             "detection": detect, "shares": shares, "compat": compat,
+            "ranks": ranks_info,
         }
     if dist is not None:
         dist.destroy_process_group()

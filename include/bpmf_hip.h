@@ -78,6 +78,13 @@ int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_byt
  *   bp.fast_uniform bp.fast_tile bp.halves bp.direct bp.split bp.wpb bp.smeta bp.verbose
  *   mf.wave_kernel mf.tiles_per_wave mf.boundary_prio mf.fused_prologue mf.max_mfma_step mf.host_batch_kb mf.host_piece_kb mf.verbose
  *   debug.poison_output (tests: outputs pre-filled with 0xFF bytes, so that a sample no kernel writes shows)
+ *   debug.virtual_devices (tests: k > 0 makes every `device` argument a LOGICAL device 0 .. k-1, logical d on
+ *     physical GPU d % visible, each with its own streams / working set / call mutex and, in the *_run_multi
+ *     entry points, its own host thread: the multi-device branches run on a box with one GPU;
+ *     bpmf_device_count then reports k)
+ *   multi.peer_fanout (*_run_multi on several devices: 1 = the first device uploads the day of data from the
+ *     host ONCE and the others copy it device -> device, hipMemcpyPeerAsync over xGMI; 0 = every device
+ *     uploads from the host itself, which is what the upstream back-ends do)
  *   and the three result-changing upstream-compatibility switches (off by default):
  *   mf.compat_exclusive_last_lag mf.compat_sqrt_norm bp.compat_first_computed
  * (The reference's counterpart is the `device=` / `arch=` string it forwards to the third-party
@@ -120,8 +127,10 @@ int bpmf_mf_run(const float *templates, const int32_t *moveouts, const float *we
                 float *cc_out);
 
 /* The same call with the templates block-partitioned over several GPUs inside the library
- * (one host thread per device, the whole `data` copied to each, no traffic between devices):
- * what upstream's `arch="gpu"` back-end does with every visible device.
+ * (one host thread per distinct device, every device holds the whole `data`): what upstream's
+ * `arch="gpu"` back-end does with every visible device.  The data reach the first device from the
+ * host once and the others device -> device (option multi.peer_fanout; upstream copies the day to
+ * every device from the host); no CC value crosses devices.
  *   n_devices <= 0: all visible devices; devices == NULL: devices 0 .. n_devices-1. */
 int bpmf_mf_run_multi(const float *templates, const int32_t *moveouts, const float *weights,
                       const float *data, size_t step, size_t L, size_t N, size_t T, size_t S,
@@ -192,7 +201,8 @@ int bpmf_bp_run(const float *features, const int32_t *moveouts, const float *w_p
 /* The same call with the source grid block-partitioned over several GPUs inside the library.
  * reduce max: the per-device maxima are merged on the host in ascending block order with a
  * strict >, so ties keep the lowest source index exactly like one sequential scan;
- * reduce none: every device fills its own rows of beam_out.  n_devices / devices as above. */
+ * reduce none: every device fills its own rows of beam_out.  n_devices / devices as above; the
+ * features reach the devices like the data of bpmf_mf_run_multi (option multi.peer_fanout). */
 int bpmf_bp_run_multi(const float *features, const int32_t *moveouts, const float *w_phases,
                       const float *w_sources, size_t N, size_t K, size_t S, size_t C, size_t P,
                       int out_of_bounds, int reduce, int n_devices, const int *devices,

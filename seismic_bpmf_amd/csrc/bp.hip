@@ -2486,7 +2486,7 @@ uint64_t hash_words(const void* p, size_t bytes, uint64_t seed)
 size_t plan_cache_capacity()
 {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) n = 1;
+    if (device_counts(&n, nullptr) != hipSuccess || n < 1) n = 1;
     return (size_t)std::max(4, 2 * n);
 }
 }  // namespace
@@ -2508,6 +2508,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     DeviceContext* ctx = device_context(device);
     if (!ctx) return -2;
     std::lock_guard<std::mutex> call_lock(ctx->call_mutex);
+    FanoutScope fan;      // (behind the lock: a source waits for its peers before another call may touch its data)
     // BPMF calls beamform once per day with the same moveout table and source weights
     // (template_search.py:549-558); building the plan costs 0.04 s for 50 000 sources but 3 s for a
     // million, so the last plans are kept.
@@ -2602,7 +2603,10 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     // (pageable memory through the runtime's own staging, on the private stream: a hand-made pipeline through
     // the context's pinned pieces filled by 8 host threads measured SLOWER -- cfg3 end to end 194 ms against
     // 176 ms -- the host-side memcpy into the pinned pieces is the bottleneck on the 16 CPUs a box grants)
-    if ((e = hipMemcpyAsync(base + o_f, features, b_f, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D features");
+    {                     // the day of features: from the host, or from the first device of a multi-device call
+        const char* what = "H2D features";
+        if ((e = fanout_upload(fan, ctx, base + o_f, features, b_f, stream, &what)) != hipSuccess) fail(e, what);
+    }
     if (!rc && (e = hipMemcpyAsync(base + o_wp, w_phases, b_wp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights_phases");
     if (!rc && reduce == BPMF_BP_REDUCE_NONE &&
         (e = hipMemsetAsync(base + o_beam, 0, b_beam, stream)) != hipSuccess) fail(e, "memset");

@@ -31,6 +31,7 @@ enum Option {
     OPT_BP_WPS, OPT_BP_UVGPR, OPT_BP_FAST, OPT_BP_FAST_UNIFORM, OPT_BP_SPLIT, OPT_BP_WPB,
     OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_BP_FAST_TILE, OPT_BP_HALVES, OPT_BP_DIRECT, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
     OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_MF_TILES_PER_WAVE, OPT_MF_BOUNDARY_PRIO, OPT_MF_FUSED_PROLOGUE, OPT_DEBUG_POISON_OUTPUT,
+    OPT_DEBUG_VIRTUAL_DEVICES, OPT_MULTI_PEER_FANOUT,
     // upstream-compatibility switches: the ONLY options that change results (off by default)
     OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG, OPT_MF_COMPAT_SQRT_NORM, OPT_BP_COMPAT_FIRST_COMPUTED, OPT_COUNT
 };
@@ -39,25 +40,44 @@ long option(Option which);
 // built under the options of its creation)
 unsigned long long option_generation();
 
-// Binds the calling thread to `device` for the lifetime of the guard and restores the device
-// that was current before: a host entry point must not change the caller's (or torch's)
-// current device as a side effect.  ok() is false if either runtime call failed.
+// Logical and physical devices (util.hip).  Every `device` argument of the C ABI is a LOGICAL device.
+// Normally logical == physical.  Option debug.virtual_devices = k > 0 (tests) makes the library see k
+// logical devices 0 .. k-1, logical d living on physical GPU d % (GPUs visible): each logical device has
+// its own DeviceContext (streams, working set, call mutex) and, in the *_run_multi entry points, its own
+// host thread -- which is how the multi-device branches (threads, peer copies of the day of data, the
+// host merge of the beam maxima) run under `pytest -m gpu` on a box with ONE GPU.
+hipError_t device_counts(int* n_logical, int* n_physical);
+int physical_device(int logical);
+// the logical device the calling thread is bound to by its innermost DeviceGuard (-1: none)
+extern thread_local int t_logical_device;
+
+// Binds the calling thread to (the physical GPU of) logical `device` for the lifetime of the guard and
+// restores the device that was current before: a host entry point must not change the caller's (or
+// torch's) current device as a side effect.  error() is not hipSuccess if either runtime call failed.
 class DeviceGuard {
 public:
-    explicit DeviceGuard(int device)
+    explicit DeviceGuard(int device) : DeviceGuard(device, physical_device(device)) {}
+    // (a context remembers the physical GPU it was created on: valid whatever the option says now)
+    DeviceGuard(int logical, int physical)
     {
+        prev_logical_ = t_logical_device;
+        t_logical_device = logical;
         err_ = hipGetDevice(&prev_);
-        if (err_ == hipSuccess && prev_ != device) {
-            err_ = hipSetDevice(device);
+        if (err_ == hipSuccess && prev_ != physical) {
+            err_ = hipSetDevice(physical);
             switched_ = err_ == hipSuccess;
         }
     }
-    ~DeviceGuard() { if (switched_) (void)hipSetDevice(prev_); }
+    ~DeviceGuard()
+    {
+        if (switched_) (void)hipSetDevice(prev_);
+        t_logical_device = prev_logical_;
+    }
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
     hipError_t error() const { return err_; }
 private:
-    int prev_ = 0;
+    int prev_ = 0, prev_logical_ = -1;
     bool switched_ = false;
     hipError_t err_ = hipSuccess;
 };

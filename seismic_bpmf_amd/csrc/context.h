@@ -15,16 +15,27 @@
 #include "common.h"
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 
 namespace bpmf {
 
 struct DeviceContext {
-    int device = 0;
+    int device = 0;                   // logical device (common.h)
+    int physical = 0;                 // the GPU it lives on, fixed at creation
     std::mutex call_mutex;            // one host-pointer call on this device at a time
     hipStream_t s_run = nullptr;      // kernels and H2D of the call (non-blocking: never the null stream)
     hipStream_t s_copy = nullptr;     // D2H of finished batches
-    hipStream_t s_side = nullptr;     // edge tiles of the backprojection beside the interior kernels
+    // edge tiles of the backprojection beside the interior kernels: a small pool dealt round-robin to
+    // the device's plans at their creation (never created or destroyed afterwards).  Host-pointer calls
+    // are serialised by call_mutex whatever stream their plan holds; resident plans driven from several
+    // threads through bpmf_bp_run_dev mostly get different side streams and do not queue behind each
+    // other's edge tiles (with more than SIDE_STREAMS live plans two of them share one: still correct --
+    // every plan forks and joins with its own events -- only serialised).
+    static constexpr int SIDE_STREAMS = 4;
+    hipStream_t s_side[SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    std::atomic<unsigned> next_side{0};
+    hipEvent_t ev_data = nullptr;     // *_run_multi: the day of data has arrived on this device (peer fan-out)
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev_piece[2] = {nullptr, nullptr};
     // grow-only buffers, valid while call_mutex is held
@@ -45,6 +56,113 @@ struct DeviceContext {
     void release_memory();
 };
 
+// The day of data of one *_run_multi call on several devices (option multi.peer_fanout): the FIRST device
+// of the list uploads it from the host once and publishes where it lies; every other device copies it
+// device -> device (hipMemcpyPeerAsync on its own stream, behind the source's event) instead of pulling
+// the same gigabytes through the host's pageable-memory staging a second, third ... eighth time (SURVEY.md
+// section 8e: "broadcast once per day").  The source keeps its copy alive until every peer is through with
+// its call (wait_peers at the end of the source's call, under its context mutex); a peer that finds the
+// hand-over cancelled or failed uploads from the host like a single-device call.  Upstream's GPU back-ends
+// copy the whole day to every device from the host.
+struct DataFanout {
+    enum Role { NONE = 0, SOURCE = 1, PEER = 2 };
+    explicit DataFanout(int n_peers) : pending(n_peers) {}
+    // source: the copy at `d_src` (device memory of physical GPU `physical`) is complete once `ready` fires
+    void publish(const void* d_src_, int physical, hipEvent_t ready_)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (published) return;
+        d_src = d_src_; src_physical = physical; ready = ready_;
+        published = true;
+        cv.notify_all();
+    }
+    // nothing will be published (the source failed before its upload, or never ran): peers upload themselves
+    void cancel()
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (!published) { published = true; failed = true; }
+        cv.notify_all();
+    }
+    // peer: blocks until the source has published or cancelled; false = upload from the host yourself
+    bool wait_published(const void** d_src_, int* physical, hipEvent_t* ready_)
+    {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return published; });
+        if (failed) return false;
+        *d_src_ = d_src; *physical = src_physical; *ready_ = ready;
+        return true;
+    }
+    void peer_done()
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (pending > 0) --pending;
+        cv.notify_all();
+    }
+    // source: until every peer has called peer_done (or the hand-over was cancelled)
+    void wait_peers()
+    {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return pending <= 0 || failed; });
+    }
+private:
+    std::mutex m;
+    std::condition_variable cv;
+    const void* d_src = nullptr;
+    int src_physical = -1;
+    hipEvent_t ready = nullptr;
+    bool published = false, failed = false;
+    int pending;
+};
+// the hand-over the calling thread's NEXT host-pointer call takes part in (set by *_run_multi around the
+// first block of every distinct device; nullptr otherwise) and its role in it
+extern thread_local DataFanout* t_fanout;
+extern thread_local int t_fanout_role;
+// RAII of a participant: whatever happens inside the call, the source cancels an unpublished hand-over
+// and waits for its peers, a peer reports that it is through
+struct FanoutScope {
+    DataFanout* f;
+    int role;
+    FanoutScope() : f(t_fanout), role(t_fanout_role) { t_fanout = nullptr; t_fanout_role = DataFanout::NONE; }
+    ~FanoutScope()
+    {
+        if (!f) return;
+        if (role == DataFanout::SOURCE) { f->cancel(); f->wait_peers(); }
+        else if (role == DataFanout::PEER) f->peer_done();
+    }
+    FanoutScope(const FanoutScope&) = delete;
+    FanoutScope& operator=(const FanoutScope&) = delete;
+};
+// *_run_multi, around one block: hands the role to the host-pointer call the thread makes next and
+// settles it if that call never got as far as taking it (an empty block, an argument error)
+struct FanoutArm {
+    FanoutArm(DataFanout* f, int role)
+    {
+        t_fanout = (f && role != DataFanout::NONE) ? f : nullptr;
+        t_fanout_role = t_fanout ? role : (int)DataFanout::NONE;
+    }
+    ~FanoutArm()
+    {
+        if (t_fanout) {
+            if (t_fanout_role == DataFanout::SOURCE) t_fanout->cancel();
+            else if (t_fanout_role == DataFanout::PEER) t_fanout->peer_done();
+        }
+        t_fanout = nullptr;
+        t_fanout_role = DataFanout::NONE;
+    }
+    FanoutArm(const FanoutArm&) = delete;
+    FanoutArm& operator=(const FanoutArm&) = delete;
+};
+// one hand-over at a time per process (*_run_multi try-locks it; a second concurrent multi-device call
+// simply uploads from the host on every device): a source waits for its peers under its device's call
+// mutex, and two hand-overs with crossed device orders would wait for each other
+extern std::mutex g_fanout_mutex;
+
+// Enqueues "the day of data -> d_dst on this thread's current device" on `stream`: from the hand-over when
+// the thread is a peer of one that got published (device -> device), from `host` otherwise; a source
+// publishes behind its upload.  hipSuccess or the failing call's error (`what` names it).
+hipError_t fanout_upload(FanoutScope& scope, DeviceContext* ctx, void* d_dst, const void* host, size_t bytes,
+                         hipStream_t stream, const char** what);
+
 // memcpy on a few host threads (large blocks) -- dst / src pageable or pinned host memory
 void parallel_copy(char* dst, const char* src, size_t bytes);
 
@@ -52,7 +170,8 @@ void parallel_copy(char* dst, const char* src, size_t bytes);
 // the device bound).  nullptr + error text when the runtime refuses.
 DeviceContext* device_context(int device);
 
-// The side stream plans of this device share (nullptr + error text on failure).
+// A side stream of this device for a new plan (round-robin over the context's pool; nullptr + error
+// text on failure).
 hipStream_t device_side_stream(int device);
 
 }  // namespace bpmf

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <system_error>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace bpmf {
@@ -22,7 +23,8 @@ void drain(DeviceContext* c)
 {
     if (c->s_run) (void)hipStreamSynchronize(c->s_run);
     if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
-    if (c->s_side) (void)hipStreamSynchronize(c->s_side);
+    for (hipStream_t s : c->s_side)
+        if (s) (void)hipStreamSynchronize(s);
 }
 }  // namespace
 
@@ -128,25 +130,28 @@ DeviceContext* device_context(int device)
         return nullptr;
     }
     if ((size_t)device < g_contexts.size() && g_contexts[device]) return g_contexts[device];
-    int visible = 0;
-    hipError_t e = hipGetDeviceCount(&visible);
+    int visible = 0;                     // logical devices (option debug.virtual_devices, common.h)
+    hipError_t e = device_counts(&visible, nullptr);
     if (e != hipSuccess || device >= visible) {
         set_error("device %d out of range (%d visible%s%s)", device, visible, e != hipSuccess ? ": " : "",
                   e != hipSuccess ? hipGetErrorString(e) : "");
         return nullptr;
     }
-    DeviceGuard bind(device);
+    const int physical = physical_device(device);
+    DeviceGuard bind(device, physical);
     if (bind.error() != hipSuccess) {
-        set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(bind.error()));
+        set_error("hipSetDevice(%d) failed: %s", physical, hipGetErrorString(bind.error()));
         return nullptr;
     }
     DeviceContext* c = new DeviceContext();
     c->device = device;
+    c->physical = physical;
     hipError_t err = hipSuccess;
     auto step = [&](hipError_t r) { if (err == hipSuccess) err = r; };
     step(hipStreamCreateWithFlags(&c->s_run, hipStreamNonBlocking));
     step(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
-    step(hipStreamCreateWithFlags(&c->s_side, hipStreamNonBlocking));
+    for (hipStream_t& s : c->s_side) step(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    step(hipEventCreateWithFlags(&c->ev_data, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
         step(hipEventCreateWithFlags(&c->ev_batch[i], hipEventDisableTiming));
         step(hipEventCreateWithFlags(&c->ev_piece[i], hipEventDisableTiming));
@@ -164,10 +169,59 @@ DeviceContext* device_context(int device)
     return c;
 }
 
+std::mutex g_fanout_mutex;
+thread_local DataFanout* t_fanout = nullptr;
+thread_local int t_fanout_role = DataFanout::NONE;
+
+namespace {
+// peer access src -> dst enabled once per ordered pair (a direct xGMI copy instead of one staged through
+// the host); a refusal is not an error, hipMemcpyPeerAsync works without it
+std::mutex g_peer_mutex;
+std::vector<std::pair<int, int>> g_peer_tried;
+void ensure_peer_access(int dst_physical, int src_physical)
+{
+    if (dst_physical == src_physical) return;
+    std::lock_guard<std::mutex> g(g_peer_mutex);
+    for (auto& p : g_peer_tried)
+        if (p.first == dst_physical && p.second == src_physical) return;
+    g_peer_tried.emplace_back(dst_physical, src_physical);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst_physical, src_physical) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(src_physical, 0);     // (the current device is dst_physical)
+    (void)hipGetLastError();                                  // "already enabled" (torch, RCCL) is fine
+}
+}  // namespace
+
+hipError_t fanout_upload(FanoutScope& scope, DeviceContext* ctx, void* d_dst, const void* host, size_t bytes,
+                         hipStream_t stream, const char** what)
+{
+    hipError_t e;
+    if (scope.f && scope.role == DataFanout::PEER) {
+        const void* d_src = nullptr;
+        int src_physical = -1;
+        hipEvent_t ready = nullptr;
+        if (scope.f->wait_published(&d_src, &src_physical, &ready)) {
+            ensure_peer_access(ctx->physical, src_physical);
+            *what = "waiting for the first device's upload";
+            if ((e = hipStreamWaitEvent(stream, ready, 0)) != hipSuccess) return e;
+            *what = "device-to-device copy of the data";
+            return hipMemcpyPeerAsync(d_dst, ctx->physical, d_src, src_physical, bytes, stream);
+        }
+    }
+    *what = "H2D data";
+    if ((e = hipMemcpyAsync(d_dst, host, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if (scope.f && scope.role == DataFanout::SOURCE) {
+        *what = "event record";
+        if ((e = hipEventRecord(ctx->ev_data, stream)) != hipSuccess) return e;
+        scope.f->publish(d_dst, ctx->physical, ctx->ev_data);
+    }
+    return hipSuccess;
+}
+
 hipStream_t device_side_stream(int device)
 {
     DeviceContext* c = device_context(device);
-    return c ? c->s_side : nullptr;
+    return c ? c->s_side[c->next_side.fetch_add(1) % DeviceContext::SIDE_STREAMS] : nullptr;
 }
 
 }  // namespace bpmf
@@ -185,9 +239,9 @@ extern "C" int bpmf_release_device_memory(int device)
     }
     for (bpmf::DeviceContext* c : todo) {
         std::lock_guard<std::mutex> call(c->call_mutex);
-        bpmf::DeviceGuard bind(c->device);
+        bpmf::DeviceGuard bind(c->device, c->physical);
         if (bind.error() != hipSuccess) {
-            bpmf::set_error("bpmf_release_device_memory: hipSetDevice(%d) failed: %s", c->device,
+            bpmf::set_error("bpmf_release_device_memory: hipSetDevice(%d) failed: %s", c->physical,
                             hipGetErrorString(bind.error()));
             return -2;
         }

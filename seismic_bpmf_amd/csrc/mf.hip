@@ -1328,6 +1328,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     DeviceContext* ctx = device_context(device);
     if (!ctx) return -2;
     std::lock_guard<std::mutex> call_lock(ctx->call_mutex);
+    FanoutScope fan;      // (behind the lock: a source waits for its peers before another call may touch its data)
     size_t o_tp = 0, o_mv = o_tp + align_up(b_tp, 256), o_w = o_mv + align_up(b_mv, 256),
            o_d = o_w + align_up(b_w, 256), o_out0 = o_d + align_up(b_d, 256),
            o_out1 = o_out0 + align_up(b_out, 256),
@@ -1349,7 +1350,10 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
-    if (!rc) MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
+    if (!rc) {            // the day of data: from the host, or from the first device of a multi-device call
+        const char* what = "H2D data";
+        MF_TRY(fanout_upload(fan, ctx, base + o_d, data, b_d, s_run, &what), what);
+    }
     if (!rc)
         rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
     auto launch = [&](size_t b) {

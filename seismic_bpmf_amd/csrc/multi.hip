@@ -15,9 +15,12 @@
 #include "common.h"
 #include "../../include/bpmf_hip.h"
 #include "bp_plan.h"
+#include "context.h"
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -32,8 +35,8 @@ using bpmf::set_error;
 int resolve_devices(int n_devices, const int* devices, size_t n_items, std::vector<int>& out,
                     const char* who)
 {
-    int visible = 0;
-    hipError_t e = hipGetDeviceCount(&visible);
+    int visible = 0;                     // logical devices (option debug.virtual_devices, common.h)
+    hipError_t e = bpmf::device_counts(&visible, nullptr);
     if (e != hipSuccess || visible < 1) {
         set_error("%s: no HIP device visible (%s)", who, hipGetErrorString(e));
         return -2;
@@ -102,8 +105,13 @@ std::vector<size_t> block_bounds(size_t n, size_t parts)
 // threads -- the per-device context of context.h would serialise them anyway); a single device
 // runs on the caller's thread.  The error text of a failing block is thread-local to its thread,
 // so it is carried back and re-raised on the caller's thread.
+//
+// `share_data`: the blocks all read the same day of data from the host; with more than one distinct
+// device (and option multi.peer_fanout) the first device uploads it and the others copy it device ->
+// device (DataFanout, context.h) -- the first block of every distinct device takes part, fn(i) of those
+// blocks runs with the role armed for the host-pointer call it makes.
 template <typename Fn>
-int run_blocks(const std::vector<int>& dev, Fn fn)
+int run_blocks(const std::vector<int>& dev, Fn fn, bool share_data = false)
 {
     const size_t n_blocks = dev.size();
     std::vector<int> rc(n_blocks, 0);
@@ -120,8 +128,15 @@ int run_blocks(const std::vector<int>& dev, Fn fn)
     // Nothing may leave a worker as an exception (an exception that escapes a std::thread, or one thrown
     // while joinable threads are alive, ends the process with std::terminate); a failure stays visible
     // as status -3 with its text.
+    std::unique_lock<std::mutex> fan_lock(bpmf::g_fanout_mutex, std::defer_lock);
+    std::unique_ptr<bpmf::DataFanout> fan;
+    if (share_data && distinct.size() > 1 && bpmf::option(bpmf::OPT_MULTI_PEER_FANOUT) != 0 && fan_lock.try_lock())
+        fan.reset(new bpmf::DataFanout((int)distinct.size() - 1));
     auto work = [&](size_t q) {
         for (size_t i : blocks_of[q]) {
+            const bool first = i == blocks_of[q][0];
+            bpmf::FanoutArm arm(fan.get(), !first ? bpmf::DataFanout::NONE
+                                                  : (q == 0 ? bpmf::DataFanout::SOURCE : bpmf::DataFanout::PEER));
             try {
                 rc[i] = fn(i);
                 if (rc[i]) msg[i] = bpmf_last_error();
@@ -144,7 +159,10 @@ int run_blocks(const std::vector<int>& dev, Fn fn)
             try {
                 th.emplace_back(work, q);
             } catch (const std::system_error&) {
-                work(q);           // no thread to be had (process / cgroup limit): this device runs here
+                // no thread to be had (process / cgroup limit): this device runs here, BEFORE the first device --
+                // nobody may wait for a hand-over from it
+                if (fan) fan->cancel();
+                work(q);
             }
         }
         work(0);                   // the first device on the caller's thread
@@ -181,7 +199,7 @@ extern "C" int bpmf_mf_run_multi(const float* templates, const int32_t* moveouts
         return bpmf_mf_run(templates + t0 * n_ch * L, moveouts + t0 * n_ch, weights + t0 * n_ch, data,
                            step, L, N, nt, S, C, n_corr, network_sum, flags, dev[i],
                            cc_out + t0 * row);
-    });
+    }, true);
 }
 
 // The split bpmf_mf_run_multi applies, for callers and tests: bounds_out[0 .. n_blocks] (no device needed).
@@ -220,7 +238,7 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
             if (nk == 0) return 0;
             return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S,
                                C, P, out_of_bounds, reduce, dev[i], beam_out + k0 * N, nullptr);
-        });
+        }, true);
     }
     if (dev.size() == 1)   // (through run_blocks: its exception barrier)
         return run_blocks(dev, [&](size_t) -> int {
@@ -244,7 +262,7 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
         return bpmf_bp_run(features, moveouts + k0 * S * P, w_phases, w_sources + k0 * S, N, nk, S, C,
                            P, out_of_bounds, reduce, dev[i], i ? pb[i].data() : beam_out,
                            i ? pa[i].data() : arg_out);
-    });
+    }, true);
     if (rc) return rc;
     // Ascending source blocks and a strict >: block 0 carries the (0, source 0) starting point of
     // the sequential scan, and a later block only replaces a value it beats.

@@ -57,6 +57,8 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.boundary_prio", 1, 0, 3, false},      // issue priority (s_setprio) of a wave of the L <= 257 kernel while it is outside its K loop (0: none; 1 measured +1.0-1.3 % at every L, 2 / 3 the same)
     {"mf.fused_prologue", 1, 0, 1, false},     // small problems (fewer than 4 tiles per wave, <= 256 channels): template norms, channel records and lag range computed by every workgroup of the L <= 257 kernel itself -- one launch per call instead of two
     {"debug.poison_output", 0, 0, 1, false},   // tests: fill the (max-beam, arg-max) / CC-sum output with 0xFF bytes (NaN / -1) before the kernels run -- a sample no kernel writes then shows
+    {"debug.virtual_devices", 0, 0, 64, false}, // tests: k > 0 = the library sees k logical devices, logical d on physical GPU d % visible, each with its own context and host thread (common.h)
+    {"multi.peer_fanout", 1, 0, 1, false},     // *_run_multi on several devices: the day of data goes to the first device once (host -> device) and from there to the others device -> device (hipMemcpyPeerAsync); 0 = every device uploads from the host itself
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))
@@ -83,6 +85,27 @@ long option(Option which)
 {
     std::call_once(g_options_once, init_options);
     return g_options[which].load(std::memory_order_relaxed);
+}
+
+thread_local int t_logical_device = -1;
+
+hipError_t device_counts(int* n_logical, int* n_physical)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    const long v = option(OPT_DEBUG_VIRTUAL_DEVICES);
+    if (n_physical) *n_physical = n;
+    if (n_logical) *n_logical = (v > 0 && n > 0) ? (int)v : n;
+    return e;
+}
+
+int physical_device(int logical)
+{
+    if (logical < 0 || option(OPT_DEBUG_VIRTUAL_DEVICES) <= 0) return logical;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return logical;
+    return logical % n;
 }
 }  // namespace bpmf
 
@@ -131,7 +154,8 @@ namespace bpmf {
 constexpr int PROFILE_MAX_LAUNCHES = 512;
 struct ProfilePair {
     hipEvent_t ev[2] = {nullptr, nullptr};
-    int device = -1;
+    int device = -1;          // physical GPU the events live on
+    int logical = -1;         // logical device of the launch (common.h), what bpmf_profile_get_device reports
     bool closed = false;      // stop edge recorded
 };
 struct ProfileLog {
@@ -170,6 +194,7 @@ void profile_mark(int which, int edge, hipStream_t stream)
             pr.device = device;
         }
         pr.closed = false;
+        pr.logical = t_logical_device >= 0 ? t_logical_device : device;
         if (hipEventRecord(pr.ev[0], stream) != hipSuccess) { lg.spare.push_back(pr); return; }
         lg.rec.push_back(pr);
         t_open_slot[which] = (int)lg.rec.size() - 1;
@@ -228,7 +253,7 @@ extern "C" int bpmf_profile_get_device(int which, int index)
     if (which < 0 || which >= BPMF_KERNEL_COUNT || index < 0 ||
         (size_t)index >= bpmf::g_log[which].rec.size())
         return -1;
-    return bpmf::g_log[which].rec[index].device;
+    return bpmf::g_log[which].rec[index].logical;
 }
 
 extern "C" const char* bpmf_last_error(void) { return bpmf::last_error_buf(); }
@@ -237,7 +262,7 @@ extern "C" const char* bpmf_last_error(void) { return bpmf::last_error_buf(); }
 extern "C" int bpmf_device_count(void)
 {
     int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
+    hipError_t e = bpmf::device_counts(&n, nullptr);      // logical devices (option debug.virtual_devices)
     if (e != hipSuccess) {
         bpmf::set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
         return -2;
@@ -249,7 +274,7 @@ extern "C" int bpmf_device_info(int device, char* name, size_t name_len, size_t*
                                 int* compute_units)
 {
     hipDeviceProp_t prop;
-    BPMF_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    BPMF_HIP_CHECK(hipGetDeviceProperties(&prop, bpmf::physical_device(device)));
     if (name && name_len) {
         strncpy(name, prop.name, name_len - 1);
         name[name_len - 1] = 0;

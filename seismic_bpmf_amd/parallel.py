@@ -104,19 +104,74 @@ def allgather_records(records, count, group=None):
     return [b[: int(c.item())] for b, c in zip(bufs, counts)]
 
 
+def allgather_varlen(records, group=None):
+    """All-gather of per-rank record lists of DIFFERENT lengths: records (n_r, width) on rank r ->
+    the list of every rank's records, on every rank.  The buffer is sized by an all-reduce(MAX) of the
+    counts (nothing is dropped, nothing is sized by a guess); KBs on the wire -- the "RCCL all-gather of
+    CC peaks" of BASELINE configs[3]."""
+    import torch.distributed as dist
+    n = int(records.shape[0])
+    kmax = torch.tensor([n], dtype=torch.int64, device=records.device)
+    dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=group)
+    cap = max(1, int(kmax.item()))
+    buf = torch.zeros((cap,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+    if n:
+        buf[:n] = records
+    return allgather_records(buf, n, group=group)
+
+
+def broadcast_day(array, src, device, group=None):
+    """The day of data / features, replicated ONCE over the group's fabric (RCCL over xGMI; gloo in the CPU
+    tests): rank `src` passes the (S, C, N) float32 array (NumPy or tensor, host or device) and uploads
+    it; every other rank passes None, allocates the same shape on `device` and receives it -- its host
+    never reads the day, where N ranks each pulling 2-4 GB through pageable host memory would contend for
+    the same few CPU cores ("broadcast once per day").  Returns the tensor on `device`."""
+    import numpy as np
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    gsrc = src if group is None else dist.get_global_rank(group, src)
+    shape = torch.zeros(4, dtype=torch.int64, device=device)
+    t = None
+    if rank == src:
+        if array is None:
+            raise ValueError(f"rank {src} is the source of the broadcast and must pass the array")
+        t = array if isinstance(array, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32))
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+        if t.dim() != 3:
+            raise ValueError("the day must be (S, C, N)")
+        shape[:3] = torch.tensor(t.shape, dtype=torch.int64)
+        shape[3] = 1
+    dist.broadcast(shape, src=gsrc, group=group)
+    if rank != src:
+        t = torch.empty(tuple(int(x) for x in shape[:3].tolist()), dtype=torch.float32, device=device)
+    dist.broadcast(t, src=gsrc, group=group)
+    return t
+
+
 class ShardedBeamformer:
     """Backprojection with the source grid tiled across the ranks of a process group."""
 
-    def __init__(self, moveouts, weights_sources, group=None, device=None):
+    def __init__(self, moveouts, weights_sources, group=None, device=None, local_factory=None):
+        """`local_factory(moveouts_block, weights_block, source_id_offset)`: the per-rank engine (run /
+        close like BeamformerGPU); None = a BeamformerGPU on `device`.  (The CPU tests of the exchange
+        pass an oracle-backed stand-in.)"""
         import torch.distributed as dist
-        from .beampower import BeamformerGPU
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.K = moveouts.shape[0]
         self.k0, self.k1 = shard_bounds(self.K, self.world)[self.rank]
-        self.local = BeamformerGPU(moveouts[self.k0:self.k1], weights_sources[self.k0:self.k1],
-                                   device=device, source_id_offset=self.k0)
+        if local_factory is None:
+            from .beampower import BeamformerGPU
+            self.local = BeamformerGPU(moveouts[self.k0:self.k1], weights_sources[self.k0:self.k1],
+                                       device=device, source_id_offset=self.k0)
+        else:
+            self.local = local_factory(moveouts[self.k0:self.k1], weights_sources[self.k0:self.k1], self.k0)
+
+    def broadcast_features(self, features, src=0):
+        """The day of features from rank `src` to every rank (broadcast_day); returns this rank's tensor."""
+        dev = getattr(self.local, "device", torch.device("cpu"))
+        return broadcast_day(features, src, dev, self.group)
 
     def run(self, features, weights_phases, reduce="max", out_of_bounds="strict"):
         if reduce == "none":
@@ -148,6 +203,15 @@ class ShardedMatchedFilter:
 
     def set_data(self, data):
         self.local.set_data(data)
+
+    def record_device(self):
+        """Where this rank's records live for the all-gather (the engine's GPU over RCCL, the host over gloo)."""
+        return getattr(self.local, "device", torch.device("cpu"))
+
+    def set_data_broadcast(self, data, src=0):
+        """`data` on rank `src` only (None elsewhere): uploaded there, broadcast over the group, adopted
+        by every rank's engine without a host copy (broadcast_day)."""
+        self.local.set_data(broadcast_day(data, src, self.record_device(), self.group))
 
     def template_range(self, n_templates, weights=None):
         """This rank's block of templates: equal counts, or -- given the (T, S, C) weights -- equal

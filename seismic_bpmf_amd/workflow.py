@@ -96,6 +96,30 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     mf = MatchedFilterGPU(device=device)
     mf.set_data(data)
     cc = mf.run(templates, moveouts, weights, step)
+    out = cc_detections(cc, moveouts, weights, step=step, sr=sr, threshold_window_dur=threshold_window_dur,
+                        minimum_interevent_time=minimum_interevent_time, n_dev=n_dev, overlap=overlap,
+                        max_cc_threshold=max_cc_threshold, white_noise=white_noise, device=device,
+                        remove_edges=remove_edges, data_buffer_sec=data_buffer_sec,
+                        data_duration_sec=data_duration_sec, sanity_check=sanity_check, max_kurto=max_kurto,
+                        threshold_type=threshold_type)
+    return out, cc
+
+
+def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, minimum_interevent_time,
+                  n_dev=8.0, overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
+                  remove_edges=True, data_buffer_sec=None, data_duration_sec=None, sanity_check=True,
+                  max_kurto=100.0, threshold_type="rms", with_values=False):
+    """The detection stage of matched_filter_detections on a (T, n_corr) CC matrix that already lies in
+    HBM (``MatchedFilter.find_detections``, BPMF/similarity_search.py:548-666): NaN scrub, threshold and
+    candidates on the device, the reference's pair-wise merge, kurtosis sanity check, edge removal.
+    `moveouts` / `weights` are those of the rows of `cc`.  Returns {row: cc indices}; with
+    `with_values` {row: (cc indices, cc values float32, threshold values float32)}."""
+    if remove_edges and data_buffer_sec is None:
+        raise ValueError("remove_edges=True needs data_buffer_sec (the reference trims cfg.DATA_BUFFER_SEC); "
+                         "pass remove_edges=False for a day without margins")
+    weights = np.asarray(weights, dtype=np.float32)
+    if device is None and hasattr(cc, "device"):
+        device = cc.device.index
     cc.nan_to_num_(nan=0.0)                                    # similarity_search.py:540
     th = ThresholdGPU(device=device)
     window = int(pp.sec_to_samp(threshold_window_dur, sr))
@@ -121,7 +145,8 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
     out = {}
     for t in range(weights.shape[0]):
         if rejected[t]:
-            out[t] = np.zeros(0, dtype=np.int64)
+            out[t] = (np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.float32)) if with_values \
+                else np.zeros(0, dtype=np.int64)
             continue
         mine = cand[cand["row"] == t]
         win = search_window(mv[t].reshape(mv.shape[1], -1), min_iet, step)
@@ -132,8 +157,128 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
             if data_duration_sec is not None:
                 samples = idx * step
                 idx = idx[samples < pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr)]
-        out[t] = idx
-    return out, cc
+        if with_values:
+            pos = np.searchsorted(mine["index"], idx)           # candidates come sorted by index within a row
+            out[t] = (idx, mine["cc"][pos].astype(np.float32), mine["threshold"][pos].astype(np.float32))
+        else:
+            out[t] = idx
+    return out
+
+
+# ------------------------------------------------------------------ one process per GPU ---
+RECORD_WIDTH = 4      # (global template id, cc index, float32 bits of cc, float32 bits of the threshold) as int64
+
+
+def detections_to_records(detections, t_offset=0):
+    """{row: (indices, cc, threshold)} -> (n, 4) int64 NumPy records with GLOBAL template ids."""
+    rows = []
+    for t in sorted(detections):
+        idx, val, thr = detections[t]
+        if len(idx) == 0:
+            continue
+        r = np.empty((len(idx), RECORD_WIDTH), dtype=np.int64)
+        r[:, 0] = t + t_offset
+        r[:, 1] = idx
+        r[:, 2] = np.asarray(val, dtype=np.float32).view(np.int32)
+        r[:, 3] = np.asarray(thr, dtype=np.float32).view(np.int32)
+        rows.append(r)
+    return np.concatenate(rows) if rows else np.zeros((0, RECORD_WIDTH), dtype=np.int64)
+
+
+def records_to_detections(records, n_templates):
+    """(n, 4) int64 records -> {template: (indices int64, cc float32, threshold float32)} for every template."""
+    records = np.asarray(records, dtype=np.int64).reshape(-1, RECORD_WIDTH)
+    order = np.lexsort((records[:, 1], records[:, 0]))
+    records = records[order]
+    out = {}
+    for t in range(n_templates):
+        mine = records[records[:, 0] == t]
+        out[t] = (mine[:, 1].copy(), mine[:, 2].astype(np.int32).view(np.float32),
+                  mine[:, 3].astype(np.int32).view(np.float32))
+    return out
+
+
+def sharded_matched_filter_detections(templates, moveouts, weights, data, *, group=None, device=None,
+                                      engine=None, detector=None, data_src=None, balance=True, step=1,
+                                      **detection_kwargs):
+    """Matched-filter search of one day on ALL ranks of a torch.distributed group (one process per GPU):
+    what ``MatchedFilter.run_matched_filter_search`` (BPMF/similarity_search.py:726-807) does with its
+    sequential template chunks, the chunks being the ranks' shards here.
+
+    Every rank passes the SAME templates / moveouts / weights (all T of them).  `data`: the (S, C, N) day on
+    every rank, or -- with `data_src=r` -- on rank r only (None elsewhere): rank r uploads it and
+    broadcasts it over RCCL / xGMI, the host of the other ranks never touches it (SURVEY.md section 8e:
+    "broadcast once per day").  Rank r computes the CC of its block of templates (balanced by weighted
+    channels), thresholds it and selects its detections on its own GPU (cc_detections); the (template,
+    index, cc, threshold) records -- a few KB -- are all-gathered; the CC matrix never leaves the GPU
+    that made it.  `detection_kwargs` are cc_detections' (sr, threshold_window_dur, ...).
+
+    Returns (detections, info): detections = {global template id: (cc indices, cc, threshold)} for ALL
+    templates, identical on every rank and equal to what matched_filter_detections(..., with values)
+    finds in one process; info = {"templates": (t0, t1), "cc": this rank's CC tensor or None,
+    "records_gathered": n, "broadcast_ms": float or None}.
+
+    `engine` / `detector`: stand-ins for the per-rank MatchedFilterGPU and for cc_detections (the CPU tests
+    of the choreography over gloo pass oracle-backed ones); None = the HIP path."""
+    import time
+    import torch
+    from . import parallel
+    smf = parallel.ShardedMatchedFilter(group=group, device=device, local=engine)
+    t_b = None
+    if data_src is None:
+        smf.set_data(data)
+    else:
+        t0c = time.perf_counter()
+        smf.set_data_broadcast(data, src=data_src)
+        t_b = (time.perf_counter() - t0c) * 1e3
+    weights = np.asarray(weights, dtype=np.float32)
+    T = weights.shape[0]
+    t0, t1, cc = smf.run(templates, moveouts, weights, step, True, balance=balance)
+    if cc is None:
+        mine = {}
+    elif detector is not None:
+        mine = detector(cc, np.asarray(moveouts)[t0:t1], weights[t0:t1], step=step, **detection_kwargs)
+    else:
+        mine = cc_detections(cc, np.asarray(moveouts)[t0:t1], weights[t0:t1], step=step, device=device,
+                             with_values=True, **detection_kwargs)
+    rec = detections_to_records(mine, t_offset=t0)
+    rec_dev = smf.record_device()
+    parts = parallel.allgather_varlen(torch.as_tensor(rec, device=rec_dev), group=group)
+    everything = np.concatenate([p.cpu().numpy() for p in parts]) if parts else rec
+    info = {"templates": (t0, t1), "cc": cc, "records_gathered": int(everything.shape[0]), "broadcast_ms": t_b}
+    return records_to_detections(everything, T), info
+
+
+def sharded_backprojection_detections(features, moveouts, weights_phases, weights_sources, *, sr,
+                                      minimum_interevent_time, threshold_window_dur=None, n_dev=15.0,
+                                      overlap=0.75, threshold=None, out_of_bounds="strict", group=None,
+                                      device=None, engine_factory=None, detector=None, features_src=None):
+    """Backprojection of one day with the source grid tiled over the ranks of a group: every rank scans
+    its block of sources (global ids) against the whole day of features, ONE all-reduce(MAX) of packed
+    (beam, id) keys leaves the global max-beam and arg-max on every rank (ties -> the lowest source id,
+    as one sequential scan), and every rank runs the (3 ms) detection stage on them.  Mirrors
+    ``Beamformer.backproject`` + ``find_detections`` (BPMF/template_search.py:508-627).
+
+    `features`: the (S, C, N) day on every rank, or with `features_src=r` on rank r only (broadcast over
+    the group).  Returns (peak samples, source indices, maxbeam, argmax) -- the tensors of
+    backprojection_detections(return_device=True) -- identical on every rank.
+    `engine_factory(moveouts_block, weights_block, source_id_offset)` / `detector(beam, arg)`: CPU
+    stand-ins for BeamformerGPU / beam_detections_device in the gloo tests."""
+    from . import parallel
+    sb = parallel.ShardedBeamformer(moveouts, weights_sources, group=group, device=device,
+                                    local_factory=engine_factory)
+    if features_src is not None:
+        features = sb.broadcast_features(features, src=features_src)
+    beam, arg = sb.run(features, weights_phases, "max", out_of_bounds)
+    mpd = int(pp.sec_to_samp(minimum_interevent_time, sr))
+    if detector is not None:
+        peaks, peak_sources = detector(beam, arg)
+    else:
+        window = None if threshold is not None else int(pp.sec_to_samp(threshold_window_dur, sr))
+        peaks, peak_sources, _ = beam_detections_device(beam, arg, mpd=mpd, threshold=threshold, window=window,
+                                                       n_dev=n_dev, overlap=overlap, device=device)
+    sb.close()
+    return peaks, peak_sources, beam, arg
 
 
 def beam_detections_device(beam, arg, *, mpd, threshold=None, window=None, n_dev=15.0, overlap=0.75,

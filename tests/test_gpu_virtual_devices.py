@@ -1,0 +1,163 @@
+"""The multi-device branches of bpmf_*_run_multi on a box with ONE GPU (option debug.virtual_devices).
+
+`debug.virtual_devices = k` makes the library see k logical devices, each with its own DeviceContext
+(streams, working set, call mutex) and -- in the *_run_multi entry points -- its own host thread, all of
+them living on the physical GPU(s) that exist (csrc/common.h).  What this reaches that no earlier round
+executed on hardware: `run_blocks` with more than one distinct device (csrc/multi.hip: one std::thread per
+device), the hand-over of the day of data from the first device to the others (DataFanout, csrc/context.h:
+hipMemcpyPeerAsync behind the source's event), the threaded host merge of the per-device beam maxima with
+its global source ids and cross-block ties, `bp.compat_first_computed` across device blocks, and the
+profile log with several threads inside the library at once.  Every result is compared bit for bit with
+the single-device call of the same inputs and with the CPU oracle.
+
+Reference behaviour mirrored: the third-party GPU back-ends split templates / sources over the visible
+devices inside one call (BPMF/similarity_search.py:526-533, BPMF/template_search.py:549-558).
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mf_case(rng, T=11, S=3, C=2, L=64, N=40_000):
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    mv = rng.integers(-40, 300, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[rng.random((T, S, C)) < 0.25] = 0.0
+    w[2] = 0.0                                   # a template without a weighted channel
+    return tp, mv, w, d
+
+
+def _bp_case(rng, K=240, S=6, N=30_000, ties=True):
+    # small-integer features and weights: sums are exact, so equal beams (ties) across blocks are common
+    f = np.round(np.abs(rng.standard_normal((S, 2, N))) * 2).astype(np.float32)
+    tau = rng.integers(0, 200, (K, S, 2)).astype(np.int32)
+    wp = np.zeros((S, 2, 2), np.float32)
+    wp[:, 0, 0] = 1.0
+    wp[:, 1, 1] = 1.0
+    ws = (rng.random((K, S)) < 0.7).astype(np.float32)
+    if ties:                                     # identical sources in different device blocks
+        tau[K // 2 + 3] = tau[5]
+        ws[K // 2 + 3] = ws[5]
+        tau[K - 2] = tau[1]
+        ws[K - 2] = ws[1]
+    return f, tau, wp, ws
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("fanout", [1, 0])
+def test_mf_on_k_virtual_devices_equals_one_device(oracle_lib, hip_opts, k, fanout):
+    from seismic_bpmf_amd import _lib, matched_filter
+    rng = np.random.default_rng(100 + k)
+    tp, mv, w, d = _mf_case(rng)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1)
+    one = matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert np.array_equal(one, want)
+    hip_opts("debug.virtual_devices", k)
+    hip_opts("multi.peer_fanout", fanout)
+    assert _lib.device_count() == k
+    multi = matched_filter(tp, mv, w, d, 1, arch="gpu", device=None, check_zeros=False)   # all k devices
+    assert np.array_equal(multi, one)
+    # per-channel output, a device list in another order with a repeated device, a step
+    per_ch = matched_filter(tp, mv, w, d, 3, arch="gpu", device=[k - 1, 0, k - 1], network_sum=False)
+    assert np.array_equal(per_ch, oracle_lib.matched_filter(tp, mv, w, d, 3, network_sum=False))
+    # every logical device kept its own working set
+    held = [_lib.device_memory_held(dv)[0] for dv in range(k)]
+    assert all(h > 0 for h in held), held
+    _lib.release_device_memory(-1)
+    assert _lib.device_memory_held(-1) == (0, 0)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("oob", ["strict", "flexible"])
+def test_bp_max_on_k_virtual_devices_equals_one_device(oracle_lib, hip_opts, k, oob):
+    from seismic_bpmf_amd import beamform
+    rng = np.random.default_rng(200 + k)
+    f, tau, wp, ws = _bp_case(rng)
+    wb, wa = oracle_lib.beamform(f, tau, wp, ws, oob, "max")
+    hip_opts("debug.virtual_devices", k)
+    mb, ma = beamform(f, tau, wp, ws, device="gpu", out_of_bounds=oob, device_id=None)
+    assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+    # ties across blocks really occurred: the duplicated sources never win over their lower-id twins
+    assert not np.isin(ma, [len(ws) // 2 + 3, len(ws) - 2]).any()
+    # reduce="none": every device fills its own rows
+    beam = beamform(f[:, :, :3000], tau, wp, ws, device="gpu", out_of_bounds=oob, reduce="none",
+                    device_id=list(range(k)))
+    assert np.array_equal(beam, oracle_lib.beamform(f[:, :, :3000], tau, wp, ws, oob, "none"))
+
+
+@pytest.mark.parametrize("k", [2, 8])
+def test_bp_first_computed_across_virtual_device_blocks(oracle_lib, hip_opts, k):
+    """bp.compat_first_computed with every beam negative: the running max must start from the first
+    COMPUTED beam of the whole grid, whichever device block holds it."""
+    from seismic_bpmf_amd import beamform
+    rng = np.random.default_rng(300 + k)
+    f, tau, wp, ws = _bp_case(rng, K=96, N=12_000, ties=False)
+    f = -f - 1.0
+    tau[:40] += 11_900                    # the first blocks compute (strict) almost nothing
+    hip_opts("debug.virtual_devices", k)
+    hip_opts("bp.compat_first_computed", 1)
+    with oracle_lib.compat(oracle_lib.COMPAT_FIRST_COMPUTED):
+        wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    mb, ma = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="strict", device_id=None)
+    assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+    assert (wb < 0).any()
+
+
+def test_profile_log_with_one_thread_per_virtual_device(hip_opts):
+    from seismic_bpmf_amd import _lib, beamform, matched_filter
+    rng = np.random.default_rng(8)
+    f, tau, wp, ws = _bp_case(rng, K=160, N=40_000)
+    tp, mv, w, d = _mf_case(rng, T=8)
+    w[2] = 1.0
+    hip_opts("debug.virtual_devices", 4)
+    _lib.profile_enable(True)
+    try:
+        beamform(f, tau, wp, ws, device="gpu", device_id=None)
+        matched_filter(tp, mv, w, d, 1, arch="gpu", device=None, check_zeros=False)
+        for which in (_lib.KERNEL_BP_BEAM, _lib.KERNEL_MF_MAIN):
+            ms = _lib.profile_times_ms(which)
+            assert len(ms) == 4 and all(0 < m < 1000 for m in ms), ms
+            assert sorted(_lib.profile_devices(which)) == [0, 1, 2, 3]
+    finally:
+        _lib.profile_enable(False)
+
+
+def test_concurrent_multi_device_calls_on_virtual_devices(oracle_lib, hip_opts):
+    """Six Python threads, each in a loop of multi-device calls over 4 logical devices in different
+    orders: only one call at a time hands its data from device to device (the others upload from the
+    host), nobody waits for anybody in a cycle, every result is bit-exact."""
+    from seismic_bpmf_amd import beamform, matched_filter
+    hip_opts("debug.virtual_devices", 4)
+    rng = np.random.default_rng(55)
+    jobs = []
+    for j in range(6):
+        tp, mv, w, d = _mf_case(rng, T=6 + j, N=8_000 + 512 * j)
+        f, tau, wp, ws = _bp_case(rng, K=64 + 16 * j, N=6_000 + 100 * j, ties=False)
+        order = list(rng.permutation(4))
+        jobs.append((tp, mv, w, d, f, tau, wp, ws, [int(x) for x in order],
+                     oracle_lib.matched_filter(tp, mv, w, d, 1), oracle_lib.beamform(f, tau, wp, ws, "strict", "max")))
+
+    def one(job):
+        tp, mv, w, d, f, tau, wp, ws, order, wcc, (wmb, wma) = job
+        for _ in range(5):
+            cc = matched_filter(tp, mv, w, d, 1, arch="gpu", device=order, check_zeros=False)
+            mb, ma = beamform(f, tau, wp, ws, device="gpu", device_id=order[::-1])
+            if not (np.array_equal(cc, wcc) and np.array_equal(mb, wmb) and np.array_equal(ma, wma)):
+                return False
+        return True
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        assert all(pool.map(one, jobs))
+
+
+def test_virtual_device_out_of_range_is_an_error(hip_opts):
+    from seismic_bpmf_amd import _lib, matched_filter
+    rng = np.random.default_rng(1)
+    tp, mv, w, d = _mf_case(rng, T=3, N=4_000)
+    hip_opts("debug.virtual_devices", 2)
+    with pytest.raises(_lib.BpmfHipError, match="out of range"):
+        matched_filter(tp, mv, w, d, 1, arch="gpu", device=[0, 2], check_zeros=False)
