@@ -389,71 +389,49 @@ def cpu_baseline_bp(bcfg, geo, target_seconds):
 
 
 # ------------------------------------------------------- detection stage (untimed extra) ---
-def detection_stage(cc, planted, local_rank, dist, device, t_offset=0):
-    """What follows the hot path in BPMF (similarity_search.py:620-666), on the CC matrix that is
-    still in HBM: RMS threshold on device, candidates above it, host merge, and -- for N > 1 -- the
-    all-gather of the per-rank peak records (the path's only inter-GPU traffic).  Reported beside
-    the headline numbers, never inside the timed region.  Also a full-size correctness check: every
-    planted event must be detected at exactly its planted CC index."""
-    from seismic_bpmf_amd import parallel, postprocess as pp
-    from seismic_bpmf_amd.threshold import ThresholdGPU
-    th = ThresholdGPU(device=local_rank)
-    window, overlap = 180_000, 0.25                       # 30 min @ 100 Hz
-    window = min(window, max(1000, cc.shape[1] // 8))     # short series (configs[0]): 8 windows
+def detection_stage(cc, planted, mv, w, local_rank, dist, device, t_offset=0):
+    """What follows the hot path in BPMF (similarity_search.py:548-666), on the CC matrix that is still in
+    HBM, through the PRODUCT's own functions: workflow.cc_detections (RMS threshold on the device,
+    candidates above it, the reference's pair-wise merge on the host) and -- for N > 1 --
+    workflow.detections_to_records + parallel.allgather_varlen, the all-gather of the per-rank peak
+    records that is the path's only inter-GPU traffic (the same calls
+    workflow.sharded_matched_filter_detections makes).  Reported beside the headline numbers, never
+    inside the timed region.  Also a full-size correctness check: every planted event must be detected
+    at exactly its planted CC index."""
+    from seismic_bpmf_amd import parallel, workflow
+    n_corr = cc.shape[1]
+    sr = 100.0
+    window_s = min(1800.0, max(10.0, n_corr / 8 / sr))     # 30 min; short series (configs[0]): 8 windows
     wn = np.random.default_rng(5).standard_normal(500).astype(np.float32)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    thr_win, _ = th.time_dependent_threshold(cc, window, 8.0, overlap=overlap, white_noise=wn)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    cand = th.extract_candidates(cc, thr_win, window, overlap=overlap)
-    t2 = time.perf_counter()
-    found = exact = 0
-    n_det = 0
-    merged = []                                 # (template, cc index, cc bits, threshold bits)
+    tm = {}
+    det = workflow.cc_detections(cc, mv.cpu().numpy(), w.cpu().numpy(), step=1, sr=sr, threshold_window_dur=window_s,
+                                 minimum_interevent_time=5.12, n_dev=8.0, overlap=0.25, white_noise=wn,
+                                 device=local_rank, remove_edges=False, sanity_check=False, with_values=True,
+                                 timings=tm)
+    found = exact = n_det = 0
     for t in range(planted.shape[0]):
-        mine = cand[cand["row"] == t]
-        idx = list(mine["index"])
-        val = list(mine["cc"])
-        thr_v = list(mine["threshold"])
-        q = 1                                   # pair-wise merge, similarity_search.py:240-251
-        while q < len(idx):
-            if idx[q] - idx[q - 1] < 512:
-                drop = q - 1 if val[q] > val[q - 1] else q
-                del idx[drop], val[drop], thr_v[drop]
-            else:
-                q += 1
+        idx = det[t][0]
         n_det += len(idx)
-        exact += len(set(idx) & set(planted[t].tolist()))
+        exact += len(set(idx.tolist()) & set(planted[t].tolist()))
         found += planted.shape[1]
-        merged.extend((t_offset + t, i, v, h) for i, v, h in zip(idx, val, thr_v))
-    out = {"threshold_ms": round((t1 - t0) * 1e3, 1), "candidates_ms": round((t2 - t1) * 1e3, 1),
-           "candidates": int(cand.size), "detections": n_det, "planted": found,
-           "planted_found_at_exact_index": exact}
+    out = {"threshold_ms": round(tm["threshold_ms"], 1), "candidates_ms": round(tm["candidates_ms"], 1),
+           "host_merge_ms": round(tm["merge_ms"], 1), "candidates": tm["candidates"], "detections": n_det,
+           "planted": found, "planted_found_at_exact_index": exact,
+           "through": "workflow.cc_detections (sanity_check off: the kurtosis pass is timed in profiles/)"}
     if dist is not None:
         # "RCCL all-gather of CC peaks" (BASELINE configs[3]): every rank contributes its MERGED
-        # detections (global template id, CC index, cc, threshold) -- a few thousand 16-byte records,
+        # detections (global template id, CC index, cc, threshold) -- a few thousand 32-byte records,
         # never the CC matrix.  The buffer is sized by the largest rank's count, nothing is dropped.
-        from seismic_bpmf_amd.threshold import candidate_dtype
-        mine = np.zeros(len(merged), dtype=candidate_dtype)
-        for q, (tid, i, v, h) in enumerate(merged):
-            mine[q] = (tid, i, v, h)
-        k = int(mine.size)
-        kmax = torch.tensor([k], dtype=torch.int64, device=device)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        cap = max(1, int(kmax.item()))
-        rec = torch.zeros((cap, 4), dtype=torch.int32, device=device)
-        if k:
-            rec[:k] = torch.as_tensor(mine.view(np.int32).reshape(-1, 4), device=device)
+        mine = workflow.detections_to_records(det, t_offset=t_offset)
+        rec = torch.as_tensor(mine, device=device)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        parts = parallel.allgather_records(rec, k)
+        parts = parallel.allgather_varlen(rec)
         torch.cuda.synchronize()
         out["allgather_records_ms"] = round((time.perf_counter() - t3) * 1e3, 2)
         out["records_all_ranks"] = int(sum(len(p) for p in parts))
-        out["records_capacity_per_rank"] = cap
-        mine_back = parts[dist.get_rank()].cpu().numpy().view(candidate_dtype).reshape(-1)
-        out["own_records_round_trip_exact"] = bool(np.array_equal(mine_back, mine))
+        out["records_this_rank"] = int(mine.shape[0])
+        out["own_records_round_trip_exact"] = bool(np.array_equal(parts[dist.get_rank()].cpu().numpy(), mine))
     return out
 
 
@@ -609,7 +587,7 @@ def main():
                 "hbm_frac_informational": round(
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     peak = float(cc[0].max().item())
-    detect = detection_stage(cc, planted, local_rank, dist, device, t_offset=rank * T)
+    detect = detection_stage(cc, planted, mv, w, local_rank, dist, device, t_offset=rank * T)
     # untimed extra: the same step under option mf.compat_sqrt_norm (cc = num / sqrtf(E_t * E_d) in the
     # epilogue of the MFMA kernel: an IEEE square root and divide per channel and lag)
     compat = None
@@ -870,6 +848,28 @@ def main():
         c4 = dict(syn.MF_CONFIGS["cfg4_per_gpu"])
         T4, S4, C4, L4, N4 = c4["T"], c4["S"], c4["C"], c4["L"], c4["N"]
         tmpl4, mv4, w4, data4, _ = mf_inputs_device(c4, device, 20260931, rank)
+        # replication of the day (SURVEY.md 8e "broadcast once per day"): configs[3]'s 4.15 GB of data in
+        # pageable host memory on rank 0 only -> upload there -> broadcast over RCCL / xGMI
+        # (parallel.broadcast_day, what workflow.sharded_matched_filter_detections(data_src=0) does); the
+        # other ranks' hosts never touch it.  Every rank's bit-pattern checksum of what it received is compared with rank 0's own.
+        from seismic_bpmf_amd import parallel
+        host4 = data4.cpu().numpy() if rank == 0 else None
+        barrier()
+        t0 = time.perf_counter()
+        got4 = parallel.broadcast_day(host4, 0, device)
+        barrier()
+        bc_ms = (time.perf_counter() - t0) * 1e3
+        chk = got4.view(torch.int32).to(torch.int64).sum().reshape(1)      # bit-pattern checksum of what arrived
+        chks = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(chks, chk)
+        ref_chk = data4.view(torch.int32).to(torch.int64).sum().reshape(1) if rank == 0 else chk
+        shares["data_broadcast"] = {
+            "what": f"configs[3]'s day of data, {data4.numel() * 4 / 1e9:.2f} GB: pageable host memory of rank 0 -> HBM of rank 0 -> "
+                    f"dist.broadcast to {world} rank(s) (parallel.broadcast_day)",
+            "ms": round(bc_ms, 1), "GB_per_s_per_receiver": round(data4.numel() * 4 / 1e9 / (bc_ms * 1e-3), 1),
+            "every_rank_received_rank0s_bits": bool(all(int(c.item()) == int(ref_chk.item()) for c in chks))}
+        del got4, host4
+        torch.cuda.empty_cache()
         mf4 = sb.MatchedFilterGPU(device=local_rank)
         mf4.set_data(data4)
         cc4 = torch.empty((T4, N4 - L4 + 1), dtype=torch.float32, device=device)

@@ -85,8 +85,10 @@ int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_byt
  *   multi.peer_fanout (*_run_multi on several devices: 1 = the first device uploads the day of data from the
  *     host ONCE and the others copy it device -> device, hipMemcpyPeerAsync over xGMI; 0 = every device
  *     uploads from the host itself, which is what the upstream back-ends do)
- *   and the three result-changing upstream-compatibility switches (off by default):
- *   mf.compat_exclusive_last_lag mf.compat_sqrt_norm bp.compat_first_computed
+ *   and the result-changing upstream-compatibility switches (off by default; every one has
+ *   a variant of the CPU oracle and tools/diff_upstream.py tells which combination equals the real packages):
+ *   mf.compat_exclusive_last_lag mf.compat_sqrt_norm mf.compat_range_all_channels mf.compat_sequential_csum
+ *   bp.compat_first_computed bp.compat_strict_upper_only bp.compat_range_all_stations
  * (The reference's counterpart is the `device=` / `arch=` string it forwards to the third-party
  * back-ends, BPMF/similarity_search.py:532, BPMF/template_search.py:554.)
  * -1 for an unknown name or a value outside the option's range. */

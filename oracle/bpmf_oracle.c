@@ -61,7 +61,15 @@ void bpmf_oracle_last_phase_seconds(double *out4)
  * mf.compat_sqrt_norm, bp.compat_first_computed; all off by default): bit 0 -- the last valid data
  * offset is exclusive (i * step < N - L - mv_max); bit 1 -- cc = num / sqrtf(E_t * E_d) where
  * E_t * E_d > 1e-6, else 0; bit 2 -- the running maximum over the sources starts from the first
- * computed beam (any sign), samples without a computed beam return (0, 0). */
+ * computed beam (any sign), samples without a computed beam return (0, 0).
+ * Round 5, the conventions the round-4 review found without a switch: bit 3 (mf.compat_range_all_channels)
+ * -- the valid lag range of a template is taken over ALL its channels, weighted or not (a template
+ * without a weighted channel stays empty); bit 4 (mf.compat_sequential_csum) -- the double prefix sum of
+ * data^2 is ONE sequential chain over the trace instead of the 1024-sample hierarchy; bit 5
+ * (bp.compat_strict_upper_only) -- "strict" tests only t + tau_max < N; a used term in front of sample 0
+ * contributes nothing (it cannot occur with BPMF's moveouts, which are >= 0); bit 6
+ * (bp.compat_range_all_stations) -- tau_min / tau_max of a source are taken over ALL its stations,
+ * weighted or not. */
 static int g_compat = 0;
 void bpmf_oracle_set_compat(int flags) { g_compat = flags; }
 int bpmf_oracle_get_compat(void) { return g_compat; }
@@ -113,6 +121,20 @@ void mf_data_csum(const float *data, size_t n_channels, size_t N, double *csum)
     /* three passes, so that every thread has work whatever the channel count (the definition is
      * hierarchical precisely so that it can be evaluated this way): chunk totals, the sequential
      * scan of the totals per channel, then the chunk-local sums plus their offset */
+    if (g_compat & 16) {                          /* one sequential chain per channel */
+#pragma omp parallel for schedule(static)
+        for (size_t ch = 0; ch < n_channels; ch++) {
+            const float *d = data + ch * N;
+            double *cs = csum + ch * (N + 1);
+            double acc = 0.0;
+            cs[0] = 0.0;
+            for (size_t n = 0; n < N; n++) {
+                acc += (double)d[n] * (double)d[n];
+                cs[n + 1] = acc;
+            }
+        }
+        return;
+    }
     const size_t n_chunks = (N + BPMF_CSUM_CHUNK - 1) / BPMF_CSUM_CHUNK;
     double *off = (double *)malloc((n_channels * n_chunks + 1) * sizeof(double));
     if (!off) return;
@@ -191,12 +213,14 @@ static int mf_valid_range(const int32_t *mv, const float *w, size_t n_ch, size_t
                           size_t *i_last)
 {
     int64_t mv_min = 0, mv_max = 0;
-    int any = 0;
+    int any = 0, seen = 0;
+    const int all_channels = (g_compat & 8) != 0;
     for (size_t ch = 0; ch < n_ch; ch++) {
-        if (w[ch] == 0.0f) continue;
-        if (!any || mv[ch] < mv_min) mv_min = mv[ch];
-        if (!any || mv[ch] > mv_max) mv_max = mv[ch];
-        any = 1;
+        if (w[ch] != 0.0f) any = 1;
+        else if (!all_channels) continue;
+        if (!seen || mv[ch] < mv_min) mv_min = mv[ch];
+        if (!seen || mv[ch] > mv_max) mv_max = mv[ch];
+        seen = 1;
     }
     if (!any || N < L) return 0;
     int64_t first = 0;
@@ -402,15 +426,17 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
     bp_prestack(features, w_phases, N, S, C, P, U);
     /* per source: is any station used, and the extreme moveouts of the used terms */
     for (size_t k = 0; k < K; k++) {
-        int any = 0;
+        int any = 0, seen = 0;
         int64_t lo = 0, hi = 0;
+        const int all_stations = (g_compat & 64) != 0;
         for (size_t s = 0; s < S; s++) {
-            if (w_sources[k * S + s] == 0.0f) continue;
+            if (w_sources[k * S + s] != 0.0f) any = 1;
+            else if (!all_stations) continue;
             for (size_t p = 0; p < P; p++) {
                 int64_t tau = moveouts[(k * S + s) * P + p];
-                if (!any || tau < lo) lo = tau;
-                if (!any || tau > hi) hi = tau;
-                any = 1;
+                if (!seen || tau < lo) lo = tau;
+                if (!seen || tau > hi) hi = tau;
+                seen = 1;
             }
         }
         active[k] = (unsigned char)any;
@@ -424,6 +450,7 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
         const size_t t0 = tb * TB;
         const size_t t1 = t0 + TB < N ? t0 + TB : N;
         const int first_computed = (g_compat & 4) != 0;
+        const int upper_only = (g_compat & 32) != 0;
         float best[512];
         int32_t arg[512];
         for (size_t j = 0; j < t1 - t0; j++) { best[j] = first_computed ? -INFINITY : 0.0f; arg[j] = 0; }
@@ -433,7 +460,7 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
             for (size_t t = t0; t < t1; t++) {
                 int computed = active[k];
                 if (out_of_bounds == 0)
-                    computed = computed && ((int64_t)t + tmin[k] >= 0) &&
+                    computed = computed && (upper_only || (int64_t)t + tmin[k] >= 0) &&
                                ((int64_t)t + tmax[k] < (int64_t)N);
                 float b = 0.0f;
                 if (computed) {
@@ -441,7 +468,7 @@ int bp_cpu(const float *features, const int32_t *moveouts, const float *w_phases
                         if (beta[s] == 0.0f) continue;
                         for (size_t p = 0; p < P; p++) {
                             int64_t x = (int64_t)t + tau[s * P + p];
-                            if (x < 0 || x >= (int64_t)N) continue; /* flexible only */
+                            if (x < 0 || x >= (int64_t)N) continue; /* flexible (and strict-upper-only: x < 0) */
                             b = fmaf(beta[s], U[(s * P + p) * N + (size_t)x], b);
                         }
                     }

@@ -170,6 +170,17 @@ def find_similar_sources(moveouts, lon, lat, cell_lon, cell_lat, threshold, n_di
 
 
 COMPAT_EXCLUSIVE_LAST_LAG, COMPAT_SQRT_NORM, COMPAT_FIRST_COMPUTED = 1, 2, 4
+COMPAT_RANGE_ALL_CHANNELS, COMPAT_SEQUENTIAL_CSUM, COMPAT_STRICT_UPPER_ONLY, COMPAT_RANGE_ALL_STATIONS = 8, 16, 32, 64
+# oracle flag -> the library option that mirrors it (bpmf_set_option), and which path it belongs to
+COMPAT_OPTIONS = {
+    COMPAT_EXCLUSIVE_LAST_LAG: ("mf.compat_exclusive_last_lag", "mf"),
+    COMPAT_SQRT_NORM: ("mf.compat_sqrt_norm", "mf"),
+    COMPAT_RANGE_ALL_CHANNELS: ("mf.compat_range_all_channels", "mf"),
+    COMPAT_SEQUENTIAL_CSUM: ("mf.compat_sequential_csum", "mf"),
+    COMPAT_FIRST_COMPUTED: ("bp.compat_first_computed", "bp"),
+    COMPAT_STRICT_UPPER_ONLY: ("bp.compat_strict_upper_only", "bp"),
+    COMPAT_RANGE_ALL_STATIONS: ("bp.compat_range_all_stations", "bp"),
+}
 
 
 class compat:

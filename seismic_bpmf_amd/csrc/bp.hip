@@ -1049,6 +1049,30 @@ void bisect_order(const int32_t* mv, size_t SP, std::vector<int>& idx, size_t lo
     bisect_order(mv, SP, idx, mid, hi, leaf);
 }
 
+// Extreme moveouts of one source for the strict bound test and the number of its used (station, phase)
+// terms: over the WEIGHTED stations (the build's convention, oracle/bpmf_oracle.c:bp_cpu), or -- option
+// bp.compat_range_all_stations -- over all stations of a source that has at least one weighted station.
+int source_tau_range(const int32_t* mv, const float* ws, size_t k, size_t S, size_t P, long long& lo, long long& hi)
+{
+    const bool all_stations = option(OPT_BP_COMPAT_RANGE_ALL_STATIONS) != 0;
+    int n = 0;
+    bool seen = false;
+    lo = hi = 0;
+    for (size_t s = 0; s < S; ++s) {
+        const bool used = ws[k * S + s] != 0.0f;
+        if (used) n += (int)P;
+        else if (!all_stations) continue;
+        for (size_t p = 0; p < P; ++p) {
+            const long long tau = mv[(k * S + s) * P + p];
+            if (!seen || tau < lo) lo = tau;
+            if (!seen || tau > hi) hi = tau;
+            seen = true;
+        }
+    }
+    if (n == 0) lo = hi = 0;
+    return n;
+}
+
 // Greedy grouping of consecutive sources (in processing order): a group is closed when the
 // next source would push the LDS need (zero slab + sum over used rows of tile + moveout
 // spread) past the soft budget.  Returns false if one source alone exceeds `hard_floats`.
@@ -1074,17 +1098,8 @@ bool build_plan(const int32_t* mv, const float* ws, const std::vector<int>& orde
     size_t max_terms = 1;
     ph.srcs.resize(K);
     auto src_of = [&](size_t k) {
-        int n = 0;
         long long lo = 0, hi = 0;
-        for (size_t s = 0; s < S; ++s) {
-            if (ws[k * S + s] == 0.0f) continue;
-            for (size_t p = 0; p < P; ++p) {
-                const long long tau = mv[(k * S + s) * P + p];
-                if (n == 0 || tau < lo) lo = tau;
-                if (n == 0 || tau > hi) hi = tau;
-                ++n;
-            }
-        }
+        const int n = source_tau_range(mv, ws, k, S, P, lo, hi);
         max_terms = std::max(max_terms, (size_t)n);
         return BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi,
                         (n + chunk - 1) / chunk * chunk};
@@ -1218,17 +1233,8 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     ph.slots = slots;
     ph.srcs.resize(K);
     auto src_of = [&](size_t k) {
-        int n = 0;
         long long lo = 0, hi = 0;
-        for (size_t s = 0; s < S; ++s) {
-            if (ws[k * S + s] == 0.0f) continue;
-            for (size_t p = 0; p < P; ++p) {
-                const long long tau = mv[(k * S + s) * P + p];
-                if (n == 0 || tau < lo) lo = tau;
-                if (n == 0 || tau > hi) hi = tau;
-                ++n;
-            }
-        }
+        const int n = source_tau_range(mv, ws, k, S, P, lo, hi);
         max_terms = std::max(max_terms, (size_t)n);
         return BpSource{(int)((long long)k + id_offset), (int)lo, (int)hi, (n + chunk - 1) / chunk * chunk};
     };
@@ -1624,20 +1630,22 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     int max_sta = 0, tmin_all = 0, tmax_all = 0;
     bool any_src = false;
     for (size_t k = 0; k < K; ++k) {
-        int n = 0;
-        for (size_t s = 0; s < S; ++s) {
-            if (w_sources[k * S + s] == 0.0f) continue;
-            ++n;
-            for (size_t p = 0; p < P; ++p) {
-                const int tau = moveouts[(k * S + s) * P + p];
-                if (!any_src || tau < tmin_all) tmin_all = tau;
-                if (!any_src || tau > tmax_all) tmax_all = tau;
-                any_src = true;
-            }
+        long long lo = 0, hi = 0;
+        const int n = source_tau_range(moveouts, w_sources, k, S, P, lo, hi) / (int)P;
+        if (n > 0) {
+            if (!any_src || lo < tmin_all) tmin_all = (int)lo;
+            if (!any_src || hi > tmax_all) tmax_all = (int)hi;
+            any_src = true;
         }
         nsta[k] = n;
         max_sta = std::max(max_sta, n);
     }
+    // option bp.compat_strict_upper_only: "strict" tests t + tau_max < N only and a used term in front of
+    // sample 0 contributes nothing.  With every used moveout >= 0 (BPMF's tables: moveouts relative to the
+    // first arrival, template_search.py:212-214) that IS the default; a table with a negative used moveout
+    // takes the global-memory kernel of bp_direct.hip, the one that tests every term.
+    const bool upper_only = option(OPT_BP_COMPAT_STRICT_UPPER_ONLY) != 0;
+    const bool upper_only_direct = upper_only && any_src && tmin_all < 0;
     // processing order of the whole grid (kd-tree walk); a class keeps its members in this order
     std::vector<int> order(K);
     for (size_t k = 0; k < K; ++k) order[k] = (int)k;
@@ -1751,7 +1759,7 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
     bpmf_bp_plan* pl = new bpmf_bp_plan();
     pl->device = device;
     pl->K = K; pl->S = S; pl->P = P;
-    if (!tpt || ph.NT > 256 || option(OPT_BP_DIRECT) != 0) {
+    if (!tpt || ph.NT > 256 || option(OPT_BP_DIRECT) != 0 || upper_only_direct) {
         // No LDS plan: one source's station-phase windows do not fit at the smallest tile, or a source has
         // more than 256 (station, phase) terms (or option bp.direct asks for it: the tests).  The grid runs
         // bp_direct.hip on compact term lists in the oracle's order.
@@ -1759,20 +1767,17 @@ extern "C" int bpmf_bp_plan_create(const int32_t* moveouts, const float* w_sourc
         std::vector<long long> first(K + 1, 0);
         std::vector<int4> terms;
         for (size_t k = 0; k < K; ++k) {
-            int lo = 0, hi = 0, any = 0;
+            long long lo = 0, hi = 0;
+            const int any = source_tau_range(moveouts, w_sources, k, S, P, lo, hi) > 0 ? 1 : 0;
             first[k] = (long long)terms.size();
             for (size_t s = 0; s < S; ++s) {
                 const float b = w_sources[k * S + s];
                 if (b == 0.0f) continue;
-                for (size_t p = 0; p < P; ++p) {
-                    const int tau = moveouts[(k * S + s) * P + p];
-                    if (!any || tau < lo) lo = tau;
-                    if (!any || tau > hi) hi = tau;
-                    any = 1;
-                    terms.push_back(make_int4((int)(s * P + p), tau, __builtin_bit_cast(int, b), 0));
-                }
+                for (size_t p = 0; p < P; ++p)
+                    terms.push_back(make_int4((int)(s * P + p), moveouts[(k * S + s) * P + p], __builtin_bit_cast(int, b), 0));
             }
-            hdr[k] = make_int4(any, lo, hi, 0);
+            // (strict-upper-only: the lower test always passes; the kernel drops a term in front of sample 0)
+            hdr[k] = make_int4(any, upper_only ? 0 : (int)lo, (int)hi, 0);
         }
         first[K] = (long long)terms.size();
         if (terms.empty()) terms.push_back(make_int4(0, 0, 0, 0));

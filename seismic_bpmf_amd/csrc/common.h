@@ -22,7 +22,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Execution options (util.hip, C ABI: bpmf_set_option / bpmf_get_option).  Every option selects
 // among code paths and sizes that produce IDENTICAL results -- kernel family, LDS budget, staging
 // batch sizes, group ranges per tile; none of them can change an output bit, and the library reads
-// nothing from the environment.  The exception are the three `*.compat_*` switches at the end (off
+// nothing from the environment.  The exception are the `*.compat_*` switches at the end (off
 // by default): each replaces one convention of this build that rests on recollection only by the
 // alternative the upstream packages may implement.  The defaults are the tuned production values; the GPU tests use
 // the options to force every kernel family through the same parity cases.
@@ -33,7 +33,9 @@ enum Option {
     OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_MF_TILES_PER_WAVE, OPT_MF_BOUNDARY_PRIO, OPT_MF_FUSED_PROLOGUE, OPT_DEBUG_POISON_OUTPUT,
     OPT_DEBUG_VIRTUAL_DEVICES, OPT_MULTI_PEER_FANOUT,
     // upstream-compatibility switches: the ONLY options that change results (off by default)
-    OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG, OPT_MF_COMPAT_SQRT_NORM, OPT_BP_COMPAT_FIRST_COMPUTED, OPT_COUNT
+    OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG, OPT_MF_COMPAT_SQRT_NORM, OPT_BP_COMPAT_FIRST_COMPUTED,
+    OPT_MF_COMPAT_RANGE_ALL_CHANNELS, OPT_MF_COMPAT_SEQUENTIAL_CSUM, OPT_BP_COMPAT_STRICT_UPPER_ONLY,
+    OPT_BP_COMPAT_RANGE_ALL_STATIONS, OPT_COUNT
 };
 long option(Option which);
 // counts the option changes since the library was loaded: cached plans are keyed by it (a plan is

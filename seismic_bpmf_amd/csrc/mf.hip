@@ -39,7 +39,7 @@ __device__ __forceinline__ int2 mf_lag_range(bool any, long long mv_min, long lo
         long long room = N - L - mv_max;
         // compat (option mf.compat_exclusive_last_lag): data offsets i * step < room only -- the loop
         // bound `i < stop_i`, stop_i = N - L - max_moveout, that upstream is recollected to use
-        if (exclusive_last) room -= 1;
+        if (exclusive_last & 1) room -= 1;
         if (room >= 0) {
             long long last = room / step;
             if (last > n_corr - 1) last = n_corr - 1;
@@ -74,17 +74,20 @@ __global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict
     __syncthreads();       // (workgroup-scope release / acquire: thread 0 reads what the others stored)
     if (threadIdx.x != 0) return;
     long long mv_min = 0, mv_max = 0;
-    bool any = false;
+    bool any = false, seen = false;
+    const bool all_channels = (exclusive_last & 2) != 0;   // option mf.compat_range_all_channels
     int4* rec = chan_rec + (size_t)t * (n_ch + 2);
     int n_used = 0;
     for (int ch = 0; ch < n_ch; ++ch) {
         const float wc = w[(size_t)t * n_ch + ch];
-        if (wc == 0.0f) continue;
+        if (wc == 0.0f && !all_channels) continue;
         long long m = mv[(size_t)t * n_ch + ch];
+        if (!seen || m < mv_min) mv_min = m;
+        if (!seen || m > mv_max) mv_max = m;
+        seen = true;
+        if (wc == 0.0f) continue;
         rec[n_used++] = make_int4(ch, (int)m, __float_as_int(wc),
                                   __float_as_int(((volatile const float*)e_t)[(size_t)t * n_ch + ch]));
-        if (!any || m < mv_min) mv_min = m;
-        if (!any || m > mv_max) mv_max = m;
         any = true;
     }
     rec[n_used] = make_int4(-1, 0, 0, 0);
@@ -154,6 +157,40 @@ __global__ void mf_csum_local_kernel(const float* __restrict__ data, size_t n_ch
         lo[n] = acc;
     }
     tot[idx] = acc;
+}
+
+// Option mf.compat_sequential_csum: local[ch, n] = ONE sequential double chain of data^2 over the whole
+// channel (what a plain CPU loop computes; off[] is zeroed, so csum = 0 + local).  One wave per channel:
+// the 64 lanes stage 1024 samples in LDS with coalesced loads, lane 0 runs the dependent chain over them
+// (8 640 000 dependent v_add_f64 per channel -- tens of milliseconds per day, whatever the channel count
+// up to 256: a compatibility path, not a tuned one), the lanes store the 1024 sums coalesced.
+__global__ __launch_bounds__(64) void mf_csum_sequential_kernel(const float* __restrict__ data, size_t N, size_t nq,
+                                                                double* __restrict__ local, double* __restrict__ off)
+{
+    __shared__ float s_in[CSUM_CHUNK];
+    __shared__ double s_out[CSUM_CHUNK];
+    const size_t ch = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* d = data + ch * N;
+    double* lo = local + ch * N;
+    double acc = 0.0;
+    for (size_t q = 0; q < nq; ++q) {
+        const size_t n0 = q * CSUM_CHUNK;
+        const size_t len = n0 + CSUM_CHUNK < N ? CSUM_CHUNK : N - n0;
+        for (size_t i = lane; i < len; i += 64) s_in[i] = d[n0 + i];
+        if (lane == 0) off[ch * nq + q] = 0.0;
+        __syncthreads();
+        if (lane == 0) {
+            for (size_t i = 0; i < len; ++i) {
+                const double v = (double)s_in[i];
+                acc = acc + v * v;
+                s_out[i] = acc;
+            }
+        }
+        __syncthreads();
+        for (size_t i = lane; i < len; i += 64) lo[n0 + i] = s_out[i];
+        __syncthreads();
+    }
 }
 
 // off[ch, q] = sequential sum of tot[ch, 0..q-1]  (one thread per channel).
@@ -587,8 +624,9 @@ __device__ __forceinline__ int2 mf_fused_prologue(const float* __restrict__ tmpl
         wc = w[(size_t)t * n_ch + tid];
         used = !(wc == 0.0f);
     }
+    const bool all_channels = (exclusive_last & 2) != 0;   // option mf.compat_range_all_channels
+    if (tid < n_ch && (used || all_channels)) m = mv[(size_t)t * n_ch + tid];
     if (used) {
-        m = mv[(size_t)t * n_ch + tid];
         const float* x = tmpl + ((size_t)t * n_ch + tid) * (size_t)L;
         float acc = 0.0f;
         int l = 0;
@@ -609,7 +647,8 @@ __device__ __forceinline__ int2 mf_fused_prologue(const float* __restrict__ tmpl
     }
     const unsigned long long mask = __ballot(used);
     const int idx = __popcll(mask & ((1ull << lane) - 1ull));
-    int mn = used ? m : 0x7fffffff, mx = used ? m : (int)0x80000000;
+    const bool ranged = used || (all_channels && tid < n_ch);
+    int mn = ranged ? m : 0x7fffffff, mx = ranged ? m : (int)0x80000000;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mn = min(mn, __shfl_xor(mn, o));
@@ -1122,15 +1161,19 @@ extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N,
     }
     const size_t nq = (N + CSUM_CHUNK - 1) / CSUM_CHUNK;
     const size_t nwin = N - L + 1;
-    {
+    if (option(OPT_MF_COMPAT_SEQUENTIAL_CSUM) != 0) {
+        // (like mf.compat_sqrt_norm: a caller of the *_dev entry points that switches it prepares the data again)
+        mf_csum_sequential_kernel<<<dim3((unsigned)n_ch), dim3(64), 0, stream>>>(d_data, N, nq, ws.local, ws.off);
+        BPMF_LAUNCH_CHECK();
+    } else {
         size_t n = n_ch * nq;
         mf_csum_local_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(
             d_data, n_ch, N, nq, ws.local, ws.tot);
         BPMF_LAUNCH_CHECK();
+        mf_csum_offsets_kernel<<<dim3((unsigned)((n_ch + 63) / 64)), dim3(64), 0, stream>>>(
+            ws.tot, n_ch, nq, ws.off);
+        BPMF_LAUNCH_CHECK();
     }
-    mf_csum_offsets_kernel<<<dim3((unsigned)((n_ch + 63) / 64)), dim3(64), 0, stream>>>(
-        ws.tot, n_ch, nq, ws.off);
-    BPMF_LAUNCH_CHECK();
     // (option mf.compat_sqrt_norm decides what the norm arrays hold: a caller of the *_dev entry points
     // that switches it prepares the data again -- MatchedFilterGPU keys its prepared state by it)
     mf_window_energy_kernel<<<dim3((unsigned)((nwin + 255) / 256), (unsigned)n_ch), dim3(256), 0,
@@ -1193,7 +1236,9 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     }
     // small problems: the wave kernel does the per-template preparation itself (mf_fused_prologue)
     const bool fused = wave_kernel && ntile < 4 && n_ch <= 256 && option(OPT_MF_FUSED_PROLOGUE) != 0;
-    const int exclusive_last = option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0;
+    // (bit 0: mf.compat_exclusive_last_lag, bit 1: mf.compat_range_all_channels -- both only shape the valid lag range)
+    const int exclusive_last = (option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0) |
+                               (option(OPT_MF_COMPAT_RANGE_ALL_CHANNELS) != 0 ? 2 : 0);
     if (!fused) {
         // template norms, lag ranges, channel records: one launch, one workgroup per template
         mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(

@@ -62,6 +62,10 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))
+    {"mf.compat_range_all_channels", 0, 0, 1, false},  // a template's valid lag range over ALL its channels (default: the weighted ones)
+    {"mf.compat_sequential_csum", 0, 0, 1, false},     // double prefix sum of data^2 as ONE sequential chain per channel (default: 1024-sample hierarchy)
+    {"bp.compat_strict_upper_only", 0, 0, 1, true},    // strict = t + tau_max < N only; used terms in front of sample 0 dropped (default: also t + tau_min >= 0)
+    {"bp.compat_range_all_stations", 0, 0, 1, true},   // a source's tau_min / tau_max over ALL its stations (default: the weighted ones)
 };
 std::atomic<long> g_options[OPT_COUNT];
 std::once_flag g_options_once;

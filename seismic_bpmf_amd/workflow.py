@@ -108,12 +108,15 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
 def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, minimum_interevent_time,
                   n_dev=8.0, overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
                   remove_edges=True, data_buffer_sec=None, data_duration_sec=None, sanity_check=True,
-                  max_kurto=100.0, threshold_type="rms", with_values=False):
+                  max_kurto=100.0, threshold_type="rms", with_values=False, timings=None):
     """The detection stage of matched_filter_detections on a (T, n_corr) CC matrix that already lies in
     HBM (``MatchedFilter.find_detections``, BPMF/similarity_search.py:548-666): NaN scrub, threshold and
     candidates on the device, the reference's pair-wise merge, kurtosis sanity check, edge removal.
     `moveouts` / `weights` are those of the rows of `cc`.  Returns {row: cc indices}; with
-    `with_values` {row: (cc indices, cc values float32, threshold values float32)}."""
+    `with_values` {row: (cc indices, cc values float32, threshold values float32)}.  `timings`: a dict
+    that receives "threshold_ms" / "candidates_ms" / "merge_ms" / "candidates" (the device is synchronised
+    around the stages only when it is given)."""
+    import time
     if remove_edges and data_buffer_sec is None:
         raise ValueError("remove_edges=True needs data_buffer_sec (the reference trims cfg.DATA_BUFFER_SEC); "
                          "pass remove_edges=False for a day without margins")
@@ -122,6 +125,15 @@ def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, mi
         device = cc.device.index
     cc.nan_to_num_(nan=0.0)                                    # similarity_search.py:540
     th = ThresholdGPU(device=device)
+
+    def clock():
+        if timings is None:
+            return 0.0
+        import torch
+        torch.cuda.synchronize(cc.device)
+        return time.perf_counter()
+
+    t_0 = clock()
     window = int(pp.sec_to_samp(threshold_window_dur, sr))
     threshold_type = threshold_type.lower()
     if threshold_type == "rms":
@@ -137,8 +149,10 @@ def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, mi
                                                      white_noise=white_noise, expand=False)
     else:
         raise ValueError("threshold_type must be 'rms' or 'mad'")
+    t_1 = clock()
     cap = max_cc_threshold * weights.reshape(weights.shape[0], -1).sum(axis=1)   # :629
     cand = th.extract_candidates(cc, thr_win, window, overlap=overlap, row_cap=cap, kind=threshold_type)
+    t_2 = clock()
     min_iet = int(pp.sec_to_samp(minimum_interevent_time, sr))
     mv = np.asarray(moveouts)
     rejected = row_excess_kurtosis(cc) > max_kurto if sanity_check else np.zeros(weights.shape[0], bool)
@@ -162,6 +176,9 @@ def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, mi
             out[t] = (idx, mine["cc"][pos].astype(np.float32), mine["threshold"][pos].astype(np.float32))
         else:
             out[t] = idx
+    if timings is not None:
+        timings.update(threshold_ms=(t_1 - t_0) * 1e3, candidates_ms=(t_2 - t_1) * 1e3,
+                       merge_ms=(time.perf_counter() - t_2) * 1e3, candidates=int(cand.size))
     return out
 
 
