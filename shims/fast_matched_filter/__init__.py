@@ -6,4 +6,5 @@ package.  Only the GPU path exists: BPMF must be driven with ``device="gpu"``.
 """
 from seismic_bpmf_amd.matched_filter import matched_filter  # noqa: F401
 
+__bpmf_shim__ = True      # tools/diff_upstream.py refuses to diff the build against itself
 __all__ = ["matched_filter"]
