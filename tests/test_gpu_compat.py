@@ -176,7 +176,7 @@ def test_mf_range_all_channels(oracle_lib, hip_opts, step, network_sum):
     with oracle_lib.compat(oracle_lib.COMPAT_RANGE_ALL_CHANNELS):
         want = oracle_lib.matched_filter(*args, network_sum)
     nz = lambda a: (a.reshape(3, -1) != 0).sum(axis=1)
-    assert nz(want)[0] < nz(base)[0] and nz(want)[2] == 0 and nz(base)[2] > 0 and nz(want)[1] == nz(base)[1]
+    assert nz(want)[0] < nz(base)[0] and nz(want)[2] == 0 and nz(base)[2] > 0 and nz(want)[1] <= nz(base)[1]
     hip_opts("mf.compat_range_all_channels", 1)
     for wave, fused in ((1, 1), (1, 0), (0, 0)):
         hip_opts("mf.wave_kernel", wave)
