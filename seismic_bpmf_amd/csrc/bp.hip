@@ -34,11 +34,12 @@ template <int MAXP>
 __global__ __launch_bounds__(256) void bp_prestack_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ w_ph,
                                                           long long N, int C, int P,
-                                                          float* __restrict__ U)
+                                                          float* __restrict__ U, long long t_lo, long long t_hi)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (samples [t_lo, t_hi): the whole series, or one piece of a day that is still arriving from the host)
+    const long long t = t_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y;
-    if (t >= N) return;
+    if (t >= t_hi) return;
     float acc[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) acc[p] = 0.0f;
@@ -56,11 +57,11 @@ __global__ __launch_bounds__(256) void bp_prestack_kernel(const float* __restric
 // Generic P (slow path, P > 4): one thread per (s, p, t).
 __global__ void bp_prestack_any_kernel(const float* __restrict__ feat,
                                        const float* __restrict__ w_ph, long long N, int C, int P,
-                                       float* __restrict__ U)
+                                       float* __restrict__ U, long long t_lo, long long t_hi)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = t_lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int s = blockIdx.y / P, p = blockIdx.y % P;
-    if (t >= N) return;
+    if (t >= t_hi) return;
     float acc = 0.0f;
     for (int c = 0; c < C; ++c)
         acc = __fmaf_rn(w_ph[((size_t)s * C + c) * P + p], feat[((size_t)s * C + c) * (size_t)N + t],
@@ -2274,6 +2275,35 @@ int dispatch_beam(const bpmf_bp_plan* pl, const float* U, size_t N, int oob, int
     return dispatch_beam2<TPT, 4>(pl, U, N, oob, reduce, stream, beam, arg);
 }
 
+
+// prestack of the samples [t_lo, t_hi)
+int launch_prestack(const float* d_features, const float* d_w_phases, size_t N, size_t C, int S, int P, float* U,
+                    long long t_lo, long long t_hi, hipStream_t stream)
+{
+    if (t_hi <= t_lo) return 0;
+    const unsigned nb = (unsigned)((t_hi - t_lo + 255) / 256);
+    if (P <= 4) {
+        bp_prestack_kernel<4><<<dim3(nb, (unsigned)S), dim3(256), 0, stream>>>(d_features, d_w_phases, (long long)N,
+                                                                               (int)C, P, U, t_lo, t_hi);
+    } else {
+        bp_prestack_any_kernel<<<dim3(nb, (unsigned)(S * P)), dim3(256), 0, stream>>>(d_features, d_w_phases, (long long)N,
+                                                                                     (int)C, P, U, t_lo, t_hi);
+    }
+    BPMF_LAUNCH_CHECK();
+    return 0;
+}
+
+// The day of features of a host-pointer call, arriving in pieces (bpmf_bp_run below): need(samp_end, stream)
+// returns once the work enqueued on `stream` behind it may read features and prestack of the samples
+// [0, samp_end) -- it uploads the missing pieces on the copy stream (the host thread is inside the runtime's
+// pageable-memory staging meanwhile; the device computes what was enqueued before) and enqueues their
+// prestack on `stream` behind the piece's event.
+struct BpFeed {
+    virtual int need(long long samp_end, hipStream_t stream) = 0;
+    virtual ~BpFeed() {}
+};
+thread_local BpFeed* t_bp_feed = nullptr;
+
 }  // namespace
 
 extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
@@ -2314,16 +2344,18 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
     }
     float* U = (float*)d_workspace;
     const int P = (int)pl->P, S = (int)pl->S;
-    if (P <= 4) {
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)S);
-        bp_prestack_kernel<4><<<grid, dim3(256), 0, stream>>>(d_features, d_w_phases, (long long)N,
-                                                              (int)C, P, U);
-    } else {
-        dim3 grid((unsigned)((N + 255) / 256), (unsigned)(S * P));
-        bp_prestack_any_kernel<<<grid, dim3(256), 0, stream>>>(d_features, d_w_phases, (long long)N,
-                                                               (int)C, P, U);
-    }
-    BPMF_LAUNCH_CHECK();
+    // A host-pointer call may stream its day of features in while the kernels run (BpFeed, bpmf_bp_run):
+    // the feed uploads AND prestacks piece by piece; only the interior-tile path below consumes it in
+    // pieces, every other path asks for the whole series first.
+    BpFeed* feed = t_bp_feed;
+    // option bp.host_piece_samples: samples of the first piece (default 131 072 = one round of the chip at tile
+    // 512; the tests shrink it), 0 = the whole day in front of the first kernel
+    const long long piece0 = (long long)align_up((size_t)option(OPT_BP_HOST_PIECE_SAMPLES), 1024);
+    const bool feed_pieces = feed && pl->fast && !pl->direct && reduce == BPMF_BP_REDUCE_MAX && piece0 > 0;
+    if (feed && !feed_pieces)
+        if (int rc = feed->need((long long)N, stream)) return rc;
+    if (!feed)
+        if (int rc = launch_prestack(d_features, d_w_phases, N, C, S, P, U, 0, (long long)N, stream)) return rc;
     struct SplitScope {          // the launchers read the thread-local pair; always reset on the way out
         SplitScope(int n, long long stride) { t_n_split = n; t_split_stride = stride; }
         ~SplitScope() { t_n_split = 1; t_split_stride = 0; t_samp_hi = -1; t_samp_lo = 0; }
@@ -2389,12 +2421,14 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         int rc = 0;
         const bool have_edge = lo_s > 0 || hi_s < (long long)N;
         hipStream_t es = stream;          // edge tiles: on the side stream, beside the interior kernels
-        if (have_edge && pl->side_stream) {
+        // (a day arriving in pieces: the edge tiles -- both ends of the series -- run behind the interior
+        // pieces, on the launch stream, once everything is there)
+        if (have_edge && pl->side_stream && !feed_pieces) {
             BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
             BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
             es = pl->side_stream;
         }
-        {
+        auto run_edges = [&]() {
             SplitScope scope(n_split_edge, rows > 1 ? (long long)N : 0);
             auto edge = [&](long long from, long long to) {
                 if (to <= from || rc) return;
@@ -2408,13 +2442,35 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
             };
             edge(0, lo_s);
             edge(hi_s, (long long)N);
-        }
+        };
+        if (!feed_pieces) run_edges();
         if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
-        for (int c = 0; c < pl->n_classes && !rc; ++c) {
-            const BpFastClass& fc = pl->cls[c];
-            rc = launch_beam_fast(fc, pl->id_offset, U, N, lo_s / fc.tile, hi_s / fc.tile, stream,
-                                  pbeam + (size_t)c * n_split * N, parg + (size_t)c * n_split * N, n_split,
-                                  rows > 1 ? (long long)N : 0, t_best0);
+        // The interior tiles: one launch per class -- or, while the day is still arriving from the host
+        // (feed_pieces), one launch per class and PIECE of the range, each behind the piece of features it
+        // reads.  A piece is a whole number of rounds of the chip (256 workgroups of 512 samples, one per CU):
+        // 1, 2, then 4 rounds -- the first kernels start after 1 % of the upload, and a launch boundary costs
+        // no partly filled round.
+        long long a = lo_s;
+        long long piece = piece0;
+        while (a < hi_s && !rc) {
+            long long b = hi_s;
+            if (feed_pieces) {
+                b = std::min(hi_s, a + piece);
+                if (hi_s - b < piece0) b = hi_s;          // no sliver at the end
+                piece = std::min<long long>(piece * 2, 4 * piece0);
+                rc = feed->need(std::min<long long>((long long)N, b + std::max(pl->tmax_all, 0) + 8 + 1024), stream);
+            }
+            for (int c = 0; c < pl->n_classes && !rc; ++c) {
+                const BpFastClass& fc = pl->cls[c];
+                rc = launch_beam_fast(fc, pl->id_offset, U, N, a / fc.tile, b / fc.tile, stream,
+                                      pbeam + (size_t)c * n_split * N, parg + (size_t)c * n_split * N, n_split,
+                                      rows > 1 ? (long long)N : 0, t_best0);
+            }
+            a = b;
+        }
+        if (feed_pieces && !rc) {
+            rc = feed->need((long long)N, stream);
+            if (!rc) run_edges();
         }
         if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
         if (!rc && rows > 1) {
@@ -2608,22 +2664,69 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     // (pageable memory through the runtime's own staging, on the private stream: a hand-made pipeline through
     // the context's pinned pieces filled by 8 host threads measured SLOWER -- cfg3 end to end 194 ms against
     // 176 ms -- the host-side memcpy into the pinned pieces is the bottleneck on the 16 CPUs a box grants)
-    {                     // the day of features: from the host, or from the first device of a multi-device call
-        const char* what = "H2D features";
-        if ((e = fanout_upload(fan, ctx, base + o_f, features, b_f, stream, &what)) != hipSuccess) fail(e, what);
+    // The day of features.  A peer of a multi-device call copies it from the first device.  Everybody else
+    // uploads it from the host IN PIECES on the copy stream while the kernels of the pieces that have arrived
+    // run (HostFeed: bpmf_bp_run_dev asks for the samples it is about to read) -- the upload of a whole day
+    // in front of the first kernel cost cfg3 a third of its time (201.7 ms end to end against 150.6 resident,
+    // round-4 bench; BPMF makes exactly this call, template_search.py:549-558).  Pageable memory goes through the
+    // runtime's own staging (a hand-made pipeline through pinned pieces measured slower).
+    struct HostFeed : BpFeed {
+        DeviceContext* ctx; FanoutScope* fan; const float* host; char* d_feat; const float* d_wp; float* U;
+        size_t N, C; int S, P; long long have = 0; int n_piece = 0; hipError_t err = hipSuccess; const char* what = "";
+        bool published = false;
+        int need(long long samp_end, hipStream_t stream) override
+        {
+            samp_end = std::min<long long>((samp_end + 1023) / 1024 * 1024, (long long)N);
+            if (samp_end <= have) return 0;
+            const size_t rows = (size_t)S * C;
+            what = "H2D features";
+            // rows x [have, samp_end): a strided copy, every row N floats apart on both sides
+            err = hipMemcpy2DAsync(d_feat + (size_t)have * sizeof(float), N * sizeof(float), host + have, N * sizeof(float),
+                                   (size_t)(samp_end - have) * sizeof(float), rows, hipMemcpyHostToDevice, ctx->s_copy);
+            hipEvent_t ev = ctx->ev_chunk[n_piece++ % DeviceContext::CHUNK_EVENTS];
+            if (err == hipSuccess) { what = "event record"; err = hipEventRecord(ev, ctx->s_copy); }
+            if (err == hipSuccess) { what = "wait event"; err = hipStreamWaitEvent(stream, ev, 0); }
+            if (err == hipSuccess && samp_end == (long long)N && !published) {
+                published = true;               // the whole day is on its way: the other devices may copy it
+                what = "event record";
+                err = fanout_publish(*fan, ctx, d_feat, ctx->s_copy);
+            }
+            if (err != hipSuccess) {
+                set_error("bpmf_bp_run: %s failed: %s", what, hipGetErrorString(err));
+                return -2;
+            }
+            const int rc = launch_prestack((const float*)d_feat, d_wp, N, C, S, P, U, have, samp_end, stream);
+            have = samp_end;
+            return rc;
+        }
+    } host_feed;
+    bool from_peer = false;
+    {
+        const char* what = "";
+        from_peer = fanout_peer_copy(fan, ctx, base + o_f, b_f, stream, &e, &what);
+        if (from_peer && e != hipSuccess) fail(e, what);
     }
     if (!rc && (e = hipMemcpyAsync(base + o_wp, w_phases, b_wp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights_phases");
     if (!rc && reduce == BPMF_BP_REDUCE_NONE &&
         (e = hipMemsetAsync(base + o_beam, 0, b_beam, stream)) != hipSuccess) fail(e, "memset");
-    if (!rc)
+    if (!rc) {
+        host_feed.ctx = ctx; host_feed.fan = &fan; host_feed.host = features; host_feed.d_feat = base + o_f;
+        host_feed.d_wp = (const float*)(base + o_wp); host_feed.U = (float*)(base + o_ws);
+        host_feed.N = N; host_feed.C = C; host_feed.S = (int)S; host_feed.P = (int)P;
+        struct FeedScope {
+            explicit FeedScope(BpFeed* f) { t_bp_feed = f; }
+            ~FeedScope() { t_bp_feed = nullptr; }
+        } feed_scope(from_peer ? nullptr : &host_feed);
         rc = bpmf_bp_run_dev(pl, (const float*)(base + o_f), (const float*)(base + o_wp), N, C,
                              out_of_bounds, reduce, base + o_ws, b_ws, stream,
                              (float*)(base + o_beam), (int32_t*)(base + o_arg));
+    }
     if (!rc && (e = hipMemcpyAsync(beam_out, base + o_beam, b_beam, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H beam");
     if (!rc && reduce == BPMF_BP_REDUCE_MAX && arg_out &&
         (e = hipMemcpyAsync(arg_out, base + o_arg, b_arg, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H argmax");
     // (always drained, also after a failure: the working set and the plan go back to their caches)
     hipError_t es = hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(ctx->s_copy);
     if (pl->side_stream) (void)hipStreamSynchronize(pl->side_stream);
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();

@@ -36,6 +36,8 @@ struct DeviceContext {
     hipStream_t s_side[SIDE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
     std::atomic<unsigned> next_side{0};
     hipEvent_t ev_data = nullptr;     // *_run_multi: the day of data has arrived on this device (peer fan-out)
+    static constexpr int CHUNK_EVENTS = 4;
+    hipEvent_t ev_chunk[CHUNK_EVENTS] = {nullptr, nullptr, nullptr, nullptr};   // pieces of a day arriving while the kernels run
     hipEvent_t ev_batch[2] = {nullptr, nullptr};
     hipEvent_t ev_piece[2] = {nullptr, nullptr};
     // grow-only buffers, valid while call_mutex is held
@@ -162,6 +164,12 @@ extern std::mutex g_fanout_mutex;
 // publishes behind its upload.  hipSuccess or the failing call's error (`what` names it).
 hipError_t fanout_upload(FanoutScope& scope, DeviceContext* ctx, void* d_dst, const void* host, size_t bytes,
                          hipStream_t stream, const char** what);
+// The two halves of it, for a caller that uploads in pieces: a PEER's device-to-device copy (true = enqueued
+// or failed with *err set; false = not a peer, or the hand-over was cancelled: upload from the host), and a
+// SOURCE's publication behind the last piece it enqueued on `stream` (a no-op for anybody else).
+bool fanout_peer_copy(FanoutScope& scope, DeviceContext* ctx, void* d_dst, size_t bytes, hipStream_t stream,
+                      hipError_t* err, const char** what);
+hipError_t fanout_publish(FanoutScope& scope, DeviceContext* ctx, const void* d_src, hipStream_t stream);
 
 // memcpy on a few host threads (large blocks) -- dst / src pageable or pinned host memory
 void parallel_copy(char* dst, const char* src, size_t bytes);

@@ -152,6 +152,7 @@ DeviceContext* device_context(int device)
     step(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
     for (hipStream_t& s : c->s_side) step(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     step(hipEventCreateWithFlags(&c->ev_data, hipEventDisableTiming));
+    for (hipEvent_t& e : c->ev_chunk) step(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
         step(hipEventCreateWithFlags(&c->ev_batch[i], hipEventDisableTiming));
         step(hipEventCreateWithFlags(&c->ev_piece[i], hipEventDisableTiming));
@@ -192,30 +193,41 @@ void ensure_peer_access(int dst_physical, int src_physical)
 }
 }  // namespace
 
+bool fanout_peer_copy(FanoutScope& scope, DeviceContext* ctx, void* d_dst, size_t bytes, hipStream_t stream,
+                      hipError_t* err, const char** what)
+{
+    *err = hipSuccess;
+    if (!scope.f || scope.role != DataFanout::PEER) return false;
+    const void* d_src = nullptr;
+    int src_physical = -1;
+    hipEvent_t ready = nullptr;
+    if (!scope.f->wait_published(&d_src, &src_physical, &ready)) return false;
+    ensure_peer_access(ctx->physical, src_physical);
+    *what = "waiting for the first device's upload";
+    if ((*err = hipStreamWaitEvent(stream, ready, 0)) != hipSuccess) return true;
+    *what = "device-to-device copy of the data";
+    *err = hipMemcpyPeerAsync(d_dst, ctx->physical, d_src, src_physical, bytes, stream);
+    return true;
+}
+
+hipError_t fanout_publish(FanoutScope& scope, DeviceContext* ctx, const void* d_src, hipStream_t stream)
+{
+    if (!scope.f || scope.role != DataFanout::SOURCE) return hipSuccess;
+    const hipError_t e = hipEventRecord(ctx->ev_data, stream);
+    if (e != hipSuccess) return e;
+    scope.f->publish(d_src, ctx->physical, ctx->ev_data);
+    return hipSuccess;
+}
+
 hipError_t fanout_upload(FanoutScope& scope, DeviceContext* ctx, void* d_dst, const void* host, size_t bytes,
                          hipStream_t stream, const char** what)
 {
     hipError_t e;
-    if (scope.f && scope.role == DataFanout::PEER) {
-        const void* d_src = nullptr;
-        int src_physical = -1;
-        hipEvent_t ready = nullptr;
-        if (scope.f->wait_published(&d_src, &src_physical, &ready)) {
-            ensure_peer_access(ctx->physical, src_physical);
-            *what = "waiting for the first device's upload";
-            if ((e = hipStreamWaitEvent(stream, ready, 0)) != hipSuccess) return e;
-            *what = "device-to-device copy of the data";
-            return hipMemcpyPeerAsync(d_dst, ctx->physical, d_src, src_physical, bytes, stream);
-        }
-    }
+    if (fanout_peer_copy(scope, ctx, d_dst, bytes, stream, &e, what)) return e;
     *what = "H2D data";
     if ((e = hipMemcpyAsync(d_dst, host, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    if (scope.f && scope.role == DataFanout::SOURCE) {
-        *what = "event record";
-        if ((e = hipEventRecord(ctx->ev_data, stream)) != hipSuccess) return e;
-        scope.f->publish(d_dst, ctx->physical, ctx->ev_data);
-    }
-    return hipSuccess;
+    *what = "event record";
+    return fanout_publish(scope, ctx, d_dst, stream);
 }
 
 hipStream_t device_side_stream(int device)

@@ -99,11 +99,12 @@ __global__ __launch_bounds__(64) void mf_prologue_kernel(const float* __restrict
 // local[ch, n] = sum of squares of samples [chunk_start(n), n]; tot[ch, q] = chunk totals.
 __global__ void mf_csum_local_kernel(const float* __restrict__ data, size_t n_ch, size_t N,
                                      size_t nq, double* __restrict__ local,
-                                     double* __restrict__ tot)
+                                     double* __restrict__ tot, size_t q_lo, size_t q_cnt)
 {
+    // (chunks [q_lo, q_lo + q_cnt) of every channel: all of them, or the piece of a day that has just arrived)
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_ch * nq) return;
-    size_t ch = idx / nq, q = idx % nq;
+    if (idx >= n_ch * q_cnt) return;
+    size_t ch = idx / q_cnt, q = q_lo + idx % q_cnt;
     size_t n0 = q * CSUM_CHUNK;
     size_t n1 = n0 + CSUM_CHUNK < N ? n0 + CSUM_CHUNK : N;
     const float* d = data + ch * N;
@@ -156,7 +157,7 @@ __global__ void mf_csum_local_kernel(const float* __restrict__ data, size_t n_ch
         acc = acc + v * v;
         lo[n] = acc;
     }
-    tot[idx] = acc;
+    tot[ch * nq + q] = acc;
 }
 
 // Option mf.compat_sequential_csum: local[ch, n] = ONE sequential double chain of data^2 over the whole
@@ -195,26 +196,30 @@ __global__ __launch_bounds__(64) void mf_csum_sequential_kernel(const float* __r
 
 // off[ch, q] = sequential sum of tot[ch, 0..q-1]  (one thread per channel).
 __global__ void mf_csum_offsets_kernel(const double* __restrict__ tot, size_t n_ch, size_t nq,
-                                       double* __restrict__ off)
+                                       double* __restrict__ off, size_t q_lo, size_t q_hi)
 {
     size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
-    double acc = 0.0;
+    // chunks [q_lo, q_hi): the chain continues where the previous piece of the day left it (same additions in
+    // the same order as one pass over the whole channel)
+    const double* tr = tot + ch * nq;
+    double* orow = off + ch * nq;
+    double acc = q_lo ? orow[q_lo - 1] + tr[q_lo - 1] : 0.0;
     // the additions are one dependent chain; the loads are not: fetch 16 totals at a time
-    size_t q = 0;
-    for (; q + 16 <= nq; q += 16) {
+    size_t q = q_lo;
+    for (; q + 16 <= q_hi; q += 16) {
         double v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = tot[ch * nq + q + i];
+        for (int i = 0; i < 16; ++i) v[i] = tr[q + i];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            off[ch * nq + q + i] = acc;
+            orow[q + i] = acc;
             acc = acc + v[i];
         }
     }
-    for (; q < nq; ++q) {
-        off[ch * nq + q] = acc;
-        acc = acc + tot[ch * nq + q];
+    for (; q < q_hi; ++q) {
+        orow[q] = acc;
+        acc = acc + tr[q];
     }
 }
 
@@ -223,11 +228,12 @@ __global__ void mf_csum_offsets_kernel(const double* __restrict__ tot, size_t n_
 __global__ void mf_window_energy_kernel(const double* __restrict__ local,
                                         const double* __restrict__ off, size_t n_ch, size_t N,
                                         size_t nq, size_t L, size_t nwin, int sqrt_norm,
-                                        float* __restrict__ e_d)
+                                        float* __restrict__ e_d, size_t w_lo, size_t w_hi)
 {
-    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (windows [w_lo, w_hi): all of them, or those the piece of a day that has just arrived completes)
+    size_t j = w_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t ch = blockIdx.y;
-    if (j >= nwin) return;
+    if (j >= w_hi) return;
     const double* lo = local + ch * N;
     const double* of = off + ch * nq;
     size_t nh = j + L - 1;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int n_lag_blocks, int prio)
+    float* __restrict__ out, int n_lag_blocks, int prio, int lag_block0)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -384,6 +390,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mf_mfma_kernel(
     int t;
     long long lag_block;
     if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
+    lag_block += lag_block0;          // (a launch over a RANGE of lag blocks: a day still arriving from the host)
     const long long lag0 = lag_block * MF_LAGS_PER_WG;
     // `range` holds CC indices; the kernel works on data-sample offsets (lag = index * step) and
     // simply skips the offsets that are not multiples of step
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ data, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
     float* __restrict__ out, int n_lag_blocks, int prio, const int* __restrict__ mv,
-    const float* __restrict__ wts, int exclusive_last)
+    const float* __restrict__ wts, int exclusive_last, int lag_block0)
 {
     extern __shared__ float smem[];
     const int Kpad = mf_kpad(L);
@@ -750,6 +757,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     // 85.7 / 85.5 / 85.1 / 84.9 % of the fp32 peak for 1 / 2 / 4 / 8 blocks, profiles/r02_mf_nsub.txt;
     // the loop also cost 7 spilled registers.  One block per workgroup.)
     if (!mf_tile_of_block(blockIdx.x, T, n_lag_blocks, t, lag_block)) return;
+    lag_block += lag_block0;          // (a launch over a RANGE of lag blocks: a day still arriving from the host)
     int2 rgi;
     int4* l_rec = nullptr;
     if constexpr (FUSED) {
@@ -1134,6 +1142,26 @@ static int mf_check_sizes(size_t step, size_t L, size_t N, size_t T, size_t S, s
     return 0;
 }
 
+// bpmf_mf_run (host pointers) computes its first template batches piece by piece while the day is still
+// arriving from the host: a launch of bpmf_mf_run_dev restricted to the data offsets [t_mf_off_lo,
+// t_mf_off_hi) -- multiples of MF_LAGS_PER_WG, or the end -- (hi < 0: all of them), and, for the later
+// pieces of a batch, without the per-template preparation and output fill the first piece did.
+thread_local long long t_mf_off_lo = 0, t_mf_off_hi = -1;
+thread_local bool t_mf_continue = false;
+
+// the launch of bpmf_mf_run_dev takes the MFMA kernels (which can be restricted to a range of lag blocks)
+static bool mf_uses_mfma(size_t step, size_t L, size_t N, size_t T, size_t n_corr, int network_sum, int flags)
+{
+    const size_t n_offsets = (n_corr - 1) * step + 1;
+    const size_t n_lag_blocks = (n_offsets + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
+    const int need_r = (mf_window_len((int)L) + MF_THREADS - 1) / MF_THREADS;
+    const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
+    const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);
+    const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;
+    return step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !(sqrt_norm && !network_sum) && need_r <= 24 &&
+           need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull && N < ((size_t)1 << 30) - 8192;
+}
+
 }  // namespace bpmf
 
 using namespace bpmf;
@@ -1141,6 +1169,40 @@ using namespace bpmf;
 extern "C" size_t bpmf_mf_workspace_bytes(size_t L, size_t N, size_t T, size_t S, size_t C)
 {
     return mf_carve(nullptr, L, N, T, S * C).bytes;
+}
+
+// The per-day preparation for the samples [samp_lo, samp_hi) (multiples of CSUM_CHUNK, or the end of the
+// trace): chunk-local prefix sums of the chunks in the range, the chain of chunk offsets continued, the norms
+// of the windows the range completes.  The whole day in one piece = bpmf_mf_prepare_data_dev; piece by piece
+// (bpmf_mf_run, a day still arriving from the host) the same kernels run the same additions in the same order.
+static int mf_prepare_range(const float* d_data, size_t L, size_t N, size_t n_ch, const MfWorkspace& ws,
+                            hipStream_t stream, size_t samp_lo, size_t samp_hi)
+{
+    const size_t nq = (N + CSUM_CHUNK - 1) / CSUM_CHUNK;
+    const size_t nwin = N - L + 1;
+    const size_t q_lo = samp_lo / CSUM_CHUNK, q_hi = (samp_hi + CSUM_CHUNK - 1) / CSUM_CHUNK;
+    if (q_hi <= q_lo) return 0;
+    {
+        size_t n = n_ch * (q_hi - q_lo);
+        mf_csum_local_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(
+            d_data, n_ch, N, nq, ws.local, ws.tot, q_lo, q_hi - q_lo);
+        BPMF_LAUNCH_CHECK();
+    }
+    mf_csum_offsets_kernel<<<dim3((unsigned)((n_ch + 63) / 64)), dim3(64), 0, stream>>>(
+        ws.tot, n_ch, nq, ws.off, q_lo, q_hi);
+    BPMF_LAUNCH_CHECK();
+    // windows [w_lo, w_hi): window j needs the prefix sums up to sample j + L - 1
+    const size_t w_lo = samp_lo >= L - 1 ? samp_lo - (L - 1) : 0;
+    const size_t w_hi = samp_hi >= N ? nwin : (samp_hi >= L - 1 ? std::min(nwin, samp_hi - (L - 1)) : 0);
+    if (w_hi > w_lo) {
+        // (option mf.compat_sqrt_norm decides what the norm arrays hold: a caller of the *_dev entry points
+        // that switches it prepares the data again -- MatchedFilterGPU keys its prepared state by it)
+        mf_window_energy_kernel<<<dim3((unsigned)((w_hi - w_lo + 255) / 256), (unsigned)n_ch), dim3(256), 0,
+                                  stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin,
+                                            option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_d, w_lo, w_hi);
+        BPMF_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N, size_t S, size_t C,
@@ -1159,28 +1221,19 @@ extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N,
                   ws.bytes);
         return -1;
     }
-    const size_t nq = (N + CSUM_CHUNK - 1) / CSUM_CHUNK;
-    const size_t nwin = N - L + 1;
     if (option(OPT_MF_COMPAT_SEQUENTIAL_CSUM) != 0) {
         // (like mf.compat_sqrt_norm: a caller of the *_dev entry points that switches it prepares the data again)
+        const size_t nq = (N + CSUM_CHUNK - 1) / CSUM_CHUNK;
+        const size_t nwin = N - L + 1;
         mf_csum_sequential_kernel<<<dim3((unsigned)n_ch), dim3(64), 0, stream>>>(d_data, N, nq, ws.local, ws.off);
         BPMF_LAUNCH_CHECK();
-    } else {
-        size_t n = n_ch * nq;
-        mf_csum_local_kernel<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream>>>(
-            d_data, n_ch, N, nq, ws.local, ws.tot);
+        mf_window_energy_kernel<<<dim3((unsigned)((nwin + 255) / 256), (unsigned)n_ch), dim3(256), 0,
+                                  stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin,
+                                            option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_d, 0, nwin);
         BPMF_LAUNCH_CHECK();
-        mf_csum_offsets_kernel<<<dim3((unsigned)((n_ch + 63) / 64)), dim3(64), 0, stream>>>(
-            ws.tot, n_ch, nq, ws.off);
-        BPMF_LAUNCH_CHECK();
+        return 0;
     }
-    // (option mf.compat_sqrt_norm decides what the norm arrays hold: a caller of the *_dev entry points
-    // that switches it prepares the data again -- MatchedFilterGPU keys its prepared state by it)
-    mf_window_energy_kernel<<<dim3((unsigned)((nwin + 255) / 256), (unsigned)n_ch), dim3(256), 0,
-                              stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin,
-                                        option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_d);
-    BPMF_LAUNCH_CHECK();
-    return 0;
+    return mf_prepare_range(d_data, L, N, n_ch, ws, stream, 0, N);
 }
 
 extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveouts,
@@ -1219,15 +1272,25 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     // option mf.compat_sqrt_norm: num / sqrtf(E_t * E_d) in the epilogue of the MFMA kernels too (network
     // sums; per-channel output with the switch on takes the generic kernel)
     const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;
-    const bool use_mfma = step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !(sqrt_norm && !network_sum) && need_r <= 24 &&
-                          need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull &&
-                          N < ((size_t)1 << 30) - 8192;
+    const bool use_mfma = mf_uses_mfma(step, L, N, T, n_corr, network_sum, flags);
+    (void)max_mfma_step;
+    // a launch over a range of data offsets (bpmf_mf_run, see t_mf_off_lo): MFMA kernels only
+    const bool ranged = t_mf_off_hi >= 0;
+    if (ranged && (!use_mfma || t_mf_off_lo % MF_LAGS_PER_WG != 0)) {
+        set_error("bpmf_mf_run_dev: internal error: a range of lag blocks on a launch that cannot take one");
+        return -1;
+    }
+    const size_t off_lo = ranged ? (size_t)t_mf_off_lo : 0;
+    const size_t off_hi = ranged ? std::min<size_t>((size_t)t_mf_off_hi, n_offsets) : n_offsets;
+    if (off_hi <= off_lo) return 0;
+    const bool first_piece = !(ranged && t_mf_continue);
     const bool wave_kernel = use_mfma && option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
     // tiles (of 256 lags) per wave of that kernel: 4 unless the problem is too small to give every SIMD ~4 waves
     // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
     // (calibrated on an hour-long series with 4 .. 256 templates, tools/probe_mf_ntile_T.py,
     // profiles/r04_mf_ntile_T.txt: 4 tiles from two full rounds of 4 waves per SIMD on, 2 tiles -- 5 waves
     // per SIMD at 83-90 VGPRs -- from one wave per SIMD on, 1 tile below)
+    // (by the size of the WHOLE problem, also for a launch over a range: every piece takes the same variant)
     const size_t waves4 = T * ((n_offsets + 4095) / 4096) * 4;
     int ntile = waves4 >= 8192 ? 4 : (waves4 >= 1024 ? 2 : 1);
     {
@@ -1240,13 +1303,16 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const int exclusive_last = (option(OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG) != 0 ? 1 : 0) |
                                (option(OPT_MF_COMPAT_RANGE_ALL_CHANNELS) != 0 ? 2 : 0);
     if (!fused) {
-        // template norms, lag ranges, channel records: one launch, one workgroup per template
+        // template norms, lag ranges, channel records: one launch, one workgroup per template (also in front
+        // of every later piece of a batch: the pieces of two batches alternate, and the records live in the
+        // one workspace both use)
         mf_prologue_kernel<<<dim3((unsigned)T), dim3(64), 0, stream>>>(
             d_templates, d_moveouts, d_weights, (int)T, (int)n_ch, (long long)step, (long long)L, (long long)N,
             (long long)n_corr, exclusive_last, sqrt_norm ? 1 : 0, ws.e_t, ws.range, ws.chan_rec);
         BPMF_LAUNCH_CHECK();
     }
-    if (!network_sum)
+    if (!first_piece) {
+    } else if (!network_sum)
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0, T * n_corr * n_ch * sizeof(float), stream));
     else if (option(OPT_DEBUG_POISON_OUTPUT) != 0)      // tests: a CC sum that no kernel writes comes back as NaN
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0xFF, T * n_corr * sizeof(float), stream));
@@ -1254,7 +1320,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
     if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks x T / 8) (lag block, template) pairs (mf_tile_of_block)
-        dim3 grid((unsigned)(8 * ((T * n_lag_blocks + 7) / 8)));
+        const size_t nb_lo = off_lo / MF_LAGS_PER_WG, nb_cnt = (off_hi - off_lo + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
+        dim3 grid((unsigned)(8 * ((T * nb_cnt + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
 #define BPMF_MF_LAUNCH2(NS, R, TT, S1) \
     do { if (NS && sqrt_norm) BPMF_MF_LAUNCH3(NS, R, TT, S1, NS); else BPMF_MF_LAUNCH3(NS, R, TT, S1, false); } while (0)
@@ -1266,15 +1333,16 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         kfn<<<grid, dim3(MF_THREADS), lds, stream>>>(                                                 \
             d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,         \
-            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_lag_blocks,                      \
-            (int)option(OPT_MF_BOUNDARY_PRIO));                                                        \
+            (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)nb_cnt,                            \
+            (int)option(OPT_MF_BOUNDARY_PRIO), (int)nb_lo);                                            \
     } while (0)
 #define BPMF_MF_LAUNCH(NS, R, TT) \
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = 256 * ntile - 16 + Kp;
             const size_t lags_wg = (size_t)4 * 256 * ntile;
-            const size_t n_blocks_w = (n_offsets + lags_wg - 1) / lags_wg;
+            const size_t nbw_lo = off_lo / lags_wg;       // (off_lo is a multiple of 4096 = of every variant's span)
+            const size_t n_blocks_w = (off_hi - off_lo + lags_wg - 1) / lags_wg;
             if (T * (n_blocks_w + 8) >= 0x7fffffffull) {
                 set_error("bpmf_mf_run_dev: grid too large");
                 return -1;
@@ -1288,7 +1356,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ, FU><<<grid_w, dim3(MF_THREADS), wl, stream>>>(    \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
         (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO), \
-        d_moveouts, d_weights, exclusive_last)
+        d_moveouts, d_weights, exclusive_last, (int)nbw_lo)
 #define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT, FU) \
     do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS, FU); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false, FU); } while (0)
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
@@ -1395,21 +1463,93 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
-    if (!rc) {            // the day of data: from the host, or from the first device of a multi-device call
-        const char* what = "H2D data";
-        MF_TRY(fanout_upload(fan, ctx, base + o_d, data, b_d, s_run, &what), what);
+    // ---- The day of data.  A peer of a multi-device call copies it from the first device; a small problem
+    // uploads it in one go.  A day-long series arrives IN PIECES on the copy stream while the first one or two
+    // template batches are computed on the lags whose windows have arrived (launches of bpmf_mf_run_dev over
+    // ranges of lag blocks, t_mf_off_lo): the 2 GB of configs[1] took 90 ms in front of the first kernel
+    // (1072.7 ms end to end against 982.9 resident, round-4 bench; BPMF makes exactly this call,
+    // similarity_search.py:526-533).
+    const bool use_mfma = mf_uses_mfma(step, L, N, std::min(TB, T), n_corr, network_sum, flags);
+    const size_t n_offsets = (n_corr - 1) * step + 1;
+    bool from_peer = false;
+    if (!rc) {
+        const char* what = "";
+        hipError_t e_ = hipSuccess;
+        from_peer = fanout_peer_copy(fan, ctx, base + o_d, b_d, s_run, &e_, &what);
+        if (from_peer && e_ != hipSuccess) fail(e_, what);
     }
-    if (!rc)
-        rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
-    auto launch = [&](size_t b) {
+    // option mf.host_piece_lags: samples of the first piece (default 131 072; the tests shrink it), 0 = off
+    const size_t PIECE0 = align_up((size_t)option(OPT_MF_HOST_PIECE_LAGS), (size_t)MF_LAGS_PER_WG);
+    const bool pieces = !rc && !from_peer && use_mfma && option(OPT_MF_COMPAT_SEQUENTIAL_CSUM) == 0 &&
+                        PIECE0 != 0 && N >= 8 * PIECE0;
+    auto launch_range = [&](size_t b, long long off_lo, long long off_hi, bool cont) {
         const size_t t0 = b * TB, nt = std::min(TB, T - t0);
         char* d_out = base + ((b & 1) ? o_out1 : o_out0);
-        int r = bpmf_mf_run_dev((const float*)(base + o_tp) + t0 * n_ch * L,
-                                (const int32_t*)(base + o_mv) + t0 * n_ch,
-                                (const float*)(base + o_w) + t0 * n_ch, (const float*)(base + o_d),
-                                step, L, N, nt, S, C, n_corr, network_sum,
-                                (flags & ~BPMF_MF_DATA_PREPARED) | BPMF_MF_DATA_PREPARED,
-                                base + o_ws, b_ws, s_run, (float*)d_out);
+        struct Scope {
+            Scope(long long lo, long long hi, bool c) { t_mf_off_lo = lo; t_mf_off_hi = hi; t_mf_continue = c; }
+            ~Scope() { t_mf_off_lo = 0; t_mf_off_hi = -1; t_mf_continue = false; }
+        } scope(off_lo, off_hi, cont);
+        return bpmf_mf_run_dev((const float*)(base + o_tp) + t0 * n_ch * L,
+                               (const int32_t*)(base + o_mv) + t0 * n_ch,
+                               (const float*)(base + o_w) + t0 * n_ch, (const float*)(base + o_d),
+                               step, L, N, nt, S, C, n_corr, network_sum,
+                               (flags & ~BPMF_MF_DATA_PREPARED) | BPMF_MF_DATA_PREPARED,
+                               base + o_ws, b_ws, s_run, (float*)d_out);
+    };
+    size_t n_streamed = 0;            // batches computed while the data arrived (their events are recorded)
+    if (pieces) {
+        n_streamed = std::min<size_t>(n_batch, 2);
+        // largest moveout of a weighted channel per streamed batch: lag block [.., B) reads data up to
+        // B + mv_max + L (+ the staging slack of its last wave)
+        long long mv_max[2] = {0, 0};
+        for (size_t b = 0; b < n_streamed; ++b) {
+            const size_t t0 = b * TB, nt = std::min(TB, T - t0);
+            bool any = false;
+            for (size_t i = t0 * n_ch; i < (t0 + nt) * n_ch; ++i)
+                if (weights[i] != 0.0f && (!any || moveouts[i] > mv_max[b])) { mv_max[b] = moveouts[i]; any = true; }
+            mv_max[b] = std::max<long long>(mv_max[b], 0);
+        }
+        // (what no piece has brought yet reads as zeros -- finite -- for the loads that run past a lag block's own windows)
+        MF_TRY(hipMemsetAsync(base + o_d, 0, b_d, s_run), "memset");
+        MF_TRY(hipEventRecord(ctx->ev_chunk[0], s_run), "event record");
+        MF_TRY(hipStreamWaitEvent(s_copy, ctx->ev_chunk[0], 0), "wait event");
+        const MfWorkspace wsd = mf_carve(base + o_ws, L, N, std::min(TB, T), n_ch);
+        size_t have = 0, piece = PIECE0;
+        long long done[2] = {0, 0};
+        int n_piece = 1;
+        while (have < N && !rc) {
+            size_t upto = std::min(N, have + piece);
+            if (N - upto < PIECE0) upto = N;                      // no sliver at the end
+            piece = std::min(piece * 2, (size_t)8 * PIECE0);      // 0.13 M, 0.26 M, 0.5 M, then 1 M samples
+            MF_TRY(hipMemcpy2DAsync(base + o_d + have * sizeof(float), N * sizeof(float), data + have, N * sizeof(float),
+                                    (upto - have) * sizeof(float), n_ch, hipMemcpyHostToDevice, s_copy), "H2D data");
+            hipEvent_t ev = ctx->ev_chunk[n_piece++ % DeviceContext::CHUNK_EVENTS];
+            MF_TRY(hipEventRecord(ev, s_copy), "event record");
+            MF_TRY(hipStreamWaitEvent(s_run, ev, 0), "wait event");
+            if (upto == N) MF_TRY(fanout_publish(fan, ctx, base + o_d, s_copy), "event record");
+            if (!rc) rc = mf_prepare_range((const float*)(base + o_d), L, N, n_ch, wsd, s_run, have, upto);
+            have = upto;
+            for (size_t b = 0; b < n_streamed && !rc; ++b) {
+                long long hi = have == N ? (long long)n_offsets
+                                         : ((long long)have - mv_max[b] - (long long)L - 2 * MF_LAGS_PER_WG) / MF_LAGS_PER_WG * MF_LAGS_PER_WG;
+                hi = std::min<long long>(hi, (long long)n_offsets);
+                if (hi <= done[b]) continue;
+                rc = launch_range(b, done[b], hi, done[b] > 0);
+                done[b] = hi;
+            }
+        }
+        for (size_t b = 0; b < n_streamed && !rc; ++b) MF_TRY(hipEventRecord(ev_batch[b & 1], s_run), "event record");
+    } else {
+        if (!rc && !from_peer) {
+            MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
+            if (!rc) MF_TRY(fanout_publish(fan, ctx, base + o_d, s_run), "event record");
+        }
+        if (!rc)
+            rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
+    }
+    auto launch = [&](size_t b) {
+        if (b < n_streamed) return 0;                            // computed while the data arrived
+        int r = launch_range(b, 0, -1, false);
         if (!r) MF_TRY(hipEventRecord(ev_batch[b & 1], s_run), "event record");
         return r;
     };

@@ -161,3 +161,33 @@ def test_virtual_device_out_of_range_is_an_error(hip_opts):
     hip_opts("debug.virtual_devices", 2)
     with pytest.raises(_lib.BpmfHipError, match="out of range"):
         matched_filter(tp, mv, w, d, 1, arch="gpu", device=[0, 2], check_zeros=False)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_bp_host_call_streams_a_long_day_in_pieces(oracle_lib, hip_opts, k):
+    """bpmf_bp_run uploads the day of features in pieces while the interior tiles of the pieces that have
+    arrived run (BpFeed, csrc/bp.hip): a series of 11 rounds of the chip is cut into 1 + 2 + 4 + 4 rounds,
+    the edge tiles follow the last piece.  Same bits as the resident engine and as the oracle; with three
+    (virtual) devices the first one streams from the host and publishes behind its last piece, the others
+    copy device to device."""
+    from seismic_bpmf_amd import BeamformerGPU, beamform
+    rng = np.random.default_rng(400 + k)
+    K, S, N = 48, 4, 1_500_000
+    f = np.abs(rng.standard_normal((S, 3, N))).astype(np.float32)
+    tau = rng.integers(-70, 900, (K, S, 2)).astype(np.int32)          # signed: edge tiles at both ends
+    wp = rng.random((S, 3, 2)).astype(np.float32)
+    ws = rng.random((K, S)).astype(np.float32)
+    ws[rng.random((K, S)) < 0.3] = 0.0
+    wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    if k > 1:
+        hip_opts("debug.virtual_devices", k)
+    mb, ma = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="strict", device_id=None if k > 1 else 0)
+    assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+    if k == 1:
+        bf = BeamformerGPU(tau, ws, device=0)
+        rb, ra = bf.run(f, wp, "max", "strict")
+        assert np.array_equal(rb.cpu().numpy(), mb) and np.array_equal(ra.cpu().numpy(), ma)
+        bf.close()
+        fb, fa = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="flexible", device_id=0)
+        ob, oa = oracle_lib.beamform(f, tau, wp, ws, "flexible", "max")
+        assert np.array_equal(fb, ob) and np.array_equal(fa, oa)
