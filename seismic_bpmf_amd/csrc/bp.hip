@@ -2577,12 +2577,27 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     const size_t b_mv = K * S * P * sizeof(int32_t), b_wsrc = K * S * sizeof(float);
     // (the plan generation is part of the key: a plan is built under the options of its creation,
     // and bpmf_set_option must not leave a plan of the previous settings in use)
-    const uint64_t key = hash_words(moveouts, b_mv, 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
-                         hash_words(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full) ^
-                         (option_generation() * 0xd6e8feb86659fd93ull);
-    const uint64_t key2 = hash_words(moveouts, b_mv, 0x165667b19e3779f9ull) +
-                          hash_words(w_sources, b_wsrc, 0x27d4eb2f165667c5ull);
+    // (tables small enough to be kept are COMPARED on a hit: their keys only pre-select, and hash one 8-byte word
+    // in 64 -- 24 MB of hashing per cfg3 call were 4 ms of a 160 ms call; larger tables are hashed in full, twice)
     const bool keep_tables = b_mv + b_wsrc <= PLAN_KEEP_BYTES;
+    auto table_hash = [&](const void* p, size_t bytes, uint64_t seed) -> uint64_t {
+        if (!keep_tables || bytes < 4096) return hash_words(p, bytes, seed);
+        uint64_t h = seed ^ bytes;
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i + 8 <= bytes; i += 512) {
+            uint64_t w8;
+            memcpy(&w8, b + i, 8);
+            h = (h ^ w8) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+        return h ^ hash_words(b + bytes - 64, 64, seed);
+    };
+    const uint64_t key = table_hash(moveouts, b_mv, 0x9e3779b97f4a7c15ull ^ (K * 31 + S * 7 + P)) ^
+                         table_hash(w_sources, b_wsrc, 0xc2b2ae3d27d4eb4full) ^
+                         (option_generation() * 0xd6e8feb86659fd93ull);
+    const uint64_t key2 = keep_tables ? key * 0x9e3779b97f4a7c15ull
+                                      : hash_words(moveouts, b_mv, 0x165667b19e3779f9ull) +
+                                        hash_words(w_sources, b_wsrc, 0x27d4eb2f165667c5ull);
     {
         std::lock_guard<std::mutex> g(g_plan_cache_mutex);
         for (auto& e : g_plan_cache) {
@@ -2650,7 +2665,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
                  o_beam = o_ws + align_up(b_ws, 256), o_arg = o_beam + align_up(b_beam, 256),
                  total = o_arg + b_arg;
     char* base = ctx->reserve_device(total);
-    if (!base) {
+    if (!base || ctx->reserve_pinned(std::min<size_t>((size_t)64 << 20, std::max<size_t>(b_f, 4096)))) {
         release_plan();
         return -2;
     }
@@ -2668,8 +2683,8 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     // uploads it from the host IN PIECES on the copy stream while the kernels of the pieces that have arrived
     // run (HostFeed: bpmf_bp_run_dev asks for the samples it is about to read) -- the upload of a whole day
     // in front of the first kernel cost cfg3 a third of its time (201.7 ms end to end against 150.6 resident,
-    // round-4 bench; BPMF makes exactly this call, template_search.py:549-558).  Pageable memory goes through the
-    // runtime's own staging (a hand-made pipeline through pinned pieces measured slower).
+    // round-4 bench; BPMF makes exactly this call, template_search.py:549-558).  The pieces travel through the
+    // context's pinned buffers (staged_upload_rows, context.h).
     struct HostFeed : BpFeed {
         DeviceContext* ctx; FanoutScope* fan; const float* host; char* d_feat; const float* d_wp; float* U;
         size_t N, C; int S, P; long long have = 0; int n_piece = 0; hipError_t err = hipSuccess; const char* what = "";
@@ -2680,9 +2695,8 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
             if (samp_end <= have) return 0;
             const size_t rows = (size_t)S * C;
             what = "H2D features";
-            // rows x [have, samp_end): a strided copy, every row N floats apart on both sides
-            err = hipMemcpy2DAsync(d_feat + (size_t)have * sizeof(float), N * sizeof(float), host + have, N * sizeof(float),
-                                   (size_t)(samp_end - have) * sizeof(float), rows, hipMemcpyHostToDevice, ctx->s_copy);
+            // rows x [have, samp_end), through the context's pinned pieces (context.h: staged_upload_rows)
+            err = staged_upload_rows(ctx, (float*)d_feat, host, rows, N, (size_t)have, (size_t)samp_end, ctx->s_copy);
             hipEvent_t ev = ctx->ev_chunk[n_piece++ % DeviceContext::CHUNK_EVENTS];
             if (err == hipSuccess) { what = "event record"; err = hipEventRecord(ev, ctx->s_copy); }
             if (err == hipSuccess) { what = "wait event"; err = hipStreamWaitEvent(stream, ev, 0); }

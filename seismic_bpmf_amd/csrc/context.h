@@ -45,6 +45,9 @@ struct DeviceContext {
     std::atomic<size_t> dev_cap{0};
     char* pinned[2] = {nullptr, nullptr};
     std::atomic<size_t> pinned_cap{0};
+    // staged_upload_rows: which pinned piece comes next, and whether a copy recorded in ev_piece[i] still reads piece i
+    size_t upload_seq = 0;
+    bool upload_inflight[2] = {false, false};
     int small_streak = 0;             // consecutive calls that needed less than a quarter of a >= 1 GiB block
 
     // At least `bytes` of device memory (256-byte aligned base).  A larger request frees the old
@@ -173,6 +176,18 @@ hipError_t fanout_publish(FanoutScope& scope, DeviceContext* ctx, const void* d_
 
 // memcpy on a few host threads (large blocks) -- dst / src pageable or pinned host memory
 void parallel_copy(char* dst, const char* src, size_t bytes);
+
+// rows x [c0, c1) of a (rows, N) float32 array in PAGEABLE host memory -> the same rows and samples of the
+// device array `d_dst`, through the context's two pinned pieces: host threads fill one piece (row segments
+// packed back to back) while the other is in flight on `stream` (hipMemcpy2DAsync, truly asynchronous from
+// pinned memory).  Why not hand the pageable pointer to the runtime: on FIRST contact with a host region it
+// page-locks the whole enclosing range before it copies -- measured 18 GB/s for a contiguous gigabyte, 1.5-5
+// GB/s for a strided piece of a larger array (tools/ubench/h2d_overlap.hip, profiles/r05_h2d_overlap.txt) --
+// and a new day of data is a new allocation; through pinned pieces the same bytes move at 53 GB/s whatever
+// the runtime has seen before, and the call returns when the last piece is IN FLIGHT (the pieces of earlier
+// calls' D2H use the same buffers: callers serialise through call_mutex).  Needs reserve_pinned() first.
+hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* host, size_t rows, size_t N, size_t c0,
+                              size_t c1, hipStream_t stream);
 
 // The context of `device`, created on first use (streams and events under the registry mutex, with
 // the device bound).  nullptr + error text when the runtime refuses.

@@ -67,6 +67,7 @@ int DeviceContext::reserve_pinned(size_t bytes)
     bytes = std::max<size_t>(bytes, 4096);
     if (pinned[0] && pinned[1] && bytes <= pinned_cap) return 0;
     drain(this);
+    upload_inflight[0] = upload_inflight[1] = false;
     for (int i = 0; i < 2; ++i) {
         if (pinned[i]) (void)hipHostFree(pinned[i]);
         pinned[i] = nullptr;
@@ -109,6 +110,57 @@ void parallel_copy(char* dst, const char* src, size_t bytes)
     for (auto& t : th) t.join();
 }
 
+hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* host, size_t rows, size_t N, size_t c0,
+                              size_t c1, hipStream_t stream)
+{
+    if (c1 <= c0 || rows == 0) return hipSuccess;
+    const size_t cap = ctx->pinned_cap.load();
+    // samples per pinned piece (whole rows' segments; a multiple of 1024 samples where the piece allows)
+    size_t w = cap / (rows * sizeof(float));
+    if (w == 0) return hipErrorInvalidValue;
+    if (w > 1024) w &= ~(size_t)1023;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
+    hipError_t e = hipSuccess;
+    size_t q = ctx->upload_seq;
+    for (size_t a = c0; a < c1 && e == hipSuccess; a += w, ++q) {
+        const size_t len = std::min(w, c1 - a);
+        char* pin = ctx->pinned[q & 1];
+        if (ctx->upload_inflight[q & 1]) {                       // the copy that last read this piece
+            if ((e = hipEventSynchronize(ctx->ev_piece[q & 1])) != hipSuccess) break;
+            ctx->upload_inflight[q & 1] = false;
+        }
+        // row segments -> the piece, packed; the rows are dealt to the threads
+        auto fill = [&](size_t r0, size_t r1) {
+            for (size_t r = r0; r < r1; ++r)
+                memcpy(pin + r * len * sizeof(float), host + r * N + a, len * sizeof(float));
+        };
+        if (rows * len * sizeof(float) < (8u << 20) || nth == 1 || rows == 1) {
+            if (rows == 1) parallel_copy(pin, (const char*)(host + a), len * sizeof(float));
+            else fill(0, rows);
+        } else {
+            std::vector<std::thread> th;
+            const size_t per = (rows + nth - 1) / nth;
+            for (size_t t = 0; t < nth; ++t) {
+                const size_t r0 = t * per, r1 = std::min(rows, r0 + per);
+                if (r0 >= r1) break;
+                try {
+                    th.emplace_back(fill, r0, r1);
+                } catch (const std::system_error&) {
+                    fill(r0, r1);
+                }
+            }
+            for (auto& t : th) t.join();
+        }
+        e = hipMemcpy2DAsync(d_dst + a, N * sizeof(float), pin, len * sizeof(float), len * sizeof(float), rows,
+                             hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_piece[q & 1], stream);
+        if (e == hipSuccess) ctx->upload_inflight[q & 1] = true;
+    }
+    ctx->upload_seq = q;
+    return e;
+}
+
 void DeviceContext::release_memory()
 {
     drain(this);
@@ -149,7 +201,16 @@ DeviceContext* device_context(int device)
     hipError_t err = hipSuccess;
     auto step = [&](hipError_t r) { if (err == hipSuccess) err = r; };
     step(hipStreamCreateWithFlags(&c->s_run, hipStreamNonBlocking));
-    step(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+    // The copy stream gets the HIGHEST priority, i.e. a hardware queue of its own class: the runtime maps streams
+    // onto a handful of hardware queues per priority, and with torch's streams, s_run and the side streams alive
+    // the copy stream otherwise lands on a queue it SHARES with a compute stream -- a piece of the day in flight
+    // then holds back the kernels queued behind it and the upload no longer runs beside them (round 5: the
+    // piecewise uploads gained nothing until this was found).
+    {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+        step(hipStreamCreateWithPriority(&c->s_copy, hipStreamNonBlocking, hi));
+    }
     for (hipStream_t& s : c->s_side) step(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     step(hipEventCreateWithFlags(&c->ev_data, hipEventDisableTiming));
     for (hipEvent_t& e : c->ev_chunk) step(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -1432,7 +1432,32 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     size_t TB = std::max<size_t>(1, batch_bytes / std::max<size_t>(row_bytes, 1));
     if (!e_b) TB = std::max<size_t>(TB, 8);   // a launch of fewer templates wastes the device
     TB = std::min(T, TB);
-    const size_t n_batch = (T + TB - 1) / TB;
+    // Batches [bt[b], bt[b + 1]): at most TB templates each, TAPERING at the end -- ..., 21, 13, 8, 5, 3, 2.
+    // The result of a batch travels to the host while the NEXT batch is computed; behind the last kernel there
+    // is nothing left to hide a transfer behind, and a transfer takes about half as long as computing the same
+    // templates: with equal batches the call ended with ~30 ms of draining (round 5: 17 batches of 31 and one
+    // of 4 -- the drain of the last full batch outlived the 8 ms of the small one).  Each batch of the taper is
+    // ~0.6 of the one before, so every drain fits behind the next kernel and the call ends with the drain of two
+    // templates.  (Every launch still has thousands of workgroups: the lag blocks.)
+    std::vector<size_t> bt;
+    {
+        std::vector<size_t> taper;                    // from the end: 2, 3, 5, 8, 13, 21, ...  while below TB
+        size_t a = 2, b2 = 3, used = 0;
+        while (a < TB && used + a <= T) {
+            taper.push_back(a);
+            used += a;
+            const size_t next = b2;                   // 2, 3, 5, 8, 13, 21: each ~1.6 x the one behind it
+            b2 = a + b2;
+            a = next;
+        }
+        const size_t rest = T - used;
+        const size_t n_full = (rest + TB - 1) / TB;
+        bt.push_back(0);
+        for (size_t i = 0; i < n_full; ++i)           // near-equal batches of at most TB
+            bt.push_back(bt.back() + rest / n_full + (i < rest % n_full ? 1 : 0));
+        for (size_t i = taper.size(); i-- > 0;) bt.push_back(bt.back() + taper[i]);
+    }
+    const size_t n_batch = bt.size() - 1;
     const size_t b_tp = T * n_ch * L * sizeof(float), b_mv = T * n_ch * sizeof(int32_t),
                  b_w = T * n_ch * sizeof(float), b_d = n_ch * N * sizeof(float),
                  b_out = TB * row_bytes, b_ws = bpmf_mf_workspace_bytes(L, N, TB, S, C);
@@ -1449,7 +1474,10 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     char* base = ctx->reserve_device(total);
     if (!base) return -2;
     // (a pinned piece never needs to be larger than one batch of output)
-    if (int prc = ctx->reserve_pinned(std::min(PIECE, std::max<size_t>(b_out, 4096)))) return prc;
+    // (... nor, for the upload of the day through the same pieces, than the day of data)
+    if (int prc = ctx->reserve_pinned(std::max(std::min(PIECE, std::max<size_t>(b_out, 4096)),
+                                               std::min<size_t>((size_t)64 << 20, std::max<size_t>(b_d, 4096)))))
+        return prc;
     char* const* pinned = ctx->pinned;
     hipStream_t s_run = ctx->s_run, s_copy = ctx->s_copy;
     hipEvent_t* ev_batch = ctx->ev_batch;
@@ -1464,8 +1492,8 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
     if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
     // ---- The day of data.  A peer of a multi-device call copies it from the first device; a small problem
-    // uploads it in one go.  A day-long series arrives IN PIECES on the copy stream while the first one or two
-    // template batches are computed on the lags whose windows have arrived (launches of bpmf_mf_run_dev over
+    // uploads it in one go.  A day-long series arrives IN PIECES on the copy stream while the first
+    // template batch is computed on the lags whose windows have arrived (launches of bpmf_mf_run_dev over
     // ranges of lag blocks, t_mf_off_lo): the 2 GB of configs[1] took 90 ms in front of the first kernel
     // (1072.7 ms end to end against 982.9 resident, round-4 bench; BPMF makes exactly this call,
     // similarity_search.py:526-533).
@@ -1483,7 +1511,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     const bool pieces = !rc && !from_peer && use_mfma && option(OPT_MF_COMPAT_SEQUENTIAL_CSUM) == 0 &&
                         PIECE0 != 0 && N >= 8 * PIECE0;
     auto launch_range = [&](size_t b, long long off_lo, long long off_hi, bool cont) {
-        const size_t t0 = b * TB, nt = std::min(TB, T - t0);
+        const size_t t0 = bt[b], nt = bt[b + 1] - bt[b];
         char* d_out = base + ((b & 1) ? o_out1 : o_out0);
         struct Scope {
             Scope(long long lo, long long hi, bool c) { t_mf_off_lo = lo; t_mf_off_hi = hi; t_mf_continue = c; }
@@ -1498,12 +1526,16 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     };
     size_t n_streamed = 0;            // batches computed while the data arrived (their events are recorded)
     if (pieces) {
-        n_streamed = std::min<size_t>(n_batch, 2);
+        // ONE batch is computed behind the arriving pieces (measured, round 5: with two, both output buffers are
+        // busy when the last piece has landed and batch 2 cannot start before batch 0 has been drained -- 23 ms of
+        // idle device in the kernel trace of a cfg2 call; one batch of ~1 GB of output computes for longer than the
+        // day takes to arrive, so it hides the whole upload, and batch 1 follows it without a gap)
+        n_streamed = 1;
         // largest moveout of a weighted channel per streamed batch: lag block [.., B) reads data up to
         // B + mv_max + L (+ the staging slack of its last wave)
         long long mv_max[2] = {0, 0};
         for (size_t b = 0; b < n_streamed; ++b) {
-            const size_t t0 = b * TB, nt = std::min(TB, T - t0);
+            const size_t t0 = bt[b], nt = bt[b + 1] - bt[b];
             bool any = false;
             for (size_t i = t0 * n_ch; i < (t0 + nt) * n_ch; ++i)
                 if (weights[i] != 0.0f && (!any || moveouts[i] > mv_max[b])) { mv_max[b] = moveouts[i]; any = true; }
@@ -1521,8 +1553,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
             size_t upto = std::min(N, have + piece);
             if (N - upto < PIECE0) upto = N;                      // no sliver at the end
             piece = std::min(piece * 2, (size_t)8 * PIECE0);      // 0.13 M, 0.26 M, 0.5 M, then 1 M samples
-            MF_TRY(hipMemcpy2DAsync(base + o_d + have * sizeof(float), N * sizeof(float), data + have, N * sizeof(float),
-                                    (upto - have) * sizeof(float), n_ch, hipMemcpyHostToDevice, s_copy), "H2D data");
+            MF_TRY(staged_upload_rows(ctx, (float*)(base + o_d), data, n_ch, N, have, upto, s_copy), "H2D data");
             hipEvent_t ev = ctx->ev_chunk[n_piece++ % DeviceContext::CHUNK_EVENTS];
             MF_TRY(hipEventRecord(ev, s_copy), "event record");
             MF_TRY(hipStreamWaitEvent(s_run, ev, 0), "wait event");
@@ -1541,8 +1572,14 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
         for (size_t b = 0; b < n_streamed && !rc; ++b) MF_TRY(hipEventRecord(ev_batch[b & 1], s_run), "event record");
     } else {
         if (!rc && !from_peer) {
-            MF_TRY(hipMemcpyAsync(base + o_d, data, b_d, hipMemcpyHostToDevice, s_run), "H2D data");
-            if (!rc) MF_TRY(fanout_publish(fan, ctx, base + o_d, s_run), "event record");
+            // (through the pinned pieces on the copy stream: the runtime's own path page-locks a host region it
+            // has not seen before -- a new day is a new array -- at a third of the rate, context.h)
+            MF_TRY(hipEventRecord(ctx->ev_chunk[0], s_run), "event record");        // behind the small uploads above
+            MF_TRY(hipStreamWaitEvent(s_copy, ctx->ev_chunk[0], 0), "wait event");
+            MF_TRY(staged_upload_rows(ctx, (float*)(base + o_d), data, n_ch, N, 0, N, s_copy), "H2D data");
+            if (!rc) MF_TRY(fanout_publish(fan, ctx, base + o_d, s_copy), "event record");
+            MF_TRY(hipEventRecord(ctx->ev_chunk[1], s_copy), "event record");
+            MF_TRY(hipStreamWaitEvent(s_run, ctx->ev_chunk[1], 0), "wait event");
         }
         if (!rc)
             rc = bpmf_mf_prepare_data_dev((const float*)(base + o_d), L, N, S, C, base + o_ws, b_ws, s_run);
@@ -1561,7 +1598,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     for (size_t b = 0; b < n_batch && !rc; ++b) {
         if (b + 1 < n_batch) rc = launch(b + 1);   // its buffer was drained one iteration ago
         if (rc) break;
-        const size_t t0 = b * TB, nt = std::min(TB, T - t0), bytes = nt * row_bytes;
+        const size_t t0 = bt[b], nt = bt[b + 1] - bt[b], bytes = nt * row_bytes;
         const char* d_out = base + ((b & 1) ? o_out1 : o_out0);
         char* h_out = (char*)cc_out + t0 * row_bytes;
         MF_TRY(hipStreamWaitEvent(s_copy, ev_batch[b & 1], 0), "wait event");
@@ -1589,7 +1626,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     (void)hipStreamSynchronize(s_run);
     (void)hipStreamSynchronize(s_copy);
     if (verbose)
-        fprintf(stderr, "[bpmf] mf_run: %zu batches of %zu templates, %.3f s after setup: waiting for the "
+        fprintf(stderr, "[bpmf] mf_run: %zu batches of at most %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
     return rc;
