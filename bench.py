@@ -774,6 +774,29 @@ def main():
                                     "equals_resident_result": bool(np.array_equal(hb, beam.cpu().numpy()) and
                                                                    np.array_equal(ha, arg.cpu().numpy()))}
             del h_f, hb, ha
+        if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
+            # untimed extra: the stage in FRONT of the beamformer in the vanilla workflow -- saturated envelopes of
+            # the day (BPMF/template_search.py:1525-1617: analytic signal, per-channel median / MAD, standardise,
+            # clip) on configs[2]'s 60 channels x 4.32 M samples, resident in HBM
+            from seismic_bpmf_amd import features as ft
+            raw = torch.randn((bcfg["S"], bcfg["C"], Nb), device=device, generator=torch.Generator(device=device).manual_seed(9))
+            ft.saturated_envelopes(raw, device=local_rank)
+            torch.cuda.synchronize()
+            t_env = []
+            for stage in (lambda: ft.envelope(raw, device=local_rank), lambda: ft.saturated_envelopes(raw, device=local_rank)):
+                best = float("inf")
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    stage()
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t0) * 1e3)
+                t_env.append(best)
+            bp_obj["features"] = {"workload": f"saturated_envelopes of {bcfg['S']} x {bcfg['C']} channels x {Nb} samples (float32 in, float32 out)",
+                                  "envelope_ms": round(t_env[0], 2), "saturated_envelopes_ms": round(t_env[1], 2),
+                                  "fraction_of_a_bp_step": round(t_env[1] / (bp_dt / args.steps * 1e3), 3),
+                                  "how": "Hilbert transform by a float64 real-input FFT pair (hipFFT behind torch.fft), median / MAD by one radix-select launch"}
+            del raw
+            torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not args.skip_dense:
             # untimed extras: DENSE station weights -- BASELINE's literal "x 20 / x 40 stations", what
             # _weights_sources_closest returns for num_closest_stations >= n_stations

@@ -65,7 +65,8 @@ int bpmf_profile_get_device(int which_kernel, int launch_index);
  * turns (the reference's counterpart: the third-party back-ends allocate and free per call,
  * BPMF/similarity_search.py:526-533, BPMF/template_search.py:549-558).  bpmf_release_device_memory
  * gives the working set and the pinned pieces back (device < 0: every device; waits for a running
- * call); bpmf_device_memory_held reports what is held right now.  The *_dev entry points hold nothing. */
+ * call); bpmf_device_memory_held reports what is held right now; option host.cache_limit_mb (0 = no limit) gives a
+ * working set above the limit back at the end of the call that needed it.  The *_dev entry points hold nothing. */
 int bpmf_release_device_memory(int device);
 int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_bytes);
 

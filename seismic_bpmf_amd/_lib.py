@@ -186,16 +186,22 @@ def profile_enable(on=True):
     lib().bpmf_profile_enable(1 if on else 0)
 
 
-def profile_devices(which):
-    """The device of every logged launch of dominant kernel `which` (same order as profile_times_ms)."""
-    return [lib().bpmf_profile_get_device(which, i) for i in range(lib().bpmf_profile_count(which))]
-
-
-def profile_times_ms(which):
-    """Durations (ms) of every logged launch of dominant kernel `which` since profile_enable."""
+def _closed_launches(which):
+    """Indices of the logged launches of `which` whose stop edge was recorded, with their durations (ms).  A launch
+    whose pair was opened but never closed (the call failed between the two edges) is skipped, not an error."""
     out = []
     for i in range(lib().bpmf_profile_count(which)):
         ms = C.c_float(0.0)
-        check(lib().bpmf_profile_get_ms(which, i, C.byref(ms)), "bpmf_profile_get_ms")
-        out.append(ms.value)
+        if lib().bpmf_profile_get_ms(which, i, C.byref(ms)) == 0:
+            out.append((i, ms.value))
     return out
+
+
+def profile_devices(which):
+    """The device of every closed launch of dominant kernel `which` (same order as profile_times_ms)."""
+    return [lib().bpmf_profile_get_device(which, i) for i, _ in _closed_launches(which)]
+
+
+def profile_times_ms(which):
+    """Durations (ms) of every logged (and closed) launch of dominant kernel `which` since profile_enable."""
+    return [ms for _, ms in _closed_launches(which)]

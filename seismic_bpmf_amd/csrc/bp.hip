@@ -2744,6 +2744,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     if (pl->side_stream) (void)hipStreamSynchronize(pl->side_stream);
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
+    ctx->trim_after_call();
     return rc;
 }
 

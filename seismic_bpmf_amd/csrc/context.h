@@ -59,6 +59,10 @@ struct DeviceContext {
     int reserve_pinned(size_t bytes);
     // Frees the device working set and the pinned pieces (the streams and events stay).
     void release_memory();
+    // End of a host-pointer call (its streams drained, call_mutex held): option host.cache_limit_mb -- a working
+    // set above the limit goes back to the allocator right away (a workflow that makes ONE large host-pointer call
+    // and then runs on torch-allocated tensors would otherwise strand it outside torch's allocator).
+    void trim_after_call();
 };
 
 // The day of data of one *_run_multi call on several devices (option multi.peer_fanout): the FIRST device

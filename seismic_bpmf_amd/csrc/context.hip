@@ -161,6 +161,12 @@ hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* hos
     return e;
 }
 
+void DeviceContext::trim_after_call()
+{
+    const long limit_mb = option(OPT_HOST_CACHE_LIMIT_MB);
+    if (limit_mb > 0 && dev_cap.load() > (size_t)limit_mb << 20) release_memory();
+}
+
 void DeviceContext::release_memory()
 {
     drain(this);

@@ -1629,6 +1629,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
         fprintf(stderr, "[bpmf] mf_run: %zu batches of at most %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
+    ctx->trim_after_call();
     return rc;
 }
 

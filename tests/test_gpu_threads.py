@@ -174,3 +174,25 @@ def test_host_calls_keep_and_release_their_working_set():
     assert _lib.device_memory_held(0) == (0, 0)
     assert np.array_equal(matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False), first)
     assert _lib.device_memory_held(0)[0] > 0
+
+
+def test_cache_limit_gives_a_large_working_set_back_at_the_end_of_the_call(hip_opts):
+    """Option host.cache_limit_mb: a host-pointer call whose device working set exceeds the limit frees it when
+    it ends (a workflow that makes ONE large host-pointer call and continues on torch-allocated tensors must not
+    strand gigabytes outside torch's allocator); package-level release_device_memory / device_memory_held."""
+    import seismic_bpmf_amd as sb
+    rng = np.random.default_rng(10)
+    tp = rng.standard_normal((3, 2, 2, 64)).astype(np.float32)
+    d = rng.standard_normal((2, 2, 400_000)).astype(np.float32)      # ~25 MB of working set
+    mv = np.zeros((3, 2, 2), np.int32)
+    w = np.ones((3, 2, 2), np.float32)
+    sb.release_device_memory(0)
+    first = sb.matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert sb.device_memory_held(0)[0] > 8 << 20
+    hip_opts("host.cache_limit_mb", 8)
+    again = sb.matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert sb.device_memory_held(0) == (0, 0) and np.array_equal(first, again)
+    hip_opts("host.cache_limit_mb", 4096)                              # a limit the call stays under: kept
+    sb.matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert sb.device_memory_held(0)[0] > 8 << 20
+    sb.release_device_memory(0)

@@ -350,3 +350,23 @@ def test_geodesic_distance_properties():
         m = d(lon_c, 0.0, [lon_c, lon_c], [lat_c, lat_c + 1.0])
         signed = np.sign([lat_c, lat_c + 1.0]) * m           # (arcs south of the equator count negative)
         assert abs(d(lon_c, lat_c, lon_c, lat_c + 1.0)[0] - abs(signed[1] - signed[0])) < 1e-5
+
+
+def test_geodesic_antipodal_fallback_keeps_every_other_distance_exact():
+    """geodesic_distance_m(nonconverged="antipodal"): the pairs Vincenty's iteration cannot finish get
+    pi (a + b) / 2 (within 17 km of any geodesic between nearly antipodal points), every other pair keeps its
+    exact length, and compute_location_uncertainty no longer fails on such a source
+    (BPMF/template_search.py:1269-1333 calls cartopy, which always returns a length)."""
+    import pytest
+    from seismic_bpmf_amd import postprocess as pp
+    lon = np.array([10.0, 179.9, -30.0])
+    lat = np.array([5.0, 0.05, 40.0])
+    with pytest.raises(ValueError):
+        pp.geodesic_distance_m(0.0, 0.0, lon, lat)
+    d = pp.geodesic_distance_m(0.0, 0.0, lon, lat, nonconverged="antipodal")
+    exact = pp.geodesic_distance_m(0.0, 0.0, lon[[0, 2]], lat[[0, 2]])
+    assert np.array_equal(d[[0, 2]], exact)
+    assert abs(d[1] - np.pi * (pp.WGS84_A + (1 - pp.WGS84_F) * pp.WGS84_A) / 2) < 1e-6
+    assert 20_003_900 < d[1] < 20_037_600
+    hunc, vunc = pp.compute_location_uncertainty(0.0, 0.0, 5.0, np.array([1.0, 1e-9, 1.0]), lon, lat, np.array([4.0, 9.0, 8.0]))
+    assert np.isfinite(hunc) and np.isfinite(vunc)
