@@ -640,7 +640,10 @@ def main():
     mf_shapes = None
     if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
         mf_shapes = {}
-        for name, (T2, S2, C2, L2, N2) in (("configs0", (4, 8, 3, 128, 180_000)), ("day_L128", (50, 20, 3, 128, 8_640_000))):
+        # ("tutorial": the shape of the reference's own tutorial, /root/reference/tutorial/notebooks/BPMF_parameters.cfg:7-16 --
+        # 10 templates of 8 s at 25 Hz on 8 stations x 3 components, one day at 25 Hz)
+        for name, (T2, S2, C2, L2, N2) in (("configs0", (4, 8, 3, 128, 180_000)), ("day_L128", (50, 20, 3, 128, 8_640_000)),
+                                           ("tutorial", (10, 8, 3, 200, 2_160_000))):
             g2 = torch.Generator(device=device)
             g2.manual_seed(77)
             d2 = torch.randn((S2, C2, N2), device=device, generator=g2)

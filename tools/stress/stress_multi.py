@@ -35,6 +35,9 @@ def bind(path):
     lib = C.CDLL(path)
     f, i, sz = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_size_t
     lib.bpmf_last_error.restype = C.c_char_p
+    if hasattr(lib, "bpmf_set_option"):
+        lib.bpmf_set_option.restype = C.c_int
+        lib.bpmf_set_option.argtypes = [C.c_char_p, C.c_long]
     lib.bpmf_mf_run_multi.restype = C.c_int
     lib.bpmf_mf_run_multi.argtypes = [f, i, f, f, sz, sz, sz, sz, sz, sz, sz, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_int), f]
@@ -52,6 +55,22 @@ def child(args):
     crash.crash_bt_install(f"proc{args.child}".encode())
     lib = bind(args.lib)
     fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    # --virtual K (round 5): K logical devices, each with its own context and HOST THREAD inside the *_run_multi
+    # entry points (option debug.virtual_devices) -- the device lists below then name DISTINCT devices in random
+    # orders, so that every call starts threads, hands the day from the first device to the others and merges
+    nv = args.virtual
+    if nv:
+        assert lib.bpmf_set_option(b"debug.virtual_devices", nv) == 0
+        assert lib.bpmf_set_option(b"mf.host_piece_lags", 4096) == 0       # the small cases cross piece boundaries too
+        assert lib.bpmf_set_option(b"bp.host_piece_samples", 1024) == 0
+
+    def device_list(rng, n_dev):
+        if not nv:
+            return [0] * n_dev
+        devs = [int(x) for x in rng.permutation(nv)[: min(n_dev, nv)]]
+        if rng.random() < 0.3:
+            devs.append(devs[0])           # a device listed twice: two blocks on one of the threads
+        return devs
 
     def ptr(a, t):
         return a.ctypes.data_as(t)
@@ -97,7 +116,7 @@ def child(args):
                 w = rng.random((T, S, Cc)).astype(np.float32)
                 for ns in (True, False):
                     want = mf(tp, mv, w, data, ns, [0])
-                    got = mf(tp, mv, w, data, ns, [0] * n_dev)
+                    got = mf(tp, mv, w, data, ns, device_list(rng, n_dev))
                     if not np.array_equal(got, want):
                         raise AssertionError(f"MF mismatch proc {args.child} thread {q} it {it}")
                 K, Sb = int(rng.integers(1, 500)), int(rng.integers(1, 9))
@@ -116,7 +135,7 @@ def child(args):
                     oob = int(j % 2)
                     if j not in want:
                         want[j] = bp(f, tau, wp, ws, oob, [0])
-                    devs = [0] * n_dev if rng.random() < 0.7 else [0]
+                    devs = device_list(rng, n_dev) if rng.random() < 0.7 else [0]
                     mb, ma = bp(f, tau, wp, ws, oob, devs)
                     if not (np.array_equal(mb, want[j][0]) and np.array_equal(ma, want[j][1])):
                         raise AssertionError(f"BP mismatch proc {args.child} thread {q} it {it}")
@@ -146,6 +165,9 @@ def main():
     ap.add_argument("--no-torch", action="store_true")
     ap.add_argument("--timeout", type=int, default=1500)
     ap.add_argument("--child", type=int, default=-1)
+    ap.add_argument("--virtual", type=int, default=0,
+                    help="debug.virtual_devices = K in every worker: the multi-device calls start one host thread per "
+                         "logical device (0 = the same GPU listed 2-6 times: one thread)")
     ap.add_argument("--hogs", type=int, default=0,
                     help="busy-loop processes beside the workers (CPU oversubscription: what 8 xdist workers x 16 idle-"
                          "spinning OpenMP threads of the oracle did to the round-3 sessions that crashed)")
@@ -160,7 +182,8 @@ def main():
     for p in range(args.procs):
         log = open(os.path.join(args.out, f"proc{p}.log"), "w")
         cmd = [sys.executable, os.path.abspath(__file__), "--child", str(p), "--threads", str(args.threads),
-               "--calls", str(args.calls), "--seed", str(args.seed), "--scale", str(args.scale), "--lib", args.lib]
+               "--calls", str(args.calls), "--seed", str(args.seed), "--scale", str(args.scale), "--lib", args.lib,
+               "--virtual", str(args.virtual)]
         if args.no_torch:
             cmd.append("--no-torch")
         procs.append((subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
