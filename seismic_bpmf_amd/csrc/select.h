@@ -33,15 +33,22 @@ __device__ __forceinline__ bool sel_element(float v, float centre, unsigned& key
     return true;
 }
 
+// What a loaded element is before it enters the series: nothing by default; the MAD threshold replaces exact
+// zeros by white noise on the fly (stats.hip: MadFill) instead of selecting on a filled copy of the matrix.
+struct SelNoFix {
+    __device__ __forceinline__ float operator()(float v, long long) const { return v; }
+};
+
 // k-th smallest (0-based) key of the series x[0 .. len), counting only the elements that belong to it,
 // and -- when `next` is not null -- the (k+1)-th as well, found in the same three passes whenever it
 // shares the k-th one's first 22 key bits (it almost always does; *next_ok = 0 otherwise and the
 // caller runs a second select).  hist: SEL_BINS counters in LDS; sel: four words of LDS for the
 // hand-over between levels.  The element loop is unrolled by 8 with the loads in front: one
 // workgroup streams a series at memory speed instead of one cache line per wave and round trip.
-template <bool DEV, bool SKIPZ = false>
+template <bool DEV, bool SKIPZ = false, class Fix = SelNoFix>
 __device__ unsigned window_select(const float* __restrict__ x, long long len, float centre, unsigned rank,
-                                  unsigned* hist, unsigned* sel, unsigned* next = nullptr, int* next_ok = nullptr)
+                                  unsigned* hist, unsigned* sel, unsigned* next = nullptr, int* next_ok = nullptr,
+                                  Fix fix = Fix())
 {
     const int tid = threadIdx.x;
     unsigned prefix = 0;          // the key bits fixed so far (right-aligned)
@@ -65,9 +72,9 @@ __device__ unsigned window_select(const float* __restrict__ x, long long len, fl
 #pragma unroll
             for (int e = 0; e < UNR; ++e) v[e] = x[i + (long long)e * SEL_THREADS];
 #pragma unroll
-            for (int e = 0; e < UNR; ++e) count_one(v[e]);
+            for (int e = 0; e < UNR; ++e) count_one(fix(v[e], i + (long long)e * SEL_THREADS));
         }
-        for (; i < len; i += SEL_THREADS) count_one(x[i]);
+        for (; i < len; i += SEL_THREADS) count_one(fix(x[i], i));
         __syncthreads();
         if (tid < 64) {
             // lane l owns bins [32 l, 32 l + 32): its total, an inclusive scan over the lanes, then
@@ -123,16 +130,16 @@ __device__ unsigned window_select(const float* __restrict__ x, long long len, fl
 }
 
 // np.median of the `count` elements that belong to the series (count = len unless SKIPZ)
-template <bool DEV, bool SKIPZ = false>
+template <bool DEV, bool SKIPZ = false, class Fix = SelNoFix>
 __device__ float window_median(const float* __restrict__ x, long long len, long long count, float centre,
-                               unsigned* hist, unsigned* sel)
+                               unsigned* hist, unsigned* sel, Fix fix = Fix())
 {
     if (count & 1)
-        return key_f32(window_select<DEV, SKIPZ>(x, len, centre, (unsigned)(count / 2), hist, sel));
+        return key_f32(window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2), hist, sel, nullptr, nullptr, fix));
     unsigned hi_key = 0;
     int ok = 0;
-    const unsigned lo_key = window_select<DEV, SKIPZ>(x, len, centre, (unsigned)(count / 2 - 1), hist, sel, &hi_key, &ok);
-    if (!ok) hi_key = window_select<DEV, SKIPZ>(x, len, centre, (unsigned)(count / 2), hist, sel);
+    const unsigned lo_key = window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2 - 1), hist, sel, &hi_key, &ok, fix);
+    if (!ok) hi_key = window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2), hist, sel, nullptr, nullptr, fix);
     return (key_f32(lo_key) + key_f32(hi_key)) / 2.0f;   // float32 mean of the two middle values (exact halving)
 }
 

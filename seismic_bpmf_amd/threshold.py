@@ -33,7 +33,7 @@ class ThresholdGPU:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.lib = _lib.lib()
         self._ws = None
-        self.mad_workspace_limit = 4 << 30      # bytes of zero-filled copy per call of the MAD threshold
+        self.mad_workspace_limit = 4 << 30      # bytes of workspace per call of the MAD threshold (the rank tables: n / 32 bytes per row)
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
@@ -91,10 +91,11 @@ class ThresholdGPU:
         if white_noise is None:
             white_noise = np.random.normal(size=n).astype("float32")
         wn = t.as_tensor(np.ascontiguousarray(white_noise, dtype=np.float32), device=self.device)
-        # rows go through the library in chunks: at most 65535 per call (its gridDim.y), and few enough
-        # that the zero-filled copy of the chunk in the workspace (rows * n floats) stays under
+        # rows go through the library in chunks: at most 65535 per call (its gridDim.y), and few enough that the
+        # workspace -- since round 5 only the zero-rank tables, n / 32 bytes per row: the zeros are replaced where
+        # the medians read them, there is no filled copy of the matrix any more -- stays under
         # `mad_workspace_limit` bytes (4 GiB by default; one row always goes)
-        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, 4 * n))))
+        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, n // 16))))
         nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(chunk, n, W, shift)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
