@@ -2421,8 +2421,6 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
         int rc = 0;
         const bool have_edge = lo_s > 0 || hi_s < (long long)N;
         hipStream_t es = stream;          // edge tiles: on the side stream, beside the interior kernels
-        // (a day arriving in pieces: the edge tiles -- both ends of the series -- run behind the interior
-        // pieces, on the launch stream, once everything is there)
         if (have_edge && pl->side_stream && !feed_pieces) {
             BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
             BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
@@ -2443,8 +2441,25 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
             edge(0, lo_s);
             edge(hi_s, (long long)N);
         };
-        if (!feed_pieces) run_edges();
-        if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
+        // (a day arriving in pieces: the edge tiles need both ends of the series -- they are forked to the side
+        // stream in front of the LAST interior piece, once everything has been asked for, and run beside it)
+        bool edges_done = false;
+        auto edges_of_a_fed_day = [&]() -> int {
+            edges_done = true;
+            if (int r = feed->need((long long)N, stream)) return r;
+            if (have_edge && pl->side_stream) {
+                BPMF_HIP_CHECK(hipEventRecord(pl->ev_fork, stream));
+                BPMF_HIP_CHECK(hipStreamWaitEvent(pl->side_stream, pl->ev_fork, 0));
+                es = pl->side_stream;
+            }
+            run_edges();
+            if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
+            return rc;
+        };
+        if (!feed_pieces) {
+            run_edges();
+            if (!rc && es != stream) BPMF_HIP_CHECK(hipEventRecord(pl->ev_join, es));
+        }
         // The interior tiles: one launch per class -- or, while the day is still arriving from the host
         // (feed_pieces), one launch per class and PIECE of the range, each behind the piece of features it
         // reads.  A piece is a whole number of rounds of the chip (256 workgroups of 512 samples, one per CU):
@@ -2458,7 +2473,8 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
                 b = std::min(hi_s, a + piece);
                 if (hi_s - b < piece0) b = hi_s;          // no sliver at the end
                 piece = std::min<long long>(piece * 2, 4 * piece0);
-                rc = feed->need(std::min<long long>((long long)N, b + std::max(pl->tmax_all, 0) + 8 + 1024), stream);
+                if (b == hi_s) rc = edges_of_a_fed_day();
+                else rc = feed->need(std::min<long long>((long long)N, b + std::max(pl->tmax_all, 0) + 8 + 1024), stream);
             }
             for (int c = 0; c < pl->n_classes && !rc; ++c) {
                 const BpFastClass& fc = pl->cls[c];
@@ -2468,10 +2484,7 @@ extern "C" int bpmf_bp_run_dev(const bpmf_bp_plan* pl, const float* d_features,
             }
             a = b;
         }
-        if (feed_pieces && !rc) {
-            rc = feed->need((long long)N, stream);
-            if (!rc) run_edges();
-        }
+        if (feed_pieces && !rc && !edges_done) rc = edges_of_a_fed_day();     // (no interior tile at all)
         if (!rc && es != stream) BPMF_HIP_CHECK(hipStreamWaitEvent(stream, pl->ev_join, 0));
         if (!rc && rows > 1) {
             bp_merge_splits_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(
