@@ -48,7 +48,7 @@ struct SelNoFix {
 template <bool DEV, bool SKIPZ = false, class Fix = SelNoFix>
 __device__ unsigned window_select(const float* __restrict__ x, long long len, float centre, unsigned rank,
                                   unsigned* hist, unsigned* sel, unsigned* next = nullptr, int* next_ok = nullptr,
-                                  Fix fix = Fix())
+                                  Fix fix = Fix(), int* nan_seen = nullptr)
 {
     const int tid = threadIdx.x;
     unsigned prefix = 0;          // the key bits fixed so far (right-aligned)
@@ -60,7 +60,13 @@ __device__ unsigned window_select(const float* __restrict__ x, long long len, fl
         const int shift = 32 - done - nbits;
         for (int b = tid; b < SEL_BINS; b += SEL_THREADS) hist[b] = 0;
         __syncthreads();
+        // `nan_seen` (LDS, zeroed by the caller): raised when an element of the series is a NaN -- noticed on the
+        // first level's pass over the elements, which reads them all anyway (np.median of such a series is NaN;
+        // a separate pass just to look for one cost the MAD threshold a seventh of its time)
+        const bool look = nan_seen != nullptr && level == 0;
+        int bad = 0;
         auto count_one = [&](float v) {
+            if (look) bad |= v != v;
             unsigned k;
             if (!sel_element<DEV, SKIPZ>(v, centre, k)) return;
             if (done == 0 || (k >> (32 - done)) == prefix)
@@ -75,6 +81,7 @@ __device__ unsigned window_select(const float* __restrict__ x, long long len, fl
             for (int e = 0; e < UNR; ++e) count_one(fix(v[e], i + (long long)e * SEL_THREADS));
         }
         for (; i < len; i += SEL_THREADS) count_one(fix(x[i], i));
+        if (bad) *nan_seen = 1;
         __syncthreads();
         if (tid < 64) {
             // lane l owns bins [32 l, 32 l + 32): its total, an inclusive scan over the lanes, then
@@ -132,13 +139,13 @@ __device__ unsigned window_select(const float* __restrict__ x, long long len, fl
 // np.median of the `count` elements that belong to the series (count = len unless SKIPZ)
 template <bool DEV, bool SKIPZ = false, class Fix = SelNoFix>
 __device__ float window_median(const float* __restrict__ x, long long len, long long count, float centre,
-                               unsigned* hist, unsigned* sel, Fix fix = Fix())
+                               unsigned* hist, unsigned* sel, Fix fix = Fix(), int* nan_seen = nullptr)
 {
     if (count & 1)
-        return key_f32(window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2), hist, sel, nullptr, nullptr, fix));
+        return key_f32(window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2), hist, sel, nullptr, nullptr, fix, nan_seen));
     unsigned hi_key = 0;
     int ok = 0;
-    const unsigned lo_key = window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2 - 1), hist, sel, &hi_key, &ok, fix);
+    const unsigned lo_key = window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2 - 1), hist, sel, &hi_key, &ok, fix, nan_seen);
     if (!ok) hi_key = window_select<DEV, SKIPZ, Fix>(x, len, centre, (unsigned)(count / 2), hist, sel, nullptr, nullptr, fix);
     return (key_f32(lo_key) + key_f32(hi_key)) / 2.0f;   // float32 mean of the two middle values (exact halving)
 }

@@ -191,3 +191,63 @@ def test_bp_host_call_streams_a_long_day_in_pieces(oracle_lib, hip_opts, k):
         fb, fa = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="flexible", device_id=0)
         ob, oa = oracle_lib.beamform(f, tau, wp, ws, "flexible", "max")
         assert np.array_equal(fb, ob) and np.array_equal(fa, oa)
+
+
+def test_configs3_sized_day_on_8_virtual_devices(oracle_lib, hip_opts):
+    """BASELINE configs[3]'s day -- 40 stations x 3 components x 8 640 000 samples, 4.15 GB -- through
+    bpmf_mf_run_multi on EIGHT logical devices (96 of the 5000 templates, ragged 10-closest-station weights: 12
+    +- per device): the first device streams the day in pieces, seven copy it device to device, eight host threads
+    drain their rows into one (96, n_corr) array.  Equal, bit for bit, to the same call on one device; oracle
+    windows on three templates."""
+    import torch
+    from seismic_bpmf_amd import _lib, matched_filter, synthetic as syn
+    T, S, C, L, N = 96, 40, 3, 256, 8_640_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    data = torch.randn((S, C, N), device="cuda", generator=g).cpu().numpy()
+    inp = syn.make_mf_inputs(T, S, C, L, 30_000, seed=8, n_events=0)
+    tmpl, mv, w = inp["templates"], (inp["moveouts"] * 10).astype(np.int32), inp["weights"].copy()
+    rng = np.random.default_rng(9)
+    for t in range(T):                                   # 10 closest stations weighted, every seventh template all 40
+        if t % 7:
+            w[t, np.argsort(mv[t, :, 0])[10:], :] = 0.0
+    w /= w.reshape(T, -1).sum(axis=1)[:, None, None]
+    one = matched_filter(tmpl, mv, w, data, 1, arch="gpu", device=0, check_zeros=False)
+    hip_opts("debug.virtual_devices", 8)
+    multi = matched_filter(tmpl, mv, w, data, 1, arch="gpu", device=None, check_zeros=False)
+    assert np.array_equal(multi, one)
+    del multi
+    for t in (0, 41, T - 1):
+        for i0 in rng.integers(0, N - L - 8000, 2):
+            i0 = int(i0)
+            seg = data[:, :, i0:i0 + 1500 + L - 1 + int(mv[t].max())]
+            want = oracle_lib.matched_filter(tmpl[t:t + 1], mv[t:t + 1], w[t:t + 1], np.ascontiguousarray(seg), 1)[0, :1500]
+            assert np.array_equal(one[t, i0:i0 + 1500], want), (t, i0)
+    _lib.release_device_memory(-1)
+
+
+def test_configs4_sized_day_on_8_virtual_devices(oracle_lib, hip_opts):
+    """BASELINE configs[4]'s day of features -- 40 stations x 3 components x 8 640 000 samples -- through
+    bpmf_bp_run_multi on eight logical devices, 8 x 2 000 sources (10 closest of 40 stations) standing in for the
+    8 x 125 000 of the full grid (tests/test_gpu_shares.py runs one such share at full size): streamed upload on the first device, peer copies on seven, eight plans,
+    the threaded host merge over 8.64 M samples with global source ids.  Equal to one device; an oracle window."""
+    import torch
+    from seismic_bpmf_amd import _lib, beamform, synthetic as syn
+    S, C, P, N = 40, 3, 2, 8_640_000
+    geo = syn.make_bp_geometry((40, 40, 10), S, P, 100.0, seed=5)            # 16 000 sources
+    tau, ws = geo["moveouts"], geo["weights_sources"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    feat = torch.randn((S, C, N), device="cuda", generator=g).abs_().cpu().numpy()
+    wp = syn.phase_weights(S, C, P)
+    ob, oa = beamform(feat, tau, wp, ws, device="gpu", device_id=0)
+    hip_opts("debug.virtual_devices", 8)
+    mb, ma = beamform(feat, tau, wp, ws, device="gpu", device_id=None)
+    assert np.array_equal(mb, ob) and np.array_equal(ma, oa)
+    assert len(np.unique(ma // 2000)) == 8                                    # every device's block wins somewhere
+    i0 = 5_000_000
+    W = 600
+    seg = np.ascontiguousarray(feat[:, :, i0:i0 + W + int(tau.max()) + 1])
+    wb, wa = oracle_lib.beamform(seg, tau, wp, ws, "flexible", "max")
+    assert np.array_equal(ob[i0:i0 + W], wb[:W]) and np.array_equal(oa[i0:i0 + W], wa[:W])
+    _lib.release_device_memory(-1)
