@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
     const float* __restrict__ U, long long N, const BpFastGroup* __restrict__ groups, int n_groups,
     const BpRun* __restrict__ runs, const BpWindow* __restrict__ wins, const int* __restrict__ recs,
     int rec_dw, int id_offset, long long tile_lo, long long n_tiles, float* __restrict__ out_beam,
-    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass)
+    int* __restrict__ out_arg, int desc_waves, long long split_stride, float best0, int n_pass, int slot_prio)
 {
     // short series: workgroup (tile, y) walks the groups [n_groups y / Y, n_groups (y + 1) / Y) and
     // writes its partial maxima to out + y * split_stride (bp.hip: bp_split_count, bp_merge_splits_kernel);
@@ -690,6 +690,12 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 auto slot_step = [&](auto sc) __attribute__((always_inline)) {
                     constexpr int SLOT = decltype(sc)::value;
                     (void)&carry; (void)&ac; (void)&A; (void)&B;
+                    // option bp.slot_prio: the 16 waves of an entry start together and do the same work, but the
+                    // hardware serves the oldest first -- they reach the barrier thousands of cycles before the
+                    // youngest, which then gather alone at a fraction of the LDS rate.  1: a wave lowers its issue
+                    // priority as it gets ahead (slots 0-2: 3, 3-4: 2, 5-6: 1, 7-8: 0), 2: the reverse.
+                    if (slot_prio == 1) __builtin_amdgcn_s_setprio(3 - (SLOT * 4) / NSLOT);
+                    else if (slot_prio == 2) __builtin_amdgcn_s_setprio((SLOT * 4) / NSLOT);
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
                         ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;
@@ -825,7 +831,7 @@ int launch_beam_fast(const BpFastClass& fc, int id_offset, const float* U, size_
         kern<<<grid, dim3(BPF_THREADS), lds, stream>>>(                                            \
             U, (long long)N, fc.d_groups, fc.n_groups, fc.d_runs, fc.d_wins, fc.d_recs,            \
             fc.rec_dw, id_offset, tile_lo, n_tiles, beam, arg, desc_waves, split_stride, best0,   \
-            fc.halves ? fc.n_pass : 1);                                                               \
+            fc.halves ? fc.n_pass : 1, (int)option(OPT_BP_SLOT_PRIO));                                \
     } while (0)
     if (fc.tile == 512) { if (fc.uniform) BPF_LAUNCH(true, 8); else BPF_LAUNCH(false, 8); }
     else if (fc.tile == 256 && fc.halves) { if (fc.uniform) BPF_LAUNCH(true, 4, true); else BPF_LAUNCH(false, 4, true); }
