@@ -146,6 +146,42 @@ __device__ __forceinline__ void bpf_for_each(F&& f, std::integer_sequence<int, I
     (f(std::integral_constant<int, I>{}), ...);
 }
 
+// Option bp.slot_prio (round 5): the 16 waves of a workgroup start a group together and do the same work, but the
+// hardware serves the oldest waves first -- they reach the group's barrier thousands of cycles before the youngest,
+// which then gather alone at a fraction of the LDS rate (profiles/r04_bp_fast_phase_cycles.txt: the oldest waves
+// wait 13 758 cycles of a 35 185-cycle entry).  A wave therefore LOWERS its issue priority as it gets through its
+// parts of the run -- 3, 2, 1, 0 by quarters -- and the waves arrive together.  Wave-uniform, a compare per pair
+// of parts.  (The control -- waves ahead go FIRST -- measured no gain: profiles/r05_bp_slot_prio.txt.)
+struct BpfYield {
+    // (two SGPRs of state: these kernels sit at the 100-SGPR limit with two records in flight -- a first version
+    // with three thresholds and the mode kept live made the compiler spill)
+    int left, level;
+    // mode 1: by progress (above).  mode 2: ROTATING -- the wave takes the next level in front of every pair of
+    // parts, starting from its place on its SIMD (a workgroup's waves go to the SIMDs round-robin: wave >> 2), so
+    // that the four waves of a SIMD hold four different priorities at any time and each is favoured a quarter of
+    // the time.  Measured (profiles/r05_bp_slot_prio.txt): rotating lifts the ISOLATED gather loop from 0.75 to 0.78 (static
+    // per-wave priorities: nothing), but in the kernel the progress schedule wins -- 0.771 against 0.758 at cfg3,
+    // 0.666 against 0.648 with 40 stations -- because it also brings the waves to the barrier together; a
+    // staggered progress schedule (older waves yield earlier) measured equal to the plain one.
+    __device__ __forceinline__ BpfYield(int mode, int wave) : left(mode == 1 ? 0 : (mode == 2 ? -1 : 0x7fffffff)), level(mode == 2 ? (wave >> 2) & 3 : 3) {}
+    __device__ __forceinline__ void set() const
+    {
+        if (level == 3) __builtin_amdgcn_s_setprio(3);
+        else if (level == 2) __builtin_amdgcn_s_setprio(2);
+        else if (level == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    // in front of the parts it, it + by of a run of n_it
+    __device__ __forceinline__ void at(int n_it, int by)
+    {
+        if (left < 0) { set(); level = (level + 1) & 3; return; }          // rotating
+        if (left > 0) { left -= by; return; }
+        set();
+        left = level > 0 ? ((n_it + 3) >> 2) - by : 0x7fffffff;
+        level = level > 0 ? level - 1 : 0;
+    }
+};
+
 // TPW: samples per lane (8 / 4 / 2 -> tile 512 / 256 / 128).  The smaller tiles exist for dense
 // station weights: the dual windows of 2 n rows must fit 160 KB -- n <= 16 at tile 512, ~28 at 256,
 // ~48 at 128 (bp.hip picks the tile per station-count class of sources).
@@ -436,12 +472,14 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 };
                 using ic0 = std::integral_constant<int, 0>;
                 using ic2 = std::integral_constant<int, 2>;
+                BpfYield yield(slot_prio, wv);
                 if constexpr (NU % 4 == 0) {
-                    for (int it = 0; it < n_it; ++it) part_body(ic0{});
+                    for (int it = 0; it < n_it; ++it) { yield.at(n_it, 1); part_body(ic0{}); }
                 } else {
                     static_assert(NU % 4 == 2, "even number of units per part");
                     int it = 0;
                     for (; it + 1 < n_it; it += 2) {
+                        yield.at(n_it, 2);
                         part_body(ic0{});
                         part_body(ic2{});
                     }
@@ -583,7 +621,13 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                 using ic0 = std::integral_constant<int, 0>;
                 using icn = std::integral_constant<int, NU % 4>;      // ring phase of the odd parts (0 or 2)
                 int it = 0;
+                // option bp.slot_prio (BpfYield above).  Measured, round 5, profiles/r05_bp_slot_prio.txt: cfg3 151.6 ->
+                // 146.7 ms = 0.726 -> 0.750 of the gather rate -- the isolated loop's own ceiling --, all 20 stations
+                // 0.702 -> 0.741; schedules that change level at 1/2, 3/4, 7/8 or at 1/8, 1/4, 1/2 of the run gain
+                // about half of that, the reverse order nothing.
+                BpfYield yield(slot_prio, wv);
                 for (; it + 1 < n_it; it += 2) {
+                    yield.at(n_it, 2);
                     part_g(A, B, ic0{});
                     part_g(B, A, icn{});
                 }
@@ -693,9 +737,17 @@ __global__ __launch_bounds__(BPF_THREADS) void bp_beam_fast_kernel(
                     // option bp.slot_prio: the 16 waves of an entry start together and do the same work, but the
                     // hardware serves the oldest first -- they reach the barrier thousands of cycles before the
                     // youngest, which then gather alone at a fraction of the LDS rate.  1: a wave lowers its issue
-                    // priority as it gets ahead (slots 0-2: 3, 3-4: 2, 5-6: 1, 7-8: 0), 2: the reverse.
+                    // priority as it gets ahead (slots 0-2: 3, 3-4: 2, 5-6: 1, 7-8: 0).  cfg5's share with
+                    // all 40 stations: 3620 -> 3267 ms, 0.607 -> 0.673 of the gather rate (the reverse order: 0.609).
                     if (slot_prio == 1) __builtin_amdgcn_s_setprio(3 - (SLOT * 4) / NSLOT);
-                    else if (slot_prio == 2) __builtin_amdgcn_s_setprio((SLOT * 4) / NSLOT);
+                    else if (slot_prio == 2) {
+                        const int l = ((wv >> 2) + SLOT) & 3;
+                        if (l == 3) __builtin_amdgcn_s_setprio(3);
+                        else if (l == 2) __builtin_amdgcn_s_setprio(2);
+                        else if (l == 1) __builtin_amdgcn_s_setprio(1);
+                        else __builtin_amdgcn_s_setprio(0);
+                    }
+
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
                         ac[r][0] = g_load ? carry[SLOT][r][0] : 0.0f;

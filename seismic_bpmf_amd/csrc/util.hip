@@ -62,7 +62,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.host_piece_lags", 131072, 0, 1 << 24, false},     // bpmf_mf_run: the day of data arrives in pieces (first piece this many samples, rounded to 4096; doubling to 8x) while the first two template batches run on the lags that have arrived; 0 = one upload in front of the first kernel
     {"bp.host_piece_samples", 131072, 0, 1 << 24, false},  // bpmf_bp_run: the same for the day of features (first piece this many samples, rounded to 131072 = one round of the chip; then 2x, 4x); 0 = one upload in front
     {"host.cache_limit_mb", 0, 0, 1L << 30, false},        // host-pointer calls: a device working set larger than this many MB is given back when the call ends (0 = kept for the next call, bpmf_release_device_memory frees it)
-    {"bp.slot_prio", 0, 0, 2, false},                      // multi-residency kernel (33-64 stations): issue priority of a wave by how far it is through its sources of the group entry (1: waves ahead yield, 2: waves ahead go first; 0: none)
+    {"bp.slot_prio", 1, 0, 2, false},                      // interior-tile kernels: a wave lowers its issue priority (s_setprio 3, 2, 1, 0 by quarters) as it gets through its sources of a group, so that the 16 waves reach the group's barrier together; 0: none (rounds 2-4)
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))

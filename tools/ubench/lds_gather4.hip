@@ -23,7 +23,7 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 template <int KIND, int WPB, int TERMS>
-__global__ __launch_bounds__(64 * WPB) void k(float* out, int n_terms, int stride)
+__global__ __launch_bounds__(64 * WPB) void k(float* out, int n_terms, int stride, int prio_mode)
 {
     extern __shared__ float lds[];
     for (int i = threadIdx.x; i < 35840; i += 64 * WPB) {
@@ -61,9 +61,16 @@ __global__ __launch_bounds__(64 * WPB) void k(float* out, int n_terms, int strid
                      a2 = {Y[(u) & 3][1][0], Y[(u) & 3][1][1]}, a3 = {Y[(u) & 3][1][2], Y[(u) & 3][1][3]}; \
             PKFMA_S(ac[0], sp, a0); PKFMA_S(ac[1], sp, a1); PKFMA_S(ac[2], sp, a2); PKFMA_S(ac[3], sp, a3); } }
 #define WW { if (KIND == 0) WAIT(12); else if (KIND == 1) WAIT(7); else WAIT(6); }
+    // round 5b: issue priorities.  1: static, by the wave's place on its SIMD (waves go to SIMDs round-robin, so
+    // wv >> 2 = 0..3 on each); 2: rotating -- every source the wave takes the next level; 3: static for the first
+    // half of the waves' work, none afterwards is not modelled here (the kernel's progress schedule needs barriers)
+    int pl = (wv >> 2) & 3;
+    auto setp = [&](int l) { if (l == 3) __builtin_amdgcn_s_setprio(3); else if (l == 2) __builtin_amdgcn_s_setprio(2); else if (l == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); };
+    if (prio_mode == 1) setp(pl);
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) ISSUE(u)
     for (int i = 0; i < n_terms; i += TERMS) {
+        if (prio_mode == 2) { pl = (pl + 1) & 3; setp(pl); }
 #pragma unroll
         for (int u = 0; u < TERMS; ++u) { ISSUE(u + RING - 1) WW FMA(u) }
         const int sid = i;
@@ -88,19 +95,19 @@ __global__ __launch_bounds__(64 * WPB) void k(float* out, int n_terms, int strid
 
 static long g_terms = 2000000;
 template <int KIND, int WPB, int TERMS>
-void run(int stride)
+void run(int stride, int prio_mode = 0)
 {
     float* d; hipMalloc(&d, 256 * 2048 * sizeof(float));
     hipFuncSetAttribute((const void*)k<KIND, WPB, TERMS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int n = (int)(g_terms * 16 / WPB / (KIND == 1 ? 1 : 2));      // the same bytes per CU for every shape
-    k<KIND, WPB, TERMS><<<256, 64 * WPB, 140 * 1024>>>(d, 1000 * TERMS, stride);
+    k<KIND, WPB, TERMS><<<256, 64 * WPB, 140 * 1024>>>(d, 1000 * TERMS, stride, prio_mode);
     hipEventRecord(e0);
-    k<KIND, WPB, TERMS><<<256, 64 * WPB, 140 * 1024>>>(d, n / TERMS * TERMS, stride);
+    k<KIND, WPB, TERMS><<<256, 64 * WPB, 140 * 1024>>>(d, n / TERMS * TERMS, stride, prio_mode);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double bytes = 256.0 * WPB * (double)(n / TERMS * TERMS) * 64.0 * (KIND == 1 ? 16 : 32);
-    printf("kind %d, %2d waves/CU, %2d terms/source: %.1f TB/s gathered (%.1f%% of 157.3), %.1f ms\n", KIND, WPB, TERMS,
+    printf("prio %d kind %d, %2d waves/CU, %2d terms/source: %.1f TB/s gathered (%.1f%% of 157.3), %.1f ms\n", prio_mode, KIND, WPB, TERMS,
            bytes / ms / 1e9, bytes / ms / 1e9 / 157.3 * 100, ms);
     fflush(stdout);
     hipFree(d);
@@ -108,6 +115,11 @@ void run(int stride)
 int main(int argc, char** argv)
 {
     if (argc > 1) g_terms = atol(argv[1]);
+    if (argc > 2) {          // round 5b: static / rotating issue priorities on the production loop and the b128 loop
+        for (int rep = 0; rep < 2; ++rep)
+            for (int pm = 0; pm < 3; ++pm) { run<0, 16, 20>(338, pm); run<1, 16, 20>(340, pm); run<2, 16, 20>(340, pm); }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<0, 16, 20>(338);
         run<1, 16, 20>(340); run<1, 8, 20>(340); run<1, 4, 20>(340);
