@@ -282,6 +282,7 @@ __device__ __forceinline__ float mf_cc_of(float num, float nt, float nd)
 constexpr int MF_THREADS = 256;
 constexpr int MF_LAGS_PER_WAVE = 1024;
 constexpr int MF_LAGS_PER_WG = 4096;
+constexpr int MF_REC_TERMINATORS = 12;     // {-1, ..} records behind a template's used-channel records in LDS (mf_fused_prologue)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned vector
@@ -677,10 +678,7 @@ __device__ __forceinline__ int2 mf_fused_prologue(const float* __restrict__ tmpl
         mv_max_i = max(mv_max_i, l_part[8 + i]);
     }
     if (used) l_rec[base + idx] = make_int4(tid, m, __float_as_int(wc), __float_as_int(nt));
-    if (tid == 0) {
-        l_rec[n_used] = make_int4(-1, 0, 0, 0);
-        l_rec[n_used + 1] = make_int4(-1, 0, 0, 0);
-    }
+    if (tid < MF_REC_TERMINATORS) l_rec[n_used + tid] = make_int4(-1, 0, 0, 0);   // (12: the channel-split variant looks 8 records ahead)
     __syncthreads();
     return mf_lag_range(n_used > 0, mv_min_i, mv_max_i, step, L, N, n_corr, exclusive_last);
 }
@@ -723,7 +721,16 @@ __device__ unsigned long long g_mf_phase[8];
 // FUSED (option mf.fused_prologue, NTILE < 4 and n_ch <= 256): no mf_prologue_kernel ran -- chan_rec and range
 // are not read, every workgroup works its template's channel records and lag range out itself
 // (mf_fused_prologue, from mv / wts) and walks the records in LDS.
-template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4, bool SQRT_NORM = false, bool FUSED = false>
+// CSPLIT (round 5; tiny problems only: one tile per wave, fused prologue, network sum, step 1): the four waves of a
+// workgroup take the SAME 256 lags and every fourth used channel each, leave their channels' CC values in LDS, and
+// after one barrier the 256 threads run the weighted sum over the channels in channel order -- the same fmaf
+// chain, so the same bits -- one lag each.  Four times the waves for the same arithmetic: BASELINE configs[0]
+// (4 templates x 24 channels x one hour) has 2 816 tiles of 256 lags for 4 096 wave slots, and a wave that walks
+// all 24 channels alone spends 4/5 of its time on the serial work around 36 MFMAs.  Measured (tools/probe_mf_csplit.py,
+// profiles/r05_mf_channel_split.txt): one template on an hour 25.7 -> 16.5 us (L = 64) ... 47.2 -> 30.1 us (L = 256), two
+// templates -15 ... -20 %, FOUR templates (configs[0]: 2 816 waves already) +3 ... +8 % -- more waves only contend there --
+// so the variant is taken up to 2 048 waves of 256 lags (option mf.channel_split).
+template <bool NETWORK_SUM, int MAXR, int MAXT, bool STEP1, int NTILE = 4, bool SQRT_NORM = false, bool FUSED = false, bool CSPLIT = false>
 __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const float* __restrict__ tmpl, const int4* __restrict__ chan_rec,
     const float* __restrict__ data, const float* __restrict__ e_d,
@@ -735,7 +742,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     const int Kpad = mf_kpad(L);
     const int tp_len = mf_band_len(L);
     static_assert(NTILE == 4 || NTILE == 2 || NTILE == 1, "tiles per wave");
-    constexpr int LAGS_W = 256 * NTILE, LAGS_WG = 4 * LAGS_W;
+    static_assert(!CSPLIT || (NTILE == 1 && FUSED && NETWORK_SUM && STEP1), "channel split: the tiny-problem variant only");
+    constexpr int LAGS_W = 256 * NTILE, LAGS_WG = CSPLIT ? LAGS_W : 4 * LAGS_W;
+    constexpr int REC_STRIDE = CSPLIT ? 4 : 1;       // records between a wave's consecutive channels
     const int Ww = LAGS_W - 16 + Kpad;          // this wave's window
     // FULLW (the 1- and 2-tile variants): the wave's buffer has room for ALL its staging registers (64 MAXR window
     // floats), whatever the template length -- see write_stage
@@ -769,7 +778,15 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
     } else {
         rgi = range[t];
     }
-    const long long lag0 = lag_block * LAGS_WG + (long long)wv * LAGS_W;
+    // CSPLIT: CC values of the workgroup's 256 lags, one row per used channel, behind the records
+    float* exch = nullptr;
+    int n_used = 0;
+    if constexpr (CSPLIT) {
+        const int* l_part = (const int*)(smem + 4 * wave_floats + 64);
+        n_used = l_part[0] + l_part[1] + l_part[2] + l_part[3];
+        exch = (float*)(l_rec + n_ch + MF_REC_TERMINATORS);
+    }
+    const long long lag0 = lag_block * LAGS_WG + (CSPLIT ? 0 : (long long)wv * LAGS_W);
     const int2 rg = make_int2(rgi.x * step, rgi.y * step);  // CC indices -> data-sample offsets
     const long long nwin = N - L + 1;
 
@@ -851,9 +868,9 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #undef MF_WD
         };
 
-        int4 rec = ld_rec(0);
-        int4 rec1 = ld_rec(1);
-        int ri = 0;
+        int4 rec = ld_rec(CSPLIT ? wv : 0);
+        int4 rec1 = ld_rec(CSPLIT ? wv + REC_STRIDE : 1);
+        int ri = CSPLIT ? wv : 0;
         if (rec.x >= 0) issue_stage(rec.x, rec.y);
         MF_PHASE_START();
         while (rec.x >= 0) {
@@ -863,7 +880,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
             const float et = __int_as_float(rec.w);
-            const int4 rec2 = ld_rec(ri + 2);
+            const int4 rec2 = ld_rec(ri + 2 * REC_STRIDE);
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
             f32x4 ed[NTILE];
             // One 16-byte load per group of 4 lags.  A group that straddles an end of the valid range
@@ -969,7 +986,17 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
 #undef MF_REQ
 #undef MF_STEP
             MF_PHASE(2);
-            if (NETWORK_SUM && STEP1 && wave_inside) {
+            if constexpr (CSPLIT) {
+                // this channel's CC of the lane's four lags -> row `ri` of the exchange buffer (0 outside the range)
+                f32x4 c4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long lag = lag_w + r;
+                    const bool ok = wave_inside || (lag >= rg.x && lag <= rg.y);
+                    c4[r] = ok ? mf_cc_of<SQRT_NORM>(acc[0][r], et, ed[0][r]) : 0.0f;
+                }
+                *(f32x4*)(exch + ri * 256 + 16 * a + 4 * kq) = c4;
+            } else if (NETWORK_SUM && STEP1 && wave_inside) {
                 // every lag of this wave is inside the template's valid range (wave-uniform, all
                 // but the first and last tiles of a day): no per-lag range tests
 #pragma unroll
@@ -1000,14 +1027,23 @@ __global__ __launch_bounds__(MF_THREADS, 4) void mf_mfma_wave_kernel(
             }
             rec = rec1;
             rec1 = rec2;
-            ++ri;
+            ri += REC_STRIDE;
             MF_PHASE(3);
 #ifdef BPMF_PHASE_CYCLES
             ++ph_n_;
 #endif
         }
     }
-    if (NETWORK_SUM) {
+    if constexpr (CSPLIT) {
+        __syncthreads();                  // every wave's channels are in the exchange buffer
+        const long long lag = lag0 + tid;
+        float s = 0.0f;
+        if (wave_valid) {
+            // the network sum: fmaf(w, cc, sum) over the used channels in channel order (the order of the records)
+            for (int i = 0; i < n_used; ++i) s = __fmaf_rn(__int_as_float(l_rec[i].z), exch[i * 256 + tid], s);
+        }
+        if (lag < n_corr) out[(size_t)t * n_corr + lag] = s;
+    } else if (NETWORK_SUM) {
 #pragma unroll
         for (int u = 0; u < NTILE; ++u) {
             const long long lag = lag_w + 256 * u;
@@ -1340,7 +1376,13 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     do { if (step == 1) BPMF_MF_LAUNCH2(NS, R, TT, true); else BPMF_MF_LAUNCH2(NS, R, TT, false); } while (0)
         if (wave_kernel) {                          // L <= 257: independent waves, no barrier
             const int Kp = mf_kpad((int)L), Ww = 256 * ntile - 16 + Kp;
-            const size_t lags_wg = (size_t)4 * 256 * ntile;
+            // option mf.channel_split = n (0: off): tiny problems -- one tile per wave, fused prologue, network sum,
+            // step 1, at most 32 channels, at most n waves of 256 lags in the whole launch, not a piece of a larger
+            // launch -- run the CSPLIT variant: four waves per 256 lags, every fourth used channel each
+            const long csplit_max = option(OPT_MF_CHANNEL_SPLIT);
+            const bool csplit = ntile == 1 && fused && network_sum && step == 1 && n_ch <= 32 && !ranged &&
+                                csplit_max > 0 && waves4 * 4 <= (size_t)csplit_max;
+            const size_t lags_wg = csplit ? (size_t)256 : (size_t)4 * 256 * ntile;
             const size_t nbw_lo = off_lo / lags_wg;       // (off_lo is a multiple of 4096 = of every variant's span)
             const size_t n_blocks_w = (off_hi - off_lo + lags_wg - 1) / lags_wg;
             if (T * (n_blocks_w + 8) >= 0x7fffffffull) {
@@ -1351,9 +1393,11 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
             // (+ 256: slack for the operand prefetch one k-step past the end; FUSED: 16 ints + the channel records)
             const int Wbuf = ntile < 4 ? 64 * (ntile == 2 ? 12 : 8) : Ww;      // (FULLW: room for every staging register)
             const size_t wl = (size_t)4 * (mf_band_len((int)L) + (Wbuf + 2 * (Wbuf >> 4) + 2 + 63) / 64 * 64 + 64) * sizeof(float) + 256 +
-                              (fused ? 64 + (n_ch + 2) * sizeof(int4) : 0);
-#define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ, FU)                                             \
-    mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ, FU><<<grid_w, dim3(MF_THREADS), wl, stream>>>(    \
+                              (fused ? 64 + (n_ch + MF_REC_TERMINATORS) * sizeof(int4) : 0) +
+                              (csplit ? n_ch * 256 * sizeof(float) : 0);
+#define BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, SQ, FU)  BPMF_MF_WAVE_LAUNCH5(NS, S1, R, NT, SQ, FU, false)
+#define BPMF_MF_WAVE_LAUNCH5(NS, S1, R, NT, SQ, FU, CS)                                         \
+    mf_mfma_wave_kernel<NS, R, 5, S1, NT, SQ, FU, CS><<<grid_w, dim3(MF_THREADS), wl, stream>>>( \
         d_templates, ws.chan_rec, d_data, ws.e_d, ws.range, (int)L, (long long)N, (int)T,        \
         (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO), \
         d_moveouts, d_weights, exclusive_last, (int)nbw_lo)
@@ -1367,13 +1411,15 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         else if (fused) BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1, true);                                \
         else BPMF_MF_WAVE_LAUNCH3(NS, S1, 8, 1, false);                                          \
     } while (0)
-            if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
+            if (csplit) { if (sqrt_norm) BPMF_MF_WAVE_LAUNCH5(true, true, 8, 1, true, true, true); else BPMF_MF_WAVE_LAUNCH5(true, true, 8, 1, false, true, true); }
+            else if (network_sum && step == 1) BPMF_MF_WAVE_LAUNCH(true, true);
             else if (network_sum) BPMF_MF_WAVE_LAUNCH(true, false);
             else if (step == 1) BPMF_MF_WAVE_LAUNCH(false, true);
             else BPMF_MF_WAVE_LAUNCH(false, false);
 #undef BPMF_MF_WAVE_LAUNCH
 #undef BPMF_MF_WAVE_LAUNCH3
 #undef BPMF_MF_WAVE_LAUNCH4
+#undef BPMF_MF_WAVE_LAUNCH5
         } else if (need_r <= 17 && need_t <= 2) {   // L <= 273
             if (network_sum) BPMF_MF_LAUNCH(true, 17, 2); else BPMF_MF_LAUNCH(false, 17, 2);
         } else if (need_r <= 20 && need_t <= 5) {   // L <= 1041

@@ -63,6 +63,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"bp.host_piece_samples", 131072, 0, 1 << 24, false},  // bpmf_bp_run: the same for the day of features (first piece this many samples, rounded to 131072 = one round of the chip; then 2x, 4x); 0 = one upload in front
     {"host.cache_limit_mb", 0, 0, 1L << 30, false},        // host-pointer calls: a device working set larger than this many MB is given back when the call ends (0 = kept for the next call, bpmf_release_device_memory frees it)
     {"bp.slot_prio", 1, 0, 2, false},                      // interior-tile kernels: a wave lowers its issue priority (s_setprio 3, 2, 1, 0 by quarters) as it gets through its sources of a group, so that the 16 waves reach the group's barrier together; 0: none (rounds 2-4)
+    {"mf.channel_split", 2048, 0, 1 << 24, false},         // tiny matched-filter problems (at most this many waves of 256 lags; one tile per wave, fused prologue, network sum, step 1, <= 32 channels): four waves per 256 lags, every fourth used channel each, the channel sum behind one barrier (0 = off)
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))

@@ -687,3 +687,40 @@ def test_bp_all_used_moveouts_negative(oracle_lib, N, tau_hi):
         bf.close()
         hb, ha = beamform(f, tau, wp, ws, device="gpu", reduce="max", out_of_bounds=oob)
         assert np.array_equal(hb, ob) and np.array_equal(ha, oa), (N, tau_hi, oob)
+
+
+@pytest.mark.parametrize("L", [8, 64, 128, 200, 257])
+@pytest.mark.parametrize("S,C", [(8, 3), (1, 1), (5, 2), (16, 2)])
+def test_mf_channel_split_variant(oracle_lib, L, S, C, hip_opts):
+    """Option mf.channel_split (round 5, tiny problems): the four waves of a workgroup take the same 256 lags and
+    every fourth used channel each, the weighted channel sum runs behind one barrier in channel order -- the same
+    fmaf chain as the plain kernel and the oracle, bit for bit.  Signed moveouts (partly valid tiles), zero-weight
+    channels, a template without any, fewer used channels than waves, zero-energy windows, mf.compat_sqrt_norm."""
+    from seismic_bpmf_amd import MatchedFilterGPU, _lib, matched_filter
+    rng = np.random.default_rng(1000 * L + 10 * S + C)
+    T, N = int(rng.integers(1, 6)), int(rng.integers(L + 300, 9000))
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    d[0, 0, 1000:1000 + 2 * L] = 0.0
+    mv = rng.integers(-150, 400, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[rng.random((T, S, C)) < 0.3] = 0.0
+    if T > 2:
+        w[1] = 0.0                       # no used channel at all
+        w[2] = 0.0
+        w[2, 0, 0] = 0.7                 # one used channel: three of the four waves have nothing to do
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1)
+    hip_opts("mf.channel_split", 1 << 20)
+    hip_opts("mf.tiles_per_wave", 1)
+    got = matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False)
+    assert np.array_equal(got, want)
+    eng = MatchedFilterGPU(device=0)
+    eng.set_data(d)
+    assert np.array_equal(eng.run(tp, mv, w, 1).cpu().numpy(), want)
+    hip_opts("mf.channel_split", 0)
+    assert np.array_equal(eng.run(tp, mv, w, 1).cpu().numpy(), want)
+    hip_opts("mf.channel_split", 1 << 20)
+    hip_opts("mf.compat_sqrt_norm", 1)
+    with oracle_lib.compat(oracle_lib.COMPAT_SQRT_NORM):
+        want2 = oracle_lib.matched_filter(tp, mv, w, d, 1)
+    assert np.array_equal(matched_filter(tp, mv, w, d, 1, arch="gpu", device=0, check_zeros=False), want2)
