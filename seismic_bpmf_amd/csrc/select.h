@@ -150,4 +150,130 @@ __device__ float window_median(const float* __restrict__ x, long long len, long 
     return (key_f32(lo_key) + key_f32(hi_key)) / 2.0f;   // float32 mean of the two middle values (exact halving)
 }
 
+// ---- np.median in TWO passes where the caller knows roughly where the values lie (round 5, the MAD threshold) ----
+// The radix select reads the series three times per median, and its first level -- the top 11 bits of a float:
+// sign, exponent, two mantissa bits -- puts a window of CC values into a handful of bins: a thousand threads
+// hammering a few LDS counters.  Here pass A counts the elements in SEL_BINS buckets of equal WIDTH over
+// [lo, lo + SEL_BINS width) (the caller's guess: centre +- 6 sigma of the row -- the values spread over hundreds
+// of buckets); the bucket that holds the middle rank(s) has a few hundred elements, which pass B copies into LDS
+// (`buf`, SEL_BUF keys) where their exact ranks are counted.  The bucket function is the same deterministic,
+// monotone float expression in both passes, so the result is the exact order statistic -- bit for bit what
+// window_median returns -- whatever the guess is worth; when it is worth nothing (the two middle values in
+// different buckets, more than SEL_BUF elements in the bucket, a non-finite guess) *ok = 0 and the caller falls
+// back to window_median.  `nan_seen` as in window_select.  No SKIPZ: every element belongs to the series.
+constexpr int SEL_BUF = 4096;
+template <bool DEV, class Fix = SelNoFix>
+__device__ float window_median_bucketed(const float* __restrict__ x, long long len, float centre, float lo, float inv_width,
+                                        unsigned* hist, unsigned* sel, unsigned* buf, Fix fix, int* nan_seen, int* ok)
+{
+    const int tid = threadIdx.x;
+    constexpr int UNR = 8;
+    auto value_of = [&](float v, long long i) -> float {
+        v = fix(v, i);
+        return DEV ? fabsf(__fsub_rn(v, centre)) : v;
+    };
+    auto bucket_of = [&](float v) -> int {
+        if (v != v) return SEL_BINS - 1;                 // (a NaN sorts behind everything, as its key does)
+        const float q = __fmul_rn(__fsub_rn(v, lo), inv_width);
+        if (!(q > 0.0f)) return 0;
+        return q >= (float)(SEL_BINS - 1) ? SEL_BINS - 1 : (int)q;
+    };
+    for (int b = tid; b < SEL_BINS; b += SEL_THREADS) hist[b] = 0;
+    if (tid == 0) { sel[0] = 0; sel[1] = 0; sel[2] = 0; sel[3] = 0; }
+    __syncthreads();
+    int bad = 0;
+    {
+        long long i = tid;
+        for (; i + (long long)(UNR - 1) * SEL_THREADS < len; i += (long long)UNR * SEL_THREADS) {
+            float v[UNR];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) v[e] = x[i + (long long)e * SEL_THREADS];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) {
+                const float u = value_of(v[e], i + (long long)e * SEL_THREADS);
+                bad |= u != u;
+                atomicAdd(&hist[bucket_of(u)], 1u);
+            }
+        }
+        for (; i < len; i += SEL_THREADS) {
+            const float u = value_of(x[i], i);
+            bad |= u != u;
+            atomicAdd(&hist[bucket_of(u)], 1u);
+        }
+    }
+    if (bad && nan_seen) *nan_seen = 1;
+    __syncthreads();
+    // the bucket of rank r_lo = (len - 1) / 2 and of r_hi = len / 2, and the number of elements below it
+    const unsigned r_lo = (unsigned)((len - 1) / 2), r_hi = (unsigned)(len / 2);
+    if (tid < 64) {
+        unsigned tot = 0;
+        for (int b = 0; b < 32; ++b) tot += hist[tid * 32 + b];
+        unsigned inc = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d, 64);
+            if (tid >= d) inc += o;
+        }
+        const unsigned exc = inc - tot;
+        if (r_lo >= exc && r_lo < inc) {
+            unsigned below = exc;
+            int b = 0;
+            for (; b < 32; ++b) {
+                const unsigned h = hist[tid * 32 + b];
+                if (r_lo < below + h) break;
+                below += h;
+            }
+            const unsigned h = hist[tid * 32 + b];
+            sel[0] = (unsigned)(tid * 32 + b);           // the bucket
+            sel[1] = below;                              // elements in front of it
+            sel[2] = h;                                  // elements in it
+            sel[3] = (r_hi < below + h && h <= (unsigned)SEL_BUF) ? 1u : 0u;     // both middle ranks inside, and it fits
+        }
+    }
+    __syncthreads();
+    const int bucket = (int)sel[0];
+    const unsigned below = sel[1], in_bucket = sel[2];
+    const bool usable = sel[3] != 0;
+    __syncthreads();
+    if (!usable || (nan_seen && *nan_seen)) { *ok = usable ? 1 : 0; return __uint_as_float(0x7fc00000u); }
+    // pass B: the bucket's elements (as order-preserving keys) into LDS
+    if (tid == 0) sel[0] = 0;
+    __syncthreads();
+    {
+        long long i = tid;
+        for (; i + (long long)(UNR - 1) * SEL_THREADS < len; i += (long long)UNR * SEL_THREADS) {
+            float v[UNR];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) v[e] = x[i + (long long)e * SEL_THREADS];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) {
+                const float u = value_of(v[e], i + (long long)e * SEL_THREADS);
+                if (bucket_of(u) == bucket) buf[atomicAdd(&sel[0], 1u)] = f32_key(u);
+            }
+        }
+        for (; i < len; i += SEL_THREADS) {
+            const float u = value_of(x[i], i);
+            if (bucket_of(u) == bucket) buf[atomicAdd(&sel[0], 1u)] = f32_key(u);
+        }
+    }
+    __syncthreads();
+    // exact ranks inside the bucket: element e is the k-th smallest of the bucket for every k in [less, less_or_equal)
+    const unsigned k_lo = r_lo - below, k_hi = r_hi - below;
+    for (unsigned e = (unsigned)tid; e < in_bucket; e += SEL_THREADS) {
+        const unsigned key = buf[e];
+        unsigned less = 0, leq = 0;
+        for (unsigned j = 0; j < in_bucket; ++j) {
+            const unsigned kj = buf[j];
+            less += kj < key;
+            leq += kj <= key;
+        }
+        if (less <= k_lo && k_lo < leq) sel[1] = key;       // (equal keys write the same value)
+        if (less <= k_hi && k_hi < leq) sel[2] = key;
+    }
+    __syncthreads();
+    const float v_lo = key_f32(sel[1]), v_hi = key_f32(sel[2]);
+    __syncthreads();
+    *ok = 1;
+    return (len & 1) ? v_lo : (v_lo + v_hi) / 2.0f;       // np.median: the middle value, or the float32 mean of the two
+}
+
 }  // namespace bpmf

@@ -180,3 +180,46 @@ def test_row_median_mad_over_non_zero_samples():
                 assert np.array_equal(med[r], np.float32(m), equal_nan=True), (n, skip, r)
                 assert np.array_equal(mad[r], np.float32(d), equal_nan=True), (n, skip, r)
                 assert nz[r] == (x[r] == 0).sum()
+
+
+@pytest.mark.parametrize("window,overlap", [(4000, 0.25), (4001, 0.5), (257, 0.0), (30_000, 0.66)])
+def test_mad_bucketed_medians_equal_the_radix_select_on_awkward_rows(hip_opts, window, overlap):
+    """Round 5: the window medians of the MAD threshold take two passes (equal-width buckets around the row's own
+    centre, the middle bucket ranked in LDS: select.h window_median_bucketed) with the three-pass radix select as
+    the fallback.  Both are exact order statistics, so option stats.bucketed_median must not change a bit -- on
+    Gaussian rows (the buckets work), and on rows where the guess is worth nothing: constant, two-valued, heavy
+    tails, a drift far from the row's centre, blocks of exact zeros (replaced by white noise where they are read),
+    an Inf, a NaN, windows of even and odd length; against the host mirror of the reference as well."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    rng = np.random.default_rng(window)
+    n = 90_000
+    rows = [rng.standard_normal(n) * 0.05,
+            np.full(n, 0.25),
+            rng.choice([-0.5, 0.75], n),
+            rng.standard_cauchy(n) * 0.01,
+            rng.standard_normal(n) * 0.05 + np.linspace(-3.0, 3.0, n),
+            np.round(rng.standard_normal(n) * 4) / 64,                       # many duplicates
+            rng.standard_normal(n) * 1e-30,
+            rng.standard_normal(n) * 0.05, rng.standard_normal(n) * 0.05, rng.standard_normal(n) * 0.05]
+    x = np.stack(rows).astype(np.float32)
+    x[0, :1500] = 0.0
+    x[0, -2500:] = 0.0
+    x[5, 30_000:31_000] = 0.0
+    x[7, 40_000] = np.inf
+    x[8, 50_000] = np.nan
+    x[9, 10_000:10_000 + window // 2 + 5] = np.inf                          # more than half a window of +Inf
+    wn = rng.standard_normal(n).astype(np.float32)
+    th = ThresholdGPU(device=0)
+    xd = torch.as_tensor(x, device="cuda")
+    outs = {}
+    for flag in (1, 0):
+        hip_opts("stats.bucketed_median", flag)
+        tw, full = th.time_dependent_threshold_mad(xd, window, 8.0, overlap=overlap, white_noise=wn, expand=True)
+        outs[flag] = (tw.cpu().numpy(), full.cpu().numpy())
+    assert np.array_equal(outs[1][0], outs[0][0], equal_nan=True)
+    assert np.array_equal(outs[1][1], outs[0][1], equal_nan=True)
+    for r in (0, 2, 3, 4, 5):                                                # the host mirror of similarity_search.py:1079-1113
+        want = pp.time_dependent_threshold_mad(x[r], window, 8.0, overlap=overlap, white_noise=wn)
+        assert np.array_equal(outs[1][1][r], want.astype(np.float32), equal_nan=True), r
