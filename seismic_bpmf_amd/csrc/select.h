@@ -164,7 +164,8 @@ __device__ float window_median(const float* __restrict__ x, long long len, long 
 constexpr int SEL_BUF = 4096;
 template <bool DEV, class Fix = SelNoFix>
 __device__ float window_median_bucketed(const float* __restrict__ x, long long len, float centre, float lo, float inv_width,
-                                        unsigned* hist, unsigned* sel, unsigned* buf, Fix fix, int* nan_seen, int* ok)
+                                        unsigned* hist, unsigned* sel, unsigned* buf, Fix fix, int* nan_seen, int* ok,
+                                        long long rank_lo = -1, long long rank_hi = -1)
 {
     const int tid = threadIdx.x;
     constexpr int UNR = 8;
@@ -203,8 +204,9 @@ __device__ float window_median_bucketed(const float* __restrict__ x, long long l
     }
     if (bad && nan_seen) *nan_seen = 1;
     __syncthreads();
-    // the bucket of rank r_lo = (len - 1) / 2 and of r_hi = len / 2, and the number of elements below it
-    const unsigned r_lo = (unsigned)((len - 1) / 2), r_hi = (unsigned)(len / 2);
+    // the bucket of rank r_lo = (len - 1) / 2 and of r_hi = len / 2 (or the two ranks the caller names: the mean
+    // of order statistics rank_lo and rank_hi = rank_lo or rank_lo + 1), and the number of elements below it
+    const unsigned r_lo = (unsigned)(rank_lo >= 0 ? rank_lo : (len - 1) / 2), r_hi = (unsigned)(rank_lo >= 0 ? rank_hi : len / 2);
     if (tid < 64) {
         unsigned tot = 0;
         for (int b = 0; b < 32; ++b) tot += hist[tid * 32 + b];
@@ -273,7 +275,114 @@ __device__ float window_median_bucketed(const float* __restrict__ x, long long l
     const float v_lo = key_f32(sel[1]), v_hi = key_f32(sel[2]);
     __syncthreads();
     *ok = 1;
-    return (len & 1) ? v_lo : (v_lo + v_hi) / 2.0f;       // np.median: the middle value, or the float32 mean of the two
+    return r_lo == r_hi ? v_lo : (v_lo + v_hi) / 2.0f;    // np.median: the middle value, or the float32 mean of the two
+}
+
+// ---- np.median in ONE pass where the caller can say [lo, hi] holds the middle value(s) (round 5) ----
+// The pass counts the elements below lo and copies those of [lo, hi] into LDS (`band`, SEL_BAND values); when the
+// middle rank(s) fall among the copied elements, an LDS radix select among them is the exact order statistic of
+// the window -- whatever [lo, hi] was derived from; otherwise *ok = 0 (nothing else is touched) and the caller
+// takes a slower route.  SIDE: the same pass also counts |x - side_centre| in SEL_BINS buckets of width
+// 1 / side_inv_w (`side_hist`): from them the caller reads roughly where the middle DEVIATION of the window lies
+// before the pass that selects it.  `nan_seen` as in window_select.
+constexpr int SEL_BAND = 12288;
+template <bool DEV, bool SIDE, class Fix = SelNoFix>
+__device__ float window_median_banded(const float* __restrict__ x, long long len, float centre, float lo, float hi,
+                                      unsigned* hist, unsigned* sel, float* band, Fix fix, int* nan_seen, int* ok,
+                                      float side_centre = 0.0f, float side_inv_w = 0.0f, unsigned* side_hist = nullptr)
+{
+    const int tid = threadIdx.x;
+    constexpr int UNR = 8;
+    if (tid == 0) { sel[0] = 0; sel[1] = 0; }
+    if (SIDE)
+        for (int b = tid; b < SEL_BINS; b += SEL_THREADS) side_hist[b] = 0;
+    __syncthreads();
+    unsigned below = 0;
+    int bad = 0;
+    auto one = [&](float v, long long i) {
+        v = fix(v, i);
+        if (SIDE) {
+            const float q = __fmul_rn(fabsf(__fsub_rn(v, side_centre)), side_inv_w);
+            atomicAdd(&side_hist[!(q > 0.0f) ? 0 : (q >= (float)(SEL_BINS - 1) ? SEL_BINS - 1 : (int)q)], 1u);
+        }
+        const float u = DEV ? fabsf(__fsub_rn(v, centre)) : v;
+        bad |= u != u;
+        below += u < lo;
+        if (u >= lo && u <= hi) {
+            const unsigned at = atomicAdd(&sel[0], 1u);
+            if (at < (unsigned)SEL_BAND) band[at] = u;
+        }
+    };
+    {
+        long long i = tid;
+        for (; i + (long long)(UNR - 1) * SEL_THREADS < len; i += (long long)UNR * SEL_THREADS) {
+            float v[UNR];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) v[e] = x[i + (long long)e * SEL_THREADS];
+#pragma unroll
+            for (int e = 0; e < UNR; ++e) one(v[e], i + (long long)e * SEL_THREADS);
+        }
+        for (; i < len; i += SEL_THREADS) one(x[i], i);
+    }
+    for (int d = 32; d > 0; d >>= 1) below += __shfl_down(below, d, 64);
+    if ((tid & 63) == 0 && below) atomicAdd(&sel[1], below);
+    if (bad && nan_seen) *nan_seen = 1;
+    __syncthreads();
+    const unsigned n_band = sel[0], n_below = sel[1];
+    const unsigned r_lo = (unsigned)((len - 1) / 2), r_hi = (unsigned)(len / 2);
+    const bool usable = n_band <= (unsigned)SEL_BAND && r_lo >= n_below && r_hi < n_below + n_band;
+    __syncthreads();
+    if (!usable || (nan_seen && *nan_seen)) { *ok = usable ? 1 : 0; return __uint_as_float(0x7fc00000u); }
+    // the order statistics among the copied elements: equal-width buckets over [lo, hi] (a handful of elements
+    // per bucket) and a ranking of the bucket of the rank, all in LDS (the keys at the end of `band`); the radix
+    // select, also in LDS, when that does not apply or work
+    if (n_band <= (unsigned)(SEL_BAND - SEL_BUF) && len > SEL_BAND && hi - lo > 0.0f && hi - lo < 1.0e37f) {
+        int fine = 0;
+        const float v = window_median_bucketed<false, SelNoFix>(band, (long long)n_band, 0.0f, lo, (float)SEL_BINS / (hi - lo), hist, sel,
+                                                                (unsigned*)(band + (SEL_BAND - SEL_BUF)), SelNoFix(), nullptr, &fine,
+                                                                (long long)(r_lo - n_below), (long long)(r_hi - n_below));
+        if (fine) { *ok = 1; return v; }
+    }
+    unsigned key_hi = 0;
+    int both = 0;
+    const unsigned key_lo = window_select<false, false>(band, (long long)n_band, 0.0f, r_lo - n_below, hist, sel,
+                                                        r_hi != r_lo ? &key_hi : nullptr, r_hi != r_lo ? &both : nullptr);
+    if (r_hi != r_lo && !both) key_hi = window_select<false, false>(band, (long long)n_band, 0.0f, r_hi - n_below, hist, sel);
+    *ok = 1;
+    return r_hi == r_lo ? key_f32(key_lo) : (key_f32(key_lo) + key_f32(key_hi)) / 2.0f;
+}
+
+// the buckets of a side histogram (window_median_banded, SIDE) that hold ranks r_lo and r_hi: sel2[0], sel2[1]
+// (SEL_BINS when the histogram does not reach the rank); call with all threads, one barrier inside
+__device__ __forceinline__ void side_rank_buckets(const unsigned* side_hist, unsigned r_lo, unsigned r_hi, unsigned* sel2)
+{
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        constexpr int PER = SEL_BINS / 64;
+        if (tid == 0) { sel2[0] = SEL_BINS; sel2[1] = SEL_BINS; }
+        unsigned tot = 0;
+        for (int b = 0; b < PER; ++b) tot += side_hist[tid * PER + b];
+        unsigned inc = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d, 64);
+            if (tid >= d) inc += o;
+        }
+        const unsigned exc = inc - tot;
+        for (int which = 0; which < 2; ++which) {
+            const unsigned r = which ? r_hi : r_lo;
+            if (r >= exc && r < inc) {
+                unsigned acc = exc;
+                int b = 0;
+                for (; b < PER - 1; ++b) {
+                    const unsigned h = side_hist[tid * PER + b];
+                    if (r < acc + h) break;
+                    acc += h;
+                }
+                sel2[which] = (unsigned)(tid * PER + b);
+            }
+        }
+    }
+    __syncthreads();
 }
 
 }  // namespace bpmf

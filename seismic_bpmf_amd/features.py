@@ -107,11 +107,17 @@ def row_median_mad(x, skip_zeros=False, device=None):
     mad = torch.empty(rows, dtype=torch.float32, device=dev)
     nz = torch.empty(rows, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    lib = _lib.lib()
+    # (long rows are read twice by the whole chip instead of seven times by one workgroup each: that path
+    # collects the middle of a row in a workspace, about a tenth of the size of the rows)
+    ws = torch.empty(lib.bpmf_row_median_mad_workspace_bytes(rows, n), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().bpmf_row_median_mad_dev(C.c_void_p(x.data_ptr()), rows, n, int(bool(skip_zeros)),
-                                                C.c_void_p(stream), C.c_void_p(med.data_ptr()),
-                                                C.c_void_p(mad.data_ptr()), C.c_void_p(nz.data_ptr()))
-    _lib.check(rc, "bpmf_row_median_mad_dev")
+        rc = lib.bpmf_row_median_mad_ws_dev(C.c_void_p(x.data_ptr()), rows, n, int(bool(skip_zeros)),
+                                            C.c_void_p(ws.data_ptr()), ws.numel(),
+                                            C.c_void_p(stream), C.c_void_p(med.data_ptr()),
+                                            C.c_void_p(mad.data_ptr()), C.c_void_p(nz.data_ptr()))
+    _lib.check(rc, "bpmf_row_median_mad_ws_dev")
+    ws.record_stream(torch.cuda.current_stream(dev))
     return med, mad, nz
 
 

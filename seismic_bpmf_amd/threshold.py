@@ -92,10 +92,11 @@ class ThresholdGPU:
             white_noise = np.random.normal(size=n).astype("float32")
         wn = t.as_tensor(np.ascontiguousarray(white_noise, dtype=np.float32), device=self.device)
         # rows go through the library in chunks: at most 65535 per call (its gridDim.y), and few enough that the
-        # workspace -- since round 5 only the zero-rank tables, n / 32 bytes per row: the zeros are replaced where
-        # the medians read them, there is no filled copy of the matrix any more -- stays under
+        # workspace -- since round 5 only the zero-rank tables (n / 32 bytes per row: the zeros are replaced where
+        # the medians read them, there is no filled copy of the matrix any more) and the buffers the row statistics
+        # collect the middle of a row in (n / 10 bytes per row) -- stays under
         # `mad_workspace_limit` bytes (4 GiB by default; one row always goes)
-        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, n // 16))))
+        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, n // 6 + 32768))))
         nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(chunk, n, W, shift)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None

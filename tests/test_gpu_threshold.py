@@ -182,7 +182,7 @@ def test_row_median_mad_over_non_zero_samples():
                 assert nz[r] == (x[r] == 0).sum()
 
 
-@pytest.mark.parametrize("window,overlap", [(4000, 0.25), (4001, 0.5), (257, 0.0), (30_000, 0.66)])
+@pytest.mark.parametrize("window,overlap", [(4000, 0.25), (4001, 0.5), (257, 0.0), (30_000, 0.66), (13_001, 0.3), (60_000, 0.5)])
 def test_mad_bucketed_medians_equal_the_radix_select_on_awkward_rows(hip_opts, window, overlap):
     """Round 5: the window medians of the MAD threshold take two passes (equal-width buckets around the row's own
     centre, the middle bucket ranked in LDS: select.h window_median_bucketed) with the three-pass radix select as
@@ -214,12 +214,71 @@ def test_mad_bucketed_medians_equal_the_radix_select_on_awkward_rows(hip_opts, w
     th = ThresholdGPU(device=0)
     xd = torch.as_tensor(x, device="cuda")
     outs = {}
-    for flag in (1, 0):
+    for flag in (2, 1, 0):
         hip_opts("stats.bucketed_median", flag)
         tw, full = th.time_dependent_threshold_mad(xd, window, 8.0, overlap=overlap, white_noise=wn, expand=True)
         outs[flag] = (tw.cpu().numpy(), full.cpu().numpy())
-    assert np.array_equal(outs[1][0], outs[0][0], equal_nan=True)
-    assert np.array_equal(outs[1][1], outs[0][1], equal_nan=True)
+    for flag in (2, 1):
+        assert np.array_equal(outs[flag][0], outs[0][0], equal_nan=True), flag
+        assert np.array_equal(outs[flag][1], outs[0][1], equal_nan=True), flag
     for r in (0, 2, 3, 4, 5):                                                # the host mirror of similarity_search.py:1079-1113
         want = pp.time_dependent_threshold_mad(x[r], window, 8.0, overlap=overlap, white_noise=wn)
         assert np.array_equal(outs[1][1][r], want.astype(np.float32), equal_nan=True), r
+
+
+@pytest.mark.parametrize("n", [5, 4096, 70_001, 300_000, 1_000_003])
+def test_row_median_mad_two_read_path_equals_the_one_workgroup_path(hip_opts, n):
+    """Round 5: rows of at least stats.row_grid_min_n samples are read twice by workgroups from all over the chip
+    (a histogram around a sampled guess, then the middle bucket and the two bands that can hold a middle deviation;
+    every step verified by ranks, csrc/stats.hip rm_*), any row that fails a check goes to the one-workgroup radix
+    select.  Same bits as that kernel alone (option -1) and as NumPy -- on rows where the guess works and on rows
+    where it cannot: constant, two-valued, heavy tails, a drift, duplicates, denormal scale, zeros to skip, half
+    of the row zero, +-Inf, a NaN, an offset a thousand deviations from zero, a sample that misleads (a burst
+    exactly where the sample looks)."""
+    import warnings
+    import torch
+    from seismic_bpmf_amd import features
+    rng = np.random.default_rng(n)
+    rows = [rng.standard_normal(n) * 0.05,
+            np.abs(rng.standard_normal(n)),
+            np.full(n, 0.25),
+            rng.choice([-0.5, 0.75], n),
+            rng.standard_cauchy(n) * 0.01,
+            rng.standard_normal(n) * 0.05 + np.linspace(-3.0, 3.0, n),
+            np.round(rng.standard_normal(n) * 4) / 64,
+            rng.standard_normal(n) * 1e-30,
+            rng.standard_normal(n) * 0.05,
+            rng.standard_normal(n) * 0.05,
+            rng.standard_normal(n) * 0.05,
+            rng.standard_normal(n) * 0.001 + 1000.0,
+            rng.lognormal(0.0, 2.0, n),
+            rng.standard_normal(n) * 0.05,
+            np.zeros(n),
+            rng.standard_normal(n) * 0.05]
+    x = np.stack(rows).astype(np.float32)
+    x[1, rng.random(n) < 0.55] = 0.0
+    x[8, n // 3] = np.inf
+    x[8, n // 2] = -np.inf
+    x[9, n // 2] = np.nan
+    x[10, : n // 2] = 0.0
+    stride = max(1, n // 4096)
+    x[13, ::stride] = 50.0 + rng.standard_normal(len(x[13, ::stride])).astype(np.float32)   # the sample sees only the burst
+    x[15, -1] = -0.0
+    xd = torch.as_tensor(x, device="cuda")
+    for skip in (False, True):
+        got = {}
+        for min_n in (0, -1):
+            hip_opts("stats.row_grid_min_n", min_n)
+            got[min_n] = [t.cpu().numpy() for t in features.row_median_mad(xd, skip)]
+        for a, b in zip(got[0], got[-1]):
+            assert np.array_equal(a, b, equal_nan=True), (n, skip)
+        med, mad, nz = got[0]
+        for r in range(x.shape[0]):
+            v = x[r][x[r] != 0] if skip else x[r]
+            with np.errstate(all="ignore"), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = np.median(v) if v.size else np.float32(np.nan)
+                d = np.median(np.abs(v - m)) if v.size else np.float32(np.nan)
+            assert np.array_equal(med[r], np.float32(m), equal_nan=True), (n, skip, r)
+            assert np.array_equal(mad[r], np.float32(d), equal_nan=True), (n, skip, r)
+            assert nz[r] == (x[r] == 0).sum()
