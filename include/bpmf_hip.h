@@ -80,6 +80,7 @@ int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_byt
  *   mf.wave_kernel mf.tiles_per_wave mf.boundary_prio mf.fused_prologue mf.channel_split mf.max_mfma_step mf.host_batch_kb mf.host_piece_kb mf.verbose
  *   stats.bucketed_median (MAD threshold, window medians: 2 one pass each, 1 two passes, 0 radix select only)
  *   stats.row_grid_min_n (row median / MAD: rows at least this long are read twice by the whole chip; -1 never)
+ *   stats.kurt_full_chunks (row kurtosis: full 8192-sample chunks summed by one workgroup each through LDS)
  *   mf.host_piece_lags bp.host_piece_samples (host-pointer calls: the day arrives in pieces while the first kernels run; 0 = off)
  *   debug.poison_output (tests: outputs pre-filled with 0xFF bytes, so that a sample no kernel writes shows)
  *   debug.virtual_devices (tests: k > 0 makes every `device` argument a LOGICAL device 0 .. k-1, logical d on

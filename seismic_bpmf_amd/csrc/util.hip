@@ -66,6 +66,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"mf.channel_split", 2048, 0, 1 << 24, false},         // tiny matched-filter problems (at most this many waves of 256 lags; one tile per wave, fused prologue, network sum, step 1, <= 32 channels): four waves per 256 lags, every fourth used channel each, the channel sum behind one barrier (0 = off)
     {"stats.bucketed_median", 2, 0, 2, false},             // MAD threshold, window medians: 2 = one pass each (the elements of a narrow band around the row's centre / around the middle of a side histogram of deviations, ranked in LDS), 1 = two passes (equal-width buckets, the middle bucket ranked in LDS; also the route when a band misses), 0 = three-pass radix select only (the last resort of the others)
     {"stats.row_grid_min_n", 131072, -1, 1 << 30, false},   // row median / MAD: rows at least this long are read twice by workgroups from all over the chip (histogram, then the middle bucket and two bands; exact, verified by ranks) instead of seven times by one workgroup; -1 = never
+    {"stats.kurt_full_chunks", 1, 0, 1, false},            // row kurtosis: a full 8192-sample chunk of NumPy's summation is summed by one workgroup through LDS (coalesced reads); 0 = the thread-per-leaf kernels for every chunk
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)
     {"bp.compat_first_computed", 0, 0, 1, false},      // running max starts from the first computed beam (default: from (0, source 0))

@@ -305,26 +305,33 @@ def test_matched_filter_detections_sanity_check_rejects_gappy_days(oracle_lib):
         assert (len(on[t]) == 0) if want_reject[t] else np.array_equal(on[t], off[t])
 
 
-def test_row_kurtosis_is_scipy_on_float32_bit_for_bit():
+def test_row_kurtosis_is_scipy_on_float32_bit_for_bit(hip_opts):
     """bpmf_row_kurtosis_dev == scipy.stats.kurtosis of the float32 rows (NumPy's pairwise sums over
     8192-element chunks, float32 powers, the float64 division by the count): lengths around every
-    boundary of the summation tree, a constant row (NaN), a mostly-zero row, a day-sized row."""
+    boundary of the summation tree, a constant row (NaN), a mostly-zero row, a day-sized row; the full
+    chunks summed by one workgroup each through LDS (round 5, the default) and by the thread-per-leaf
+    kernels (option stats.kurt_full_chunks 0) -- with an Inf and a NaN in a full chunk as well."""
     import torch
     from scipy.stats import kurtosis
     from seismic_bpmf_amd import postprocess as pp, workflow
     rng = np.random.default_rng(11)
-    for n in (1, 5, 7, 8, 9, 127, 128, 129, 143, 255, 257, 1000, 8191, 8192, 8193, 16385, 100_003, 2_000_001):
-        rows = 3 if n > 100_000 else 5
+    for n in (1, 5, 7, 8, 9, 127, 128, 129, 143, 255, 257, 1000, 8191, 8192, 8193, 16384, 16385, 24_576 + 57, 100_003, 2_000_001):
+        rows = 3 if n > 100_000 else 7
         x = (rng.standard_normal((rows, n)) * rng.uniform(0.01, 2.0, (rows, 1)) + rng.uniform(-1, 1, (rows, 1))).astype(np.float32)
         if n > 4:
             x[1, : n // 2] = 0.0
             x[2] = x[2, 0]
+        if rows > 5 and n > 9000:
+            x[5, 4097] = np.inf
+            x[6, 8000] = np.nan
         with np.errstate(all="ignore"):
             want = np.array([pp.excess_kurtosis_f32(r) for r in x], dtype=np.float32)
             ref = np.asarray(kurtosis(x, axis=1), dtype=np.float32)
-        got = workflow.row_excess_kurtosis(torch.as_tensor(x, device="cuda"))
         assert np.array_equal(want, ref, equal_nan=True), n
-        assert np.array_equal(got, want, equal_nan=True), (n, got, want)
+        for full in (1, 0):
+            hip_opts("stats.kurt_full_chunks", full)
+            got = workflow.row_excess_kurtosis(torch.as_tensor(x, device="cuda"))
+            assert np.array_equal(got, want, equal_nan=True), (n, full, got, want)
 
 
 def test_relocation_likelihood_on_device_equals_the_host_mirror(oracle_lib):
