@@ -359,6 +359,17 @@ size_t bpmf_row_kurtosis_workspace_bytes(size_t rows, size_t n);
 int bpmf_row_kurtosis_dev(const float *d_x, size_t rows, size_t n, void *d_workspace,
                           size_t workspace_bytes, bpmf_stream_t stream, float *d_kurtosis);
 
+/* The same sums, handed out before the last expression: d_parts (rows, 3) receives (mean, m2, m4) of every row
+ * in float32 (d_kurtosis may be NULL).  Why: SciPy evaluates `m4 / m2**2.0 - 3` on NumPy SCALARS when the input is
+ * one series -- which is how BPMF calls it (similarity_search.py:640) -- and a NumPy scalar `**` is the C
+ * library's powf, which glibc rounds faithfully but not always correctly (one case in 2500 random rows: 2 ulp in
+ * the kurtosis); on an ARRAY the same expression is the correctly rounded square, which is what
+ * bpmf_row_kurtosis_dev computes.  A host that wants the reference's very bits finishes the expression with its own
+ * NumPy scalars (seismic_bpmf_amd.workflow.row_excess_kurtosis does). */
+int bpmf_row_kurtosis_parts_dev(const float *d_x, size_t rows, size_t n, void *d_workspace,
+                                size_t workspace_bytes, bpmf_stream_t stream, float *d_kurtosis,
+                                float *d_parts);
+
 /* ------------------------------------------------------------ running kurtosis --- */
 /*
  * Device version of BPMF.clib.kurtosis (BPMF/clib.py:86-102 -> BPMF/libc.c:11-53): kurto[ch][n],

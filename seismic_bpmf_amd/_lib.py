@@ -82,6 +82,7 @@ SIGNATURES = {
     "bpmf_tdt_mad_dev": (C.c_int, [_vp, _vp, _sz, C.c_float, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "bpmf_row_kurtosis_workspace_bytes": (_sz, [_sz, _sz]),
     "bpmf_row_kurtosis_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
+    "bpmf_row_kurtosis_parts_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -529,8 +529,19 @@ def excess_kurtosis_f32(a):
     s2 = d ** 2
     m2 = np.mean(s2)
     m4 = np.mean(s2 ** 2)
+    return kurtosis_from_moments_f32(mean[0], m2, m4)
+
+
+def kurtosis_from_moments_f32(mean, m2, m4):
+    """The last expression of scipy.stats.kurtosis on ONE float32 series, `m4 / m2**2.0 - 3` (NaN when
+    m2 <= (eps * mean)**2), on NumPy float32 SCALARS as SciPy evaluates it there.  Not a detail: a NumPy scalar
+    `**` is the C library's powf, which glibc does not always round like the exact square an array `**` gives
+    (one random row in 2500 ends 2 ulp apart), and BPMF passes one series (similarity_search.py:640).  The device
+    hands out (mean, m2, m4) per row (bpmf_row_kurtosis_parts_dev) and the host finishes here, with whatever
+    NumPy / libm the reference itself would run on."""
+    mean, m2, m4 = np.float32(mean), np.float32(m2), np.float32(m4)
     with np.errstate(all="ignore"):
-        if m2 <= (np.finfo(np.float32).eps * mean[0]) ** 2:
+        if m2 <= (np.finfo(np.float32).eps * mean) ** 2:
             return np.float32(np.nan)
         return np.float32(m4 / m2 ** 2.0) - np.float32(3)
 

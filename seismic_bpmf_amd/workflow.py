@@ -46,7 +46,7 @@ def row_excess_kurtosis(cc):
     """scipy.stats.kurtosis (Fisher, biased: m4 / m2**2 - 3) of every row of a (T, n) float32 device
     tensor, evaluated as SciPy evaluates it on the reference's float32 CC series
     (BPMF/similarity_search.py:633-642): float32 moments in NumPy's summation order
-    (csrc/stats.hip, bpmf_row_kurtosis_dev; host mirror postprocess.excess_kurtosis_f32).  Returns a
+    (csrc/stats.hip, bpmf_row_kurtosis_parts_dev; host mirror postprocess.excess_kurtosis_f32).  Returns a
     float32 NumPy array; NaN for a constant row, like SciPy."""
     import ctypes as C
     import torch
@@ -57,17 +57,20 @@ def row_excess_kurtosis(cc):
     if rows == 0:
         return np.zeros(0, dtype=np.float32)
     lib = _lib.lib()
-    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    parts = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
     chunk = min(rows, 65535)                   # rows per call of the library (its gridDim.y)
     ws = torch.empty(lib.bpmf_row_kurtosis_workspace_bytes(chunk, n), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         for r0 in range(0, rows, chunk):
-            rc = lib.bpmf_row_kurtosis_dev(C.c_void_p(x[r0:].data_ptr()), min(chunk, rows - r0), n,
-                                           C.c_void_p(ws.data_ptr()), ws.numel(),
-                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
-                                           C.c_void_p(out[r0:].data_ptr()))
-            _lib.check(rc, "bpmf_row_kurtosis_dev")
-    return out.cpu().numpy()
+            rc = lib.bpmf_row_kurtosis_parts_dev(C.c_void_p(x[r0:].data_ptr()), min(chunk, rows - r0), n,
+                                                 C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                 C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream),
+                                                 None, C.c_void_p(parts[r0:].data_ptr()))
+            _lib.check(rc, "bpmf_row_kurtosis_parts_dev")
+    # (mean, m2, m4) per row from the device; the last expression on NumPy scalars, as SciPy evaluates it on one
+    # series -- postprocess.kurtosis_from_moments_f32 says why that is not the same as finishing on the device
+    from .postprocess import kurtosis_from_moments_f32
+    return np.array([kurtosis_from_moments_f32(*p) for p in parts.cpu().numpy()], dtype=np.float32)
 
 
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,

@@ -153,3 +153,106 @@ def test_fuzz_workflow_matched_filter_detections(oracle_lib, seed):
         if kurtosis(cc_ref[t].astype(np.float64)) > 100.0:        # the reference's sanity check (:633-642)
             want = np.zeros(0, dtype=np.int64)
         assert np.array_equal(got[t], want), f"seed {seed} template {t}: T={T} S={S} C={C} L={L} N={N} step={step}"
+
+
+def _fuzz_row(rng, n):
+    """One row of a distribution the guesses of the order-statistics kernels may or may not cope with."""
+    kind = int(rng.integers(0, 12))
+    scale = np.float32(10.0 ** rng.uniform(-6, 3))
+    x = rng.standard_normal(n)
+    if kind == 1:
+        x = rng.standard_cauchy(n)
+    elif kind == 2:
+        x = np.round(x * rng.choice([2, 16, 1000]))                         # ties, from heavy to light
+    elif kind == 3:
+        x = np.abs(x) ** rng.uniform(0.3, 4.0)                              # skewed
+    elif kind == 4:
+        x = x + np.where(rng.random(n) < rng.uniform(0.05, 0.6), rng.uniform(3, 300), 0.0)   # two modes
+    elif kind == 5:
+        x = x * np.linspace(0.01, rng.uniform(1, 50), n)                    # the noise level drifts
+    elif kind == 6:
+        x = x + np.linspace(-1, 1, n) * rng.uniform(0, 30)                  # the centre drifts
+    elif kind == 7:
+        x = np.full(n, rng.standard_normal())                               # constant
+        x[rng.integers(0, n, max(1, n // 50))] += rng.standard_normal()
+    elif kind == 8:
+        x = x * 1e-3 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(0, 4)  # far from zero
+    elif kind == 9:
+        x = rng.lognormal(0.0, rng.uniform(0.5, 3.0), n)
+    elif kind == 10:
+        x = rng.choice(rng.standard_normal(int(rng.integers(1, 9))), n)     # a handful of values
+    x = (x * scale).astype(np.float32)
+    if rng.random() < 0.5:
+        x[rng.random(n) < rng.choice([0.001, 0.1, 0.5, 0.9])] = 0.0
+    if rng.random() < 0.3 and n > 10:
+        k = int(rng.integers(1, max(2, n // 20)))
+        x[:k] = 0.0
+        x[-k:] = 0.0
+    if rng.random() < 0.1:
+        x[rng.integers(0, n)] = np.float32(rng.choice([np.inf, -np.inf]))
+    if rng.random() < 0.05:
+        x[rng.integers(0, n)] = np.nan
+    return x
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")
+@pytest.mark.parametrize("seed", _fuzz_seeds(12))
+def test_fuzz_workflow_row_statistics(hip_opts, seed):
+    """Row median / MAD (the two-read path forced for every length, and the one-workgroup path) and the row
+    kurtosis against NumPy / SciPy's float32 arithmetic on rows of a dozen distributions."""
+    import torch
+    from seismic_bpmf_amd import features, postprocess as pp, workflow
+    rng = np.random.default_rng(77_000 + seed)
+    n = int(rng.choice([1, 2, 17, 1_000, 4_097, 8_192, 65_537, 200_000, 700_001]))
+    rows = int(rng.integers(1, 9))
+    x = np.stack([_fuzz_row(rng, n) for _ in range(rows)])
+    xd = torch.as_tensor(x, device="cuda")
+    for skip in (False, True):
+        want_m, want_d = [], []
+        for r in range(rows):
+            v = x[r][x[r] != 0] if skip else x[r]
+            with np.errstate(all="ignore"):
+                m = np.median(v) if v.size else np.float32(np.nan)
+                d = np.median(np.abs(v - m)) if v.size else np.float32(np.nan)
+            want_m.append(np.float32(m))
+            want_d.append(np.float32(d))
+        for min_n in (0, -1):
+            hip_opts("stats.row_grid_min_n", min_n)
+            med, mad, nz = (t.cpu().numpy() for t in features.row_median_mad(xd, skip))
+            what = f"seed {seed} n={n} rows={rows} skip={skip} min_n={min_n}"
+            assert np.array_equal(med, np.array(want_m), equal_nan=True), what
+            assert np.array_equal(mad, np.array(want_d), equal_nan=True), what
+            assert np.array_equal(nz, (x == 0).sum(axis=1)), what
+    with np.errstate(all="ignore"):
+        want_k = np.array([pp.excess_kurtosis_f32(r) for r in x], dtype=np.float32)
+    for full in (1, 0):
+        hip_opts("stats.kurt_full_chunks", full)
+        assert np.array_equal(workflow.row_excess_kurtosis(xd), want_k, equal_nan=True), f"seed {seed} n={n} full={full}"
+
+
+@pytest.mark.filterwarnings("ignore::RuntimeWarning")
+@pytest.mark.parametrize("seed", _fuzz_seeds(12))
+def test_fuzz_workflow_mad_threshold(hip_opts, seed):
+    """The MAD threshold of similarity_search.py:1079-1113 on the device, every route of its medians (one pass,
+    two passes, radix select) and of its row statistics, against the host mirror pinned to the reference."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp
+    from seismic_bpmf_amd.threshold import ThresholdGPU
+    rng = np.random.default_rng(78_000 + seed)
+    n = int(rng.choice([600, 5_000, 40_000, 150_000]))
+    window = int(rng.choice([w for w in (50, 257, 4_000, 13_001, 30_000, 60_000) if w <= n]))
+    overlap = float(rng.choice([0.0, 0.25, 0.5, 0.66]))
+    rows = int(rng.integers(1, 6))
+    x = np.stack([_fuzz_row(rng, n) for _ in range(rows)])
+    x[~np.isfinite(x)] = 0.0                      # (a CC series holds no Inf; NaN rows are covered by the variants test)
+    wn = rng.standard_normal(n).astype(np.float32)
+    th = ThresholdGPU(device=0)
+    xd = torch.as_tensor(x, device="cuda")
+    with np.errstate(all="ignore"):
+        want = np.stack([pp.time_dependent_threshold_mad(r, window, 8.0, overlap=overlap, white_noise=wn) for r in x]).astype(np.float32)
+    for mode, min_n in ((2, 0), (1, -1), (0, 0)):
+        hip_opts("stats.bucketed_median", mode)
+        hip_opts("stats.row_grid_min_n", min_n)
+        _, full = th.time_dependent_threshold_mad(xd, window, 8.0, overlap=overlap, white_noise=wn, expand=True)
+        assert np.array_equal(full.cpu().numpy(), want, equal_nan=True), \
+            f"seed {seed} n={n} window={window} overlap={overlap} rows={rows} mode={mode} min_n={min_n}"

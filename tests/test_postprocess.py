@@ -370,3 +370,27 @@ def test_geodesic_antipodal_fallback_keeps_every_other_distance_exact():
     assert 20_003_900 < d[1] < 20_037_600
     hunc, vunc = pp.compute_location_uncertainty(0.0, 0.0, 5.0, np.array([1.0, 1e-9, 1.0]), lon, lat, np.array([4.0, 9.0, 8.0]))
     assert np.isfinite(hunc) and np.isfinite(vunc)
+
+
+def test_excess_kurtosis_mirror_is_scipy_on_one_series():
+    """postprocess.excess_kurtosis_f32 == np.float32(scipy.stats.kurtosis(series)) for ONE float32 series at a time
+    (BPMF/similarity_search.py:640) -- on the row of tests/golden/kurtosis_scalar_pow_row.npz as well, whose m2 the C
+    library's powf (what a NumPy scalar `**` calls) does not square like an array `**` does."""
+    import os
+    from scipy.stats import kurtosis
+    from seismic_bpmf_amd import postprocess as pp
+    rng = np.random.default_rng(5)
+    series = [np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kurtosis_scalar_pow_row.npz"))["row"]]
+    for n in (1, 2, 9, 1000, 8193, 70_001):
+        series.append((rng.standard_normal(n) * rng.uniform(0.01, 3)).astype(np.float32))
+        series.append(np.full(n, 0.5, np.float32))
+    for x in series:
+        with np.errstate(all="ignore"):
+            want = np.float32(kurtosis(x))
+            got = pp.excess_kurtosis_f32(x)
+        assert np.array_equal(got, want, equal_nan=True), x.size
+        if x.size > 8:                      # and from the moments, as the device path finishes it
+            m = np.mean(x, keepdims=True)
+            s2 = (x - m) ** 2
+            with np.errstate(all="ignore"):
+                assert np.array_equal(pp.kurtosis_from_moments_f32(m[0], np.mean(s2), np.mean(s2 ** 2)), want, equal_nan=True)
