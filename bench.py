@@ -417,7 +417,28 @@ def detection_stage(cc, planted, mv, w, local_rank, dist, device, t_offset=0):
     out = {"threshold_ms": round(tm["threshold_ms"], 1), "candidates_ms": round(tm["candidates_ms"], 1),
            "host_merge_ms": round(tm["merge_ms"], 1), "candidates": tm["candidates"], "detections": n_det,
            "planted": found, "planted_found_at_exact_index": exact,
-           "through": "workflow.cc_detections (sanity_check off: the kurtosis pass is timed in profiles/)"}
+           "through": "workflow.cc_detections (sanity_check off: the kurtosis pass is timed beside it)"}
+    if dist is None:
+        # the two optional passes of the same stage, untimed extras at N = 1: the reference's sanity check
+        # (scipy.stats.kurtosis of every CC series, similarity_search.py:633-642; on by default there) and the
+        # MAD variant of the threshold (similarity_search.py:1079-1113), each timed on its second call
+        from seismic_bpmf_amd.threshold import ThresholdGPU
+        th = ThresholdGPU(device=local_rank)
+        wn_mad = np.random.default_rng(6).standard_normal(20_000).astype(np.float32)
+        for name, fn in (("kurtosis_ms", lambda: workflow.row_excess_kurtosis(cc)),
+                         ("mad_threshold_ms", lambda: th.time_dependent_threshold_mad(
+                             cc, int(window_s * sr), 8.0, overlap=0.25, white_noise=wn_mad, expand=False))):
+            try:
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                out[name] = round((time.perf_counter() - t0) * 1e3, 1)
+            except Exception as e:                      # (an extra must not cost the line)
+                out[name] = f"failed: {e}"
+        del th
+        torch.cuda.empty_cache()
     if dist is not None:
         # "RCCL all-gather of CC peaks" (BASELINE configs[3]): every rank contributes its MERGED
         # detections (global template id, CC index, cc, threshold) -- a few thousand 32-byte records,

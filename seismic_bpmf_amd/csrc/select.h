@@ -284,9 +284,11 @@ __device__ float window_median_bucketed(const float* __restrict__ x, long long l
 // the window -- whatever [lo, hi] was derived from; otherwise *ok = 0 (nothing else is touched) and the caller
 // takes a slower route.  SIDE: the same pass also counts |x - side_centre| in SEL_BINS buckets of width
 // 1 / side_inv_w (`side_hist`): from them the caller reads roughly where the middle DEVIATION of the window lies
-// before the pass that selects it.  `nan_seen` as in window_select.
+// before the pass that selects it.  `nan_seen` as in window_select.  LEAN: no radix select among the copies when
+// the bucket ranking does not apply (*ok = 0 instead): the streaming kernel of the MAD threshold stays small enough
+// in registers for two workgroups per CU.
 constexpr int SEL_BAND = 12288;
-template <bool DEV, bool SIDE, class Fix = SelNoFix>
+template <bool DEV, bool SIDE, class Fix = SelNoFix, bool LEAN = false>
 __device__ float window_median_banded(const float* __restrict__ x, long long len, float centre, float lo, float hi,
                                       unsigned* hist, unsigned* sel, float* band, Fix fix, int* nan_seen, int* ok,
                                       float side_centre = 0.0f, float side_inv_w = 0.0f, unsigned* side_hist = nullptr)
@@ -342,6 +344,14 @@ __device__ float window_median_banded(const float* __restrict__ x, long long len
                                                                 (unsigned*)(band + (SEL_BAND - SEL_BUF)), SelNoFix(), nullptr, &fine,
                                                                 (long long)(r_lo - n_below), (long long)(r_hi - n_below));
         if (fine) { *ok = 1; return v; }
+    }
+    if (LEAN && r_hi != r_lo) {
+        // (a caller with a second kernel for what this one leaves, and no registers to spare: two middle ranks
+        // that do not share a bucket take two single-rank selects of the slim kind instead of the paired one)
+        const unsigned k_lo = window_select<false, false>(band, (long long)n_band, 0.0f, r_lo - n_below, hist, sel);
+        const unsigned k_hi = window_select<false, false>(band, (long long)n_band, 0.0f, r_hi - n_below, hist, sel);
+        *ok = 1;
+        return (key_f32(k_lo) + key_f32(k_hi)) / 2.0f;
     }
     unsigned key_hi = 0;
     int both = 0;
