@@ -818,7 +818,7 @@ def main():
             bp_obj["features"] = {"workload": f"saturated_envelopes of {bcfg['S']} x {bcfg['C']} channels x {Nb} samples (float32 in, float32 out)",
                                   "envelope_ms": round(t_env[0], 2), "saturated_envelopes_ms": round(t_env[1], 2),
                                   "fraction_of_a_bp_step": round(t_env[1] / (bp_dt / args.steps * 1e3), 3),
-                                  "how": "Hilbert transform by a float64 real-input FFT pair (hipFFT behind torch.fft), median / MAD by one radix-select launch"}
+                                  "how": "Hilbert transform by a float64 real-input FFT pair (hipFFT behind torch.fft), median / MAD of the valid samples in two reads of the channels by the whole chip (csrc/stats.hip rm_*)"}
             del raw
             torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not args.skip_dense:

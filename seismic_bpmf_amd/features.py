@@ -97,8 +97,9 @@ def envelope(traces, device=None, channels_per_batch=None, precision="float64"):
 
 def row_median_mad(x, skip_zeros=False, device=None):
     """np.median and MAD of every row of a (rows, n) float32 device tensor (over the non-zero
-    samples only when `skip_zeros`), by radix select on the device (csrc/stats.hip).  Returns
-    (median, mad, n_zero) device tensors; nothing is synchronised."""
+    samples only when `skip_zeros`), exact order statistics on the device (csrc/stats.hip: long rows
+    in two reads by the whole chip, short ones by a radix select).  Returns (median, mad, n_zero) device
+    tensors; nothing is synchronised."""
     import ctypes as C
     torch, dev = _torch_device(device)
     x = x.to(device=dev, dtype=torch.float32).contiguous()
@@ -124,7 +125,7 @@ def row_median_mad(x, skip_zeros=False, device=None):
 def saturated_envelopes(traces, anomaly_threshold=1.0e-11, max_dynamic_range=1.0e5, device=None):
     """Device version of BPMF/template_search.py:1525-1572.  Returns (features (S, C, N) float32
     device tensor, data_availability (S,) int32 NumPy array).  The median and MAD of the valid
-    samples of all channels come from ONE launch (radix select, csrc/stats.hip); the decisions per
+    samples of all channels come from ONE call (row_median_mad, csrc/stats.hip); the decisions per
     channel (more than half missing, MAD below the anomaly threshold) are taken on the device, and
     the only transfer to the host is the (S,) availability vector at the end."""
     torch, dev = _torch_device(device)

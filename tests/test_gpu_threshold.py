@@ -282,3 +282,32 @@ def test_row_median_mad_two_read_path_equals_the_one_workgroup_path(hip_opts, n)
             assert np.array_equal(med[r], np.float32(m), equal_nan=True), (n, skip, r)
             assert np.array_equal(mad[r], np.float32(d), equal_nan=True), (n, skip, r)
             assert nz[r] == (x[r] == 0).sum()
+
+
+def test_row_median_mad_two_read_path_when_the_middle_ranks_straddle_a_bucket_edge(hip_opts):
+    """The two-read path histograms a row over 4096 buckets laid around a sampled guess; the two middle ranks of an
+    even count land in DIFFERENT buckets once in a few hundred rows of this length (once in 10 000 day-long rows: row
+    65 of the bench's CC matrix did, and the one-workgroup kernel it was sent to cost 12 ms).  Four seeds where a
+    host restatement of the guess (strided sample, float32 median / MAD, the kernel's bucket expression) says they
+    straddle: the plan takes the adjacent buckets together, the results are NumPy's."""
+    import torch
+    from seismic_bpmf_amd import features
+    f = np.float32
+    rows = []
+    for seed in (64, 278, 358, 738):
+        x = (np.random.default_rng(900_000 + seed).standard_normal(200_000) * 0.05).astype(f)
+        n = x.size
+        smp = x[(np.arange(4096, dtype=np.uint64) * np.uint64(n) // np.uint64(4096)).astype(np.int64)]
+        m = np.median(smp).astype(f)
+        sigma = f(1.4826) * np.median(np.abs(smp - m)).astype(f)
+        lo, inv_w = f(m - f(6.0) * sigma), f(f(4096) / (f(12.0) * sigma))
+        s = np.sort(x)
+        b_lo, b_hi = (int(f(f(v - lo) * inv_w)) for v in (s[(n - 1) // 2], s[n // 2]))
+        assert b_hi == b_lo + 1, (seed, b_lo, b_hi)          # (the premise of the test)
+        rows.append(x)
+    x = np.stack(rows)
+    hip_opts("stats.row_grid_min_n", 0)
+    med, mad, nz = (t.cpu().numpy() for t in features.row_median_mad(torch.as_tensor(x, device="cuda"), True))
+    for r in range(x.shape[0]):
+        m = np.median(x[r])
+        assert med[r] == m and mad[r] == np.median(np.abs(x[r] - m)) and nz[r] == 0, r
