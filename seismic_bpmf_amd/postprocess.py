@@ -539,11 +539,27 @@ def kurtosis_from_moments_f32(mean, m2, m4):
     (one random row in 2500 ends 2 ulp apart), and BPMF passes one series (similarity_search.py:640).  The device
     hands out (mean, m2, m4) per row (bpmf_row_kurtosis_parts_dev) and the host finishes here, with whatever
     NumPy / libm the reference itself would run on."""
-    mean, m2, m4 = np.float32(mean), np.float32(m2), np.float32(m4)
     with np.errstate(all="ignore"):
-        if m2 <= (np.finfo(np.float32).eps * mean) ** 2:
-            return np.float32(np.nan)
-        return np.float32(m4 / m2 ** 2.0) - np.float32(3)
+        return _kurtosis_from_moments(np.float32(mean), np.float32(m2), np.float32(m4))
+
+
+_F32_EPS = np.finfo(np.float32).eps
+_F32_NAN = np.float32(np.nan)
+_F32_THREE = np.float32(3)
+
+
+def _kurtosis_from_moments(mean, m2, m4):
+    """(np.float32 scalars in, warnings handled by the caller: a row of a loop over a CC matrix)"""
+    if m2 <= (_F32_EPS * mean) ** 2:
+        return _F32_NAN
+    return np.float32(m4 / m2 ** 2.0) - _F32_THREE
+
+
+def kurtosis_from_moments_rows(parts):
+    """kurtosis_from_moments_f32 for every row of a (rows, 3) float32 array of (mean, m2, m4)."""
+    parts = np.asarray(parts, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        return np.array([_kurtosis_from_moments(p[0], p[1], p[2]) for p in parts], dtype=np.float32)
 
 
 # ---------------------------------------------------------------- event relocation ---

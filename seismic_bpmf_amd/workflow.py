@@ -69,8 +69,8 @@ def row_excess_kurtosis(cc):
             _lib.check(rc, "bpmf_row_kurtosis_parts_dev")
     # (mean, m2, m4) per row from the device; the last expression on NumPy scalars, as SciPy evaluates it on one
     # series -- postprocess.kurtosis_from_moments_f32 says why that is not the same as finishing on the device
-    from .postprocess import kurtosis_from_moments_f32
-    return np.array([kurtosis_from_moments_f32(*p) for p in parts.cpu().numpy()], dtype=np.float32)
+    from .postprocess import kurtosis_from_moments_rows
+    return kurtosis_from_moments_rows(parts.cpu().numpy())
 
 
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
