@@ -27,11 +27,19 @@ def search_window(moveouts_t, minimum_interevent_samp, step):
     return win / step
 
 
+def search_windows(moveouts, minimum_interevent_samp, step):
+    """search_window for every template of a (T, S, C) moveout array at once (same integers)."""
+    d_mv = np.max(moveouts, axis=-1) - np.min(moveouts, axis=-1)
+    d_mv = np.median(d_mv, axis=-1).astype(np.int64) + 1
+    win = np.minimum(10 * minimum_interevent_samp, np.maximum(d_mv, minimum_interevent_samp))
+    return win / step
+
+
 def merge_candidates(index, cc, search_win):
     """The reference's sequential pair-wise merge (BPMF/similarity_search.py:240-251) applied to
     the candidate list: neighbours closer than `search_win` keep only the larger CC."""
-    idx = list(index)
-    val = list(cc)
+    idx = np.asarray(index).tolist()
+    val = np.asarray(cc).tolist()
     q = 1
     while q < len(idx):
         if idx[q] - idx[q - 1] < search_win:
@@ -160,23 +168,31 @@ def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, mi
     mv = np.asarray(moveouts)
     rejected = row_excess_kurtosis(cc) > max_kurto if sanity_check else np.zeros(weights.shape[0], bool)
     out = {}
-    for t in range(weights.shape[0]):
+    # (the candidates come sorted by row, then index: the rows are slices of four plain arrays, not 500 masks over
+    # all records and field views of each; the search windows of all templates in one go)
+    n_t = weights.shape[0]
+    bounds = np.searchsorted(cand["row"], np.arange(n_t + 1))
+    c_index = np.ascontiguousarray(cand["index"])
+    c_cc = np.ascontiguousarray(cand["cc"])
+    c_thr = np.ascontiguousarray(cand["threshold"])
+    wins = search_windows(mv.reshape(n_t, mv.shape[1], -1), min_iet, step)
+    lo_edge = pp.sec_to_samp(data_buffer_sec, sr) if remove_edges else None
+    hi_edge = pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr) if remove_edges and data_duration_sec is not None else None
+    empty = (np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.float32)) if with_values \
+        else np.zeros(0, dtype=np.int64)
+    for t in range(n_t):
         if rejected[t]:
-            out[t] = (np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.float32)) if with_values \
-                else np.zeros(0, dtype=np.int64)
+            out[t] = empty
             continue
-        mine = cand[cand["row"] == t]
-        win = search_window(mv[t].reshape(mv.shape[1], -1), min_iet, step)
-        idx = merge_candidates(mine["index"], mine["cc"], win)
+        b0, b1 = bounds[t], bounds[t + 1]
+        idx = merge_candidates(c_index[b0:b1], c_cc[b0:b1], wins[t])
         if remove_edges:                        # (data_buffer_sec is given: checked on entry)
-            samples = idx * step
-            idx = idx[samples >= pp.sec_to_samp(data_buffer_sec, sr)]
-            if data_duration_sec is not None:
-                samples = idx * step
-                idx = idx[samples < pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr)]
+            idx = idx[idx * step >= lo_edge]
+            if hi_edge is not None:
+                idx = idx[idx * step < hi_edge]
         if with_values:
-            pos = np.searchsorted(mine["index"], idx)           # candidates come sorted by index within a row
-            out[t] = (idx, mine["cc"][pos].astype(np.float32), mine["threshold"][pos].astype(np.float32))
+            pos = b0 + np.searchsorted(c_index[b0:b1], idx)     # candidates come sorted by index within a row
+            out[t] = (idx, c_cc[pos], c_thr[pos])
         else:
             out[t] = idx
     if timings is not None:
