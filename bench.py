@@ -602,7 +602,7 @@ def main():
                 "avg_launch_ms": round(k_ms, 3), "launches": len(mf_kernel_ms),
                 "algorithmic": "2*L*S*C flop per network-CC-sample x T*n_corr samples per launch",
                 "frac_note": ("peak = 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz (nominal).  Cycle counters in the kernel "
-                              "(profiles/r04_mf_phase_cycles.txt, tools/phase/, NOT measured in this run): at L = 256 the matrix "
+                              "(profiles/r05_mf_phase_cycles.txt, tools/phase/, NOT measured in this run): at L = 256 the matrix "
                               "pipe is busy 95 % of the counted cycles and the chip sustains ~2.3 GHz under this instruction mix; "
                               "L / (L + 16) = 0.941 of the issued MFMA flops are direct-form flops: 0.941 x 0.96 x 0.95 = 0.86"),
                 "hbm_frac_informational": round(
@@ -757,8 +757,10 @@ def main():
                                "traffic_source": ("profiles/bp_beam_pmc.json: separate rocprofv3 --pmc passes over this "
                                                   "launch, committed, NOT measured in this run") if bp_traffic is not None else None,
                                "frac_note": ("peak = 256 CU x 256 B/clk x 2.4 GHz (nominal).  Under this kernel the chip sustains "
-                                             "2.18 GHz (GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r02_pmc.json, NOT measured in "
-                                             "this run): 0.78 of the LDS rate at the sustained clock, LDS pipe busy 78 %"),
+                                             "1.9 - 2.1 GHz depending on the box (cycle counters of the instrumented build, "
+                                             "profiles/r05_bp_fast_phase_cycles.txt and ..._slow_box.txt, NOT measured in this run: the "
+                                             "same 181 5xx cycles per group and wave on a 143 ms box and on a 157 ms box): 0.89 of the "
+                                             "ds_read_b64 rate at the sustained clock on either"),
                                "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
