@@ -333,6 +333,12 @@ int bpmf_row_median_mad_ws_dev(const float *d_x, size_t rows, size_t n, int skip
                                void *d_workspace, size_t workspace_bytes, bpmf_stream_t stream,
                                float *d_median, float *d_mad, int64_t *d_n_zero);
 
+/* The last step of saturated_envelopes (BPMF/template_search.py:1562-1572) in one pass over the (rows, n)
+ * envelopes: (x - median[row]) / mad[row] in float32, 0 for missing samples (exact zeros) and for rows with
+ * dead[row] != 0, capped at `cap` (np.minimum: a NaN stays a NaN).  d_out may be d_x.  rows <= 65535 per call. */
+int bpmf_saturate_rows_dev(const float *d_x, const float *d_median, const float *d_mad, const int32_t *d_dead,
+                           size_t rows, size_t n, float cap, bpmf_stream_t stream, float *d_out);
+
 /* time_dependent_threshold(time_series, sliding_window, overlap, threshold_type="mad",
  * white_noise) of BPMF/similarity_search.py:1079-1113 for every row of a (rows, n) CC matrix:
  * `window` = sliding_window, `shift` = int((1 - overlap) * sliding_window).  d_thr_windows

@@ -136,11 +136,20 @@ def saturated_envelopes(traces, anomaly_threshold=1.0e-11, max_dynamic_range=1.0
     # channels the reference zeroes: more than half of the samples missing, or MAD < threshold (a NaN
     # MAD -- no valid sample -- only occurs together with the first condition)
     dead = (n_missing.to(torch.float64) > n_samples / 2) | ~(mad.to(torch.float64) >= anomaly_threshold)
-    missing = rows == 0.0
-    std = (rows - median[:, None]) / mad[:, None]            # float32, NumPy's operations
-    std = torch.where(missing, torch.zeros((), dtype=torch.float32, device=dev), std)
-    cap = torch.tensor(max_dynamic_range, dtype=torch.float32, device=dev)
-    out = torch.where(dead[:, None], torch.zeros((), dtype=torch.float32, device=dev), torch.minimum(std, cap))
+    # (x - median) / MAD in float32 (NumPy's operations), 0 for missing samples and dead channels, capped: one pass,
+    # in place over the envelopes (csrc/stats.hip saturate_rows_kernel; it was five element-wise passes of torch)
+    import ctypes as C
+    out = rows
+    dead_i = dead.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        for r0 in range(0, rows.shape[0], 65535):
+            nr = min(65535, rows.shape[0] - r0)
+            rc = _lib.lib().bpmf_saturate_rows_dev(C.c_void_p(rows[r0:].data_ptr()), C.c_void_p(median[r0:].data_ptr()),
+                                                   C.c_void_p(mad[r0:].data_ptr()), C.c_void_p(dead_i[r0:].data_ptr()),
+                                                   nr, n_samples, float(np.float32(max_dynamic_range)),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                                   C.c_void_p(out[r0:].data_ptr()))
+            _lib.check(rc, "bpmf_saturate_rows_dev")
     availability = (~dead).reshape(n_stations, n_components).sum(dim=1).to(torch.int32).cpu().numpy()
     return out.reshape(n_stations, n_components, n_samples), availability
 

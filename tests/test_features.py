@@ -104,3 +104,33 @@ def test_device_kurtosis_equals_the_reference_output(oracle_lib):
     rng = np.random.default_rng(4)
     x = (rng.standard_normal((2, 3, 3001)) * np.array([1.0, 1e-4, 30.0])[None, :, None]).astype(np.float32)
     assert np.array_equal(kurtosis(x, 37).cpu().numpy(), oracle_lib.kurtosis(x, 37))
+
+
+@pytest.mark.gpu
+def test_saturate_rows_kernel_equals_the_element_wise_formulation():
+    """saturated_envelopes' last step is one kernel (csrc/stats.hip saturate_rows_kernel); it must give the bits of
+    the element-wise float32 formulation it replaced -- (x - median) / MAD, 0 for missing samples and dead channels,
+    np.minimum against the cap -- on channels with gaps, a dead channel, a channel that is mostly missing, a spike
+    beyond the cap, a NaN."""
+    import torch
+    from seismic_bpmf_amd.features import envelope, row_median_mad, saturated_envelopes
+    rng = np.random.default_rng(12)
+    tr = rng.standard_normal((3, 3, 20_011)).astype(np.float32)
+    tr[0, 0, 5_000:9_000] = 0.0
+    tr[0, 1] = 0.0
+    tr[1, 0, : 15_000] = 0.0
+    tr[1, 1, 7_777] = 3.0e7
+    tr[2, 2] *= 1.0e-14                         # MAD below the anomaly threshold
+    tr[2, 0, 100] = np.nan
+    feat, avail = saturated_envelopes(tr, max_dynamic_range=1.0e3)
+    wf = envelope(tr)
+    rows = wf.reshape(9, -1)
+    median, mad, n_missing = row_median_mad(rows, skip_zeros=True)
+    dead = (n_missing.to(torch.float64) > rows.shape[1] / 2) | ~(mad.to(torch.float64) >= 1.0e-11)
+    std = (rows - median[:, None]) / mad[:, None]
+    std = torch.where(rows == 0.0, torch.zeros((), device=rows.device), std)
+    want = torch.where(dead[:, None], torch.zeros((), device=rows.device),
+                       torch.minimum(std, torch.tensor(1.0e3, dtype=torch.float32, device=rows.device)))
+    assert np.array_equal(feat.cpu().numpy().reshape(9, -1), want.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(avail, (~dead).reshape(3, 3).sum(dim=1).cpu().numpy())
+    assert float(feat.max()) == 1.0e3                      # (the spike of channel (1, 1) is beyond the cap)
