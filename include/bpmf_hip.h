@@ -333,6 +333,14 @@ int bpmf_row_median_mad_ws_dev(const float *d_x, size_t rows, size_t n, int skip
                                void *d_workspace, size_t workspace_bytes, bpmf_stream_t stream,
                                float *d_median, float *d_mad, int64_t *d_n_zero);
 
+/* The element-wise steps of the envelope (BPMF/template_search.py:1598-1617) around the library FFTs, one pass each:
+ * d_spectrum (rows, bins) complex128, the rfft of the traces, becomes -i X in place with the DC bin -- and, when the
+ * trace length is even, the last (Nyquist) bin -- cleared: its irfft is the Hilbert transform; then
+ * d_out[i] = (float) sqrt((double) d_x[i]^2 + d_h[i]^2), float64 arithmetic, over `total` samples.  rows <= 65535. */
+int bpmf_hilbert_spectrum_dev(void *d_spectrum, size_t rows, size_t bins, int n_is_even, bpmf_stream_t stream);
+int bpmf_envelope_combine_dev(const float *d_x, const double *d_h, size_t total, bpmf_stream_t stream,
+                              float *d_out);
+
 /* The last step of saturated_envelopes (BPMF/template_search.py:1562-1572) in one pass over the (rows, n)
  * envelopes: (x - median[row]) / mad[row] in float32, 0 for missing samples (exact zeros) and for rows with
  * dead[row] != 0, capped at `cap` (np.minimum: a NaN stays a NaN).  d_out may be d_x.  rows <= 65535 per call. */

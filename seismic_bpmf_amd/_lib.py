@@ -78,6 +78,8 @@ SIGNATURES = {
     "bpmf_row_median_mad_workspace_bytes": (_sz, [_sz, _sz]),
     "bpmf_row_median_mad_ws_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _sz, _vp, _vp, _vp, _vp]),
     "bpmf_saturate_rows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, C.c_float, _vp, _vp]),
+    "bpmf_hilbert_spectrum_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp]),
+    "bpmf_envelope_combine_dev": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "bpmf_tdt_mad_num_windows": (_sz, [_sz, _sz, _sz]),
     "bpmf_tdt_mad_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz]),
     "bpmf_tdt_mad_dev": (C.c_int, [_vp, _vp, _sz, C.c_float, _sz, _sz, _sz, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),

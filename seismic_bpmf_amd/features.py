@@ -83,9 +83,29 @@ def envelope(traces, device=None, channels_per_batch=None, precision="float64"):
         per_channel = n * (8 if dtype == torch.float64 else 4) * 5        # x, X, -iX, H[x], temporaries
         channels_per_batch = max(1, min(x.shape[0], int(6e9 // max(per_channel, 1))))
     out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    fused = dtype == torch.float64 and x.dtype == torch.float32 and x.is_contiguous()
+    if fused:
+        import ctypes as C
+        lib = _lib.lib()
+        channels_per_batch = min(channels_per_batch, 65535)
     for i in range(0, x.shape[0], channels_per_batch):
         xb = x[i:i + channels_per_batch].to(dtype)
         X = torch.fft.rfft(xb, dim=-1)
+        if fused:
+            # -i X with the DC (and Nyquist) bin cleared, in place; then sqrt(x^2 + h^2) from the float32 trace and
+            # the float64 transform: one pass each (csrc/stats.hip; the tensor expressions below made ten)
+            del xb
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            with torch.cuda.device(dev):
+                _lib.check(lib.bpmf_hilbert_spectrum_dev(C.c_void_p(X.data_ptr()), X.shape[0], X.shape[1], int(n % 2 == 0),
+                                                         stream), "bpmf_hilbert_spectrum_dev")
+                h = torch.fft.irfft(X, n=n, dim=-1)
+                del X
+                xs, os_ = x[i:i + channels_per_batch], out[i:i + channels_per_batch]
+                _lib.check(lib.bpmf_envelope_combine_dev(C.c_void_p(xs.data_ptr()), C.c_void_p(h.data_ptr()), xs.numel(),
+                                                         stream, C.c_void_p(os_.data_ptr())), "bpmf_envelope_combine_dev")
+            del h
+            continue
         X[:, 0] = 0                      # the DC bin (and, for even n, the Nyquist bin) has no quadrature part
         if n % 2 == 0:
             X[:, -1] = 0

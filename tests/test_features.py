@@ -134,3 +134,22 @@ def test_saturate_rows_kernel_equals_the_element_wise_formulation():
     assert np.array_equal(feat.cpu().numpy().reshape(9, -1), want.cpu().numpy(), equal_nan=True)
     assert np.array_equal(avail, (~dead).reshape(3, 3).sum(dim=1).cpu().numpy())
     assert float(feat.max()) == 1.0e3                      # (the spike of channel (1, 1) is beyond the cap)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [16, 1001, 20_000, 131_071])
+def test_envelope_fused_steps_equal_the_tensor_expressions(n):
+    """envelope() on float32 traces runs its two element-wise steps as one kernel each (-i X in place with the DC /
+    Nyquist bins cleared; sqrt(x^2 + h^2) from the float32 trace and the float64 transform: csrc/stats.hip); on a
+    float64 copy of the same traces it takes the tensor expressions.  Same FFT calls, same IEEE operations: same bits,
+    for even and odd lengths, with a zero channel, a gap and a large offset."""
+    import torch
+    from seismic_bpmf_amd.features import envelope
+    rng = np.random.default_rng(n)
+    tr = rng.standard_normal((2, 3, n)).astype(np.float32)
+    tr[0, 1] = 0.0
+    tr[1, 0, n // 3: n // 2] = 0.0
+    tr[1, 2] += 1000.0
+    fused = envelope(tr).cpu().numpy()
+    plain = envelope(torch.as_tensor(tr).double()).cpu().numpy()
+    assert fused.dtype == np.float32 and np.array_equal(fused, plain)
