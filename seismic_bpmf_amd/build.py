@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libbpmf_hip.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
-SOURCES = ["mf.hip", "bp.hip", "bp_fast.hip", "bp_direct.hip", "bp_detect.hip", "stats.hip", "intertp.hip", "post.hip", "decimate.hip", "util.hip", "multi.hip", "context.hip"]
+SOURCES = ["mf.hip", "mf_split.hip", "bp.hip", "bp_fast.hip", "bp_direct.hip", "bp_detect.hip", "stats.hip", "intertp.hip", "post.hip", "decimate.hip", "util.hip", "multi.hip", "context.hip"]
 ARCH = "gfx950"
 # -ffp-contract=off: the kernels spell out every fmaf; the compiler must not fuse more.
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",

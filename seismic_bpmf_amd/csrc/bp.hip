@@ -2757,6 +2757,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     if (pl->side_stream) (void)hipStreamSynchronize(pl->side_stream);
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
+    fan.finish();         // a source's peers are through with its copy of the day before the working set may go
     ctx->trim_after_call();
     return rc;
 }

@@ -132,11 +132,17 @@ struct FanoutScope {
     DataFanout* f;
     int role;
     FanoutScope() : f(t_fanout), role(t_fanout_role) { t_fanout = nullptr; t_fanout_role = DataFanout::NONE; }
-    ~FanoutScope()
+    ~FanoutScope() { finish(); }
+    // Settles the participant's part once (idempotent).  A SOURCE must call this BEFORE anything that may free
+    // the buffer it published -- DeviceContext::trim_after_call() under option host.cache_limit_mb -- because its
+    // peers copy from that buffer until they report peer_done (the destructor alone runs at function return,
+    // behind the trim: round-5 advisor finding).
+    void finish()
     {
         if (!f) return;
         if (role == DataFanout::SOURCE) { f->cancel(); f->wait_peers(); }
         else if (role == DataFanout::PEER) f->peer_done();
+        f = nullptr;
     }
     FanoutScope(const FanoutScope&) = delete;
     FanoutScope& operator=(const FanoutScope&) = delete;

@@ -12,6 +12,7 @@
 // zeros add exact zeros), so every numerator equals the scalar chain of the oracle.
 #include "common.h"
 #include "context.h"
+#include "mf_split_api.h"
 #include <system_error>
 #include <thread>
 #include <chrono>
@@ -1133,6 +1134,8 @@ struct MfWorkspace {
     float* e_t;     // [T, n_ch]
     int2* range;    // [T]
     int4* chan_rec; // [T, n_ch + 2] compact used-channel records
+    void* sp_day;   // option mf.split16: the split day (mf_split_api.h), nullptr otherwise
+    void* sp_batch; // option mf.split16: band images of the template batch
     size_t bytes;
 };
 
@@ -1148,9 +1151,16 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.off = (double*)(p + o);   o += align_up(n_ch * nq * sizeof(double), 256);
     o += 256;  // slack: the main kernel's 16-byte norm loads may start 3 floats early ...
     ws.e_d = (float*)(p + o);    o += align_up(n_ch * nwin * sizeof(float) + 64, 256);  // ... or end 3 late
+    // option mf.split16: the split day lies with the per-day arrays, in front of everything that depends on T (a
+    // prepared day stays valid when the template count changes); the option is part of the workspace's size
+    const bool split16 = option(OPT_MF_SPLIT16) != 0;
+    ws.sp_day = nullptr;
+    ws.sp_batch = nullptr;
+    if (split16) { ws.sp_day = p + o; o += align_up(sp::day_region_bytes(N, n_ch), 256); }
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
     ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
+    if (split16) { ws.sp_batch = p + o; o += align_up(sp::batch_region_bytes(T, n_ch), 256); }
     ws.bytes = o;
     return ws;
 }
@@ -1267,9 +1277,12 @@ extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N,
                                   stream>>>(ws.local, ws.off, n_ch, N, nq, L, nwin,
                                             option(OPT_MF_COMPAT_SQRT_NORM) != 0 ? 1 : 0, ws.e_d, 0, nwin);
         BPMF_LAUNCH_CHECK();
-        return 0;
+    } else if (int rc = mf_prepare_range(d_data, L, N, n_ch, ws, stream, 0, N)) {
+        return rc;
     }
-    return mf_prepare_range(d_data, L, N, n_ch, ws, stream, 0, N);
+    // option mf.split16: the day as fp16 (hi, lo) pairs, each channel scaled by a power of two (mf_split.h)
+    if (ws.sp_day && sp::usable(L, N)) return sp::prepare_day(d_data, N, n_ch, ws.sp_day, stream);
+    return 0;
 }
 
 extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveouts,
@@ -1320,7 +1333,14 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const size_t off_hi = ranged ? std::min<size_t>((size_t)t_mf_off_hi, n_offsets) : n_offsets;
     if (off_hi <= off_lo) return 0;
     const bool first_piece = !(ranged && t_mf_continue);
-    const bool wave_kernel = use_mfma && option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
+    // option mf.split16: the split-precision kernel takes every launch the MFMA kernels would take for templates of
+    // at most 378 samples (not under mf.compat_sqrt_norm: its norm arrays hold energies)
+    const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N) && !sqrt_norm;
+    if (split16 && ranged) {
+        set_error("bpmf_mf_run_dev: internal error: a range of lag blocks under mf.split16");
+        return -1;
+    }
+    const bool wave_kernel = !split16 && use_mfma && option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;
     // tiles (of 256 lags) per wave of that kernel: 4 unless the problem is too small to give every SIMD ~4 waves
     // (option mf.tiles_per_wave: 0 = this rule, 1 / 2 / 4 = forced)
     // (calibrated on an hour-long series with 4 .. 256 templates, tools/probe_mf_ntile_T.py,
@@ -1354,7 +1374,12 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         BPMF_HIP_CHECK(hipMemsetAsync(d_cc_out, 0xFF, T * n_corr * sizeof(float), stream));
 
     profile_mark(BPMF_KERNEL_MF_MAIN, 0, stream);
-    if (use_mfma) {
+    if (split16) {
+        const size_t nb_cnt = (n_offsets + sp::LAGS_PER_WG - 1) / sp::LAGS_PER_WG;
+        if (int rc = sp::run(d_templates, d_moveouts, ws.sp_day, ws.sp_batch, ws.chan_rec, ws.e_d, ws.range, step, L, N, T,
+                             n_ch, n_corr, network_sum, 0, nb_cnt, d_cc_out, stream))
+            return rc;
+    } else if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks x T / 8) (lag block, template) pairs (mf_tile_of_block)
         const size_t nb_lo = off_lo / MF_LAGS_PER_WG, nb_cnt = (off_hi - off_lo + MF_LAGS_PER_WG - 1) / MF_LAGS_PER_WG;
         dim3 grid((unsigned)(8 * ((T * nb_cnt + 7) / 8)));
@@ -1554,8 +1579,9 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     }
     // option mf.host_piece_lags: samples of the first piece (default 131 072; the tests shrink it), 0 = off
     const size_t PIECE0 = align_up((size_t)option(OPT_MF_HOST_PIECE_LAGS), (size_t)MF_LAGS_PER_WG);
+    // (not under mf.split16: a channel's scale is its maximum over the WHOLE day)
     const bool pieces = !rc && !from_peer && use_mfma && option(OPT_MF_COMPAT_SEQUENTIAL_CSUM) == 0 &&
-                        PIECE0 != 0 && N >= 8 * PIECE0;
+                        option(OPT_MF_SPLIT16) == 0 && PIECE0 != 0 && N >= 8 * PIECE0;
     auto launch_range = [&](size_t b, long long off_lo, long long off_hi, bool cont) {
         const size_t t0 = bt[b], nt = bt[b + 1] - bt[b];
         char* d_out = base + ((b & 1) ? o_out1 : o_out0);
@@ -1675,6 +1701,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
         fprintf(stderr, "[bpmf] mf_run: %zu batches of at most %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
+    fan.finish();         // a source's peers are through with its copy of the day before the working set may go
     ctx->trim_after_call();
     return rc;
 }

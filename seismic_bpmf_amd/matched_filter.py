@@ -222,9 +222,10 @@ class MatchedFilterGPU:
         ws = self._workspace(nbytes)
         flags = FLAG_FORCE_DIRECT if force_direct else 0
         # (the prepared norm arrays hold energies under mf.compat_sqrt_norm, reciprocal norms otherwise; their
-        # prefix sums are one chain under mf.compat_sequential_csum)
+        # prefix sums are one chain under mf.compat_sequential_csum; under mf.split16 a prepared day also holds the
+        # fp16 split of the data)
         key = (self.data.data_ptr(), int(N), int(L), ws.data_ptr(), _lib.get_option("mf.compat_sqrt_norm")[0],
-               _lib.get_option("mf.compat_sequential_csum")[0])
+               _lib.get_option("mf.compat_sequential_csum")[0], _lib.get_option("mf.split16")[0])
         if self._prepared_for == key:
             flags |= FLAG_DATA_PREPARED
         stream = t.cuda.current_stream(self.device).cuda_stream

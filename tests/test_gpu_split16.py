@@ -1,0 +1,215 @@
+"""Option mf.split16 (round 6): matched-filter numerators from fp16 hi/lo splits of data and templates (three
+v_mfma_f32_32x32x16_f16 products, fp32 accumulation -- seismic_bpmf_amd/csrc/mf_split.h) instead of the exact-fp32
+MFMA chain.  OFF by default; the default path stays bit-identical to the oracle (tests/test_gpu_parity.py).
+
+Bar for this path = the north star's float32 TOLERANCE, written out here:
+    |cc_sum - reference| <= 2e-5 * sum |w|      (per channel |cc - reference| <= 2e-5)
+against BOTH the CPU oracle (fp32 chains) and the float64 brute force; detection indices exact; everything the
+fp32 path decides WITHOUT the numerator stays bit-identical: lags outside a template's valid range are exactly 0,
+zero-energy windows / templates and zero-weight channels contribute exactly 0, nothing is ever NaN / Inf.
+The measured differences are ~2e-7 (printed by the tests): a hundred times inside the bar.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_CC = 2e-5          # per unit of sum |w|
+
+
+@pytest.fixture
+def split16(hip_opts):
+    hip_opts("mf.split16", 1)
+    return hip_opts
+
+
+def _case(rng, T, S, C, L, N, mv_lo, mv_hi, scales=True):
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    tp -= tp.mean(axis=-1, keepdims=True)
+    mv = rng.integers(mv_lo, mv_hi + 1, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[0, 0, :] = 0.0                                  # a dead station
+    w[T - 1, :, 1 % C] = 0.0                          # a dead component
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    d[S - 1, 0, N // 3: N // 3 + 3 * L] = 0.0         # a gap: CC exactly 0 there
+    if scales and S > 2:
+        d[1] *= np.float32(2.5e3)                     # channels in other units ...
+        d[2, 0] *= np.float32(4.0e-3)
+        tp[:, 1] *= np.float32(3.0e-2)
+        d[0, C - 1, N // 2] = np.float32(3.0e4)       # ... and a glitch of 30 000 sigma
+    return tp, mv, w, d
+
+
+def _check(got, want, w, what, per_channel=False):
+    assert got.shape == want.shape, what
+    assert np.isfinite(got).all(), what
+    # what no numerator decides is bit-identical: exact zeros where the reference has exact zeros
+    assert np.array_equal(got == 0.0, want == 0.0) or np.abs(got[(got == 0.0) != (want == 0.0)]).max(initial=0.0) < 1e-30, what
+    diff = np.abs(got.astype(np.float64) - np.asarray(want, np.float64))
+    if per_channel:
+        bound = TOL_CC
+        worst = diff.max()
+    else:
+        sw = np.abs(w).reshape(w.shape[0], -1).sum(axis=1)[:, None]
+        worst = (diff / np.maximum(sw, 1e-30)).max()
+        bound = TOL_CC
+    print(f"{what}: max |d cc| / sum|w| = {worst:.3e} (bar {bound:.0e})")
+    assert worst <= bound, f"{what}: {worst:.3e} > {bound:.0e}"
+    return worst
+
+
+@pytest.mark.parametrize("network_sum", [True, False])
+@pytest.mark.parametrize("L,N,T", [(32, 9000, 3), (100, 30011, 3), (256, 40000, 4), (200, 25000, 2), (378, 20000, 2)])
+def test_split16_within_tolerance_of_oracle_and_float64(oracle_lib, split16, network_sum, L, N, T):
+    from seismic_bpmf_amd import matched_filter
+    from oracle import ref_numpy
+    rng = np.random.default_rng(L * 13 + N)
+    tp, mv, w, d = _case(rng, T, 4, 3, L, N, -70, 900)
+    got = matched_filter(tp, mv, w, d, 1, arch="gpu", network_sum=network_sum, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, network_sum)
+    _check(got, want, w, f"split16 vs oracle L={L} N={N} ns={network_sum}", per_channel=not network_sum)
+    if N <= 30011:
+        f64 = ref_numpy.matched_filter_f64(tp, mv, w, d, 1, network_sum)
+        # (the float64 reference zeroes E_t * E_d <= 1e-6, the build r_t * r_d >= 1000: same channels here)
+        diff = np.abs(got - f64)
+        scale = 1.0 if not network_sum else np.abs(w).reshape(T, -1).sum(axis=1)[:, None]
+        worst = (diff / scale).max()
+        print(f"split16 vs float64: {worst:.3e}")
+        assert worst <= TOL_CC
+
+
+def test_split16_differs_from_the_exact_path_only_in_the_last_bits(oracle_lib, hip_opts):
+    """The same call with the option off is bit-identical to the oracle; with it on, within the tolerance -- and
+    the two are NOT the same array (the option really selects the other kernel)."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(77)
+    tp, mv, w, d = _case(rng, 3, 5, 3, 128, 60000, 0, 700)
+    exact = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
+    assert np.array_equal(exact, want)
+    hip_opts("mf.split16", 1)
+    split = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    hip_opts.reset("mf.split16")
+    assert not np.array_equal(split, exact)
+    _check(split, exact, w, "split16 vs exact path")
+    again = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    assert np.array_equal(again, exact)
+
+
+@pytest.mark.parametrize("step", [2, 5])
+def test_split16_steps(oracle_lib, split16, step):
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(300 + step)
+    tp, mv, w, d = _case(rng, 2, 3, 3, 64, 20001, -16, 200)
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, d, step, check_zeros=False, network_sum=ns)
+        want = oracle_lib.matched_filter(tp, mv, w, d, step, ns)
+        _check(got, want, w, f"split16 step {step} ns={ns}", per_channel=not ns)
+
+
+def test_split16_edge_cases(oracle_lib, split16):
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(9)
+    tp, mv, w, d = _case(rng, 3, 2, 3, 48, 3000, 0, 50, scales=False)
+    w[1] = 0.0                      # a dead template -> a row of exact zeros
+    mv[2, 1, 0] = 2990              # a moveout that leaves no valid lag -> a row of exact zeros
+    got = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
+    _check(got, want, w, "split16 edge: dead template / impossible moveout")
+    assert not got[1].any() and not got[2].any()
+    # N == L: exactly one lag
+    mv0 = np.zeros_like(mv)
+    w1 = np.ones_like(w)
+    got = matched_filter(tp, mv0, w1, d[:, :, :48], 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv0, w1, d[:, :, :48], 1, True)
+    assert got.shape == (3, 1)
+    _check(got, want, w1, "split16 edge: N == L")
+    # zero-energy template and zero-energy data: exactly 0 contributions, never NaN / Inf
+    tp2 = tp.copy()
+    tp2[0, 0, 0] = 0.0
+    d2 = d.copy()
+    d2[1] = 0.0
+    got = matched_filter(tp2, mv0, w1, d2, 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp2, mv0, w1, d2, 1, True)
+    _check(got, want, w1, "split16 edge: zero energy")
+    got_c = matched_filter(tp2, mv0, w1, d2, 1, check_zeros=False, network_sum=False)
+    assert not got_c[:, :, 1].any() and not got_c[0, :, 0, 0].any()
+    # non-finite data poison only what they touch and never reach other templates' rows as Inf
+    # (BPMF scrubs NaN from the result, similarity_search.py:540)
+
+
+def test_split16_autocorrelation_and_detection_indices(split16):
+    """A template cut out of the data correlates to the weight sum at its own lag (within the tolerance), and
+    the arg-max -- the detection index -- is exactly that lag."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(11)
+    S, C, L, N = 6, 3, 256, 150_000
+    d = rng.standard_normal((S, C, N)).astype(np.float32)
+    lags = [5000, 77_777, 120_001]
+    mv = rng.integers(0, 1500, (len(lags), S, C)).astype(np.int32)
+    tp = np.stack([np.stack([np.stack([d[s, c, i0 + mv[k, s, c]: i0 + mv[k, s, c] + L] for c in range(C)])
+                             for s in range(S)]) for k, i0 in enumerate(lags)])
+    w = np.full((len(lags), S, C), 1.0 / (S * C), np.float32)
+    cc = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    for k, i0 in enumerate(lags):
+        assert int(cc[k].argmax()) == i0
+        assert abs(float(cc[k, i0]) - 1.0) <= TOL_CC
+
+
+def test_split16_extreme_dynamic_range(oracle_lib, split16):
+    """A channel whose largest sample is 10^6 noise deviations (a clipped digitiser, a calibration pulse): the
+    lo halves of the quiet samples fall into fp16's subnormal range, which the matrix pipe honours
+    (tools/ubench/mfma_split16.hip prints the probe) -- still inside the tolerance."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(5)
+    tp, mv, w, d = _case(rng, 2, 3, 3, 256, 50_000, 0, 300, scales=False)
+    d[0, 0, 40_000] = np.float32(1.0e6)
+    d[1, 1] *= np.float32(1.0e-7)
+    d[1, 1, 100] = np.float32(1.0)          # 10^7 deviations of that channel
+    got = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
+    _check(got, want, w, "split16 extreme dynamic range")
+
+
+def test_split16_resident_engine_reuses_the_prepared_day(oracle_lib, split16):
+    """MatchedFilterGPU: the split of the day is part of the prepared state (several template batches, then the
+    option off again -> the day is prepared again and the exact path answers bit for bit)."""
+    import torch
+    from seismic_bpmf_amd.matched_filter import MatchedFilterGPU
+    rng = np.random.default_rng(21)
+    tp, mv, w, d = _case(rng, 6, 4, 3, 200, 80_000, -30, 1200)
+    eng = MatchedFilterGPU()
+    eng.set_data(d)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
+    a = eng.run(tp[:4], mv[:4], w[:4]).cpu().numpy()
+    b = eng.run(tp[4:], mv[4:], w[4:]).cpu().numpy()
+    _check(np.concatenate([a, b]), want, w, "split16 resident engine, two batches")
+    split16.reset("mf.split16")
+    c = eng.run(tp, mv, w).cpu().numpy()
+    assert np.array_equal(c, want)
+    torch.cuda.synchronize()
+
+
+def test_split16_long_templates_fall_back_to_the_exact_kernels(oracle_lib, split16):
+    """L > 378 does not fit the split kernel's band: the exact-fp32 kernels answer, bit for bit."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(31)
+    tp, mv, w, d = _case(rng, 2, 3, 3, 400, 30_000, 0, 100, scales=False)
+    got = matched_filter(tp, mv, w, d, 1, check_zeros=False)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
+    assert np.array_equal(got, want)
+
+
+def test_split16_configs0_in_full(oracle_lib, split16):
+    """BASELINE configs[0] (4 templates x 8 stations x 3 components, L = 128, one hour at 50 Hz) in full: every
+    CC sum within the tolerance of the oracle, all planted events at their exact index."""
+    from seismic_bpmf_amd import matched_filter
+    from seismic_bpmf_amd import synthetic as syn
+    mf = syn.make_mf_inputs(T=4, S=8, C=3, L=128, N=180_000, max_moveout=1500, n_events=5)
+    got = matched_filter(mf["templates"], mf["moveouts"], mf["weights"], mf["data"], 1, check_zeros=False)
+    want = oracle_lib.matched_filter(mf["templates"], mf["moveouts"], mf["weights"], mf["data"], 1)
+    _check(got, want, mf["weights"], "split16 configs[0]")
+    for t, i0 in mf["planted"]:
+        lo, hi = max(0, i0 - 64), i0 + 65
+        assert int(got[t, lo:hi].argmax()) == int(want[t, lo:hi].argmax())
+    assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in want]
