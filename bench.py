@@ -456,6 +456,52 @@ def detection_stage(cc, planted, mv, w, local_rank, dist, device, t_offset=0):
     return out
 
 
+# --------------------------------------------------------------------- the JSON line ---
+# keys the driver's contract names (+ the two objects of the hot-path tier); tests/test_bench_cli.py holds every
+# N to them
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def merge_rank_stats(ranks_info, per_rank):
+    """Per-rank {step time, kernel time, roofline fraction} (all_gather_object of every rank's own numbers) into
+    ranks_info["ranks"][i], matched by rank; also the spread of the kernel times (slowest / fastest)."""
+    by_rank = {int(r["rank"]): r for r in per_rank if r}
+    for entry in ranks_info.get("ranks", []):
+        entry.update({k: v for k, v in by_rank.get(int(entry["rank"]), {}).items() if k != "rank"})
+    for key in ("mf_kernel_ms", "bp_kernel_ms"):
+        vals = [r[key] for r in by_rank.values() if isinstance(r.get(key), (int, float)) and r[key] == r[key]]
+        if vals:
+            ranks_info[key + "_spread"] = {"min": min(vals), "max": max(vals), "slowest_over_fastest": round(max(vals) / min(vals), 4)}
+    return ranks_info
+
+
+def assemble_line(*, args, world, n_gpus, mf_value, mf_dt, dims, peak, roofline, cpu, e2e, mf_shapes, bp_obj, detect,
+                  shares, compat, split16, ranks_info):
+    """The one JSON line of a run, from what the ranks measured (pure Python: the CPU suite builds the N = 8
+    line from stubbed numbers and holds it to the keys of the N = 1 line)."""
+    T, S, C, L, N = dims
+    return {
+        "metric": "million network-CC-samples/s (matched filter)",
+        "value": round(mf_value, 2), "unit": "M CC-samples/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(mf_dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE {MF_LABEL.get(args.mf_config, args.mf_config)}: {T} templates x {S} stations x {C} comp, "
+                               f"L={L}, N={N} (1 day @ 100 Hz), step 1, per GPU",
+                   "same_per_gpu_workload_at_every_n": args.mf_config == "cfg2",
+                   "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
+                   "parallelism": (f"templates sharded x{world}: every rank holds {T} templates of a {world * T}-template "
+                                   "job, data replicated, no data-path collective; all-gather of merged peak records"
+                                   if world > 1 else "single GPU"),
+                   "row0_peak_cc": round(peak, 4)},
+        "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "mf_shapes": mf_shapes, "bp": bp_obj,
+        "detection": detect, "shares": shares, "compat": compat, "mf_split16": split16,
+        "ranks": ranks_info,
+    }
+
+
 # ------------------------------------------------------------------------------- main ---
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.
@@ -549,6 +595,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    own_dt = []
+
     def timed(step_fn, steps, warmup):
         for _ in range(warmup):
             step_fn()
@@ -560,6 +608,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         _lib.profile_enable(False)
+        own_dt.append(dt)                  # this rank's own clock (the line carries every rank's, `ranks`)
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -582,6 +631,7 @@ def main():
         mf.run(tmpl, mv, w, 1, out=cc)
 
     mf_dt = timed(mf_step, args.steps, args.warmup)
+    mf_own_dt = own_dt[-1]
     mf_kernel_ms = _lib.profile_times_ms(_lib.KERNEL_MF_MAIN)
     mf_value = world * T * n_corr * args.steps / mf_dt / 1e6
     flop_per_launch = 2.0 * L * S * C * T * n_corr          # direct-form, all channels weighted
@@ -607,6 +657,8 @@ def main():
                               "L / (L + 16) = 0.941 of the issued MFMA flops are direct-form flops: 0.941 x 0.96 x 0.95 = 0.86"),
                 "hbm_frac_informational": round(
                     4.0 * (S * C * N + T * S * C * (L + 2) + T * n_corr) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    rank_stats = {"rank": rank, "mf_ms_per_step": round(mf_own_dt / args.steps * 1e3, 3), "mf_kernel_ms": round(k_ms, 3),
+                  "mf_frac": round(achieved / FP32_PEAK_TFLOPS, 4)}
     peak = float(cc[0].max().item())
     detect = detection_stage(cc, planted, mv, w, local_rank, dist, device, t_offset=rank * T)
     # untimed extra: the same step under option mf.compat_sqrt_norm (cc = num / sqrtf(E_t * E_d) in the
@@ -628,6 +680,55 @@ def main():
                                           "kernel_ms_default": round(k_ms, 2),
                                           "slowdown": round(kms / k_ms, 4),
                                           "frac_of_fp32_peak": round(flop_per_launch / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+    # untimed extra (round 6): the same step under option mf.split16 -- numerators from fp16 hi/lo splits of data and
+    # templates, three v_mfma_f32_32x32x16_f16 products, fp32 accumulation (csrc/mf_split.h).  Never `value`: the
+    # headline stays the exact-fp32 kernel, bit-identical to the oracle.  Reported: the step and kernel time, the
+    # direct-form rate, and what the option costs in accuracy MEASURED on this very matrix -- max |cc - exact| / sum|w|
+    # over all T x n_corr CC sums (bar 2e-5: SURVEY App. C MF-5) and whether every planted event is still detected
+    # at exactly its index by the product's detection stage.
+    split16 = None
+    if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
+        try:
+            cc2 = torch.empty_like(cc)
+            with _lib.options(**{"mf.split16": 1}):
+                def split_step():
+                    mf._prepared_for = None
+                    mf.run(tmpl, mv, w, 1, out=cc2)
+                split_step()
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    split_step()
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / 3
+                _lib.profile_enable(False)
+                kms = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_MF_MAIN)))
+            mf._prepared_for = None
+            sw = float(w.abs().reshape(T, -1).sum(dim=1).max().item())
+            worst = 0.0
+            for t0_ in range(0, T, 25):       # (row blocks: no third 17 GB array)
+                worst = max(worst, float((cc2[t0_:t0_ + 25] - cc[t0_:t0_ + 25]).abs().max().item()))
+            same_zero = bool(((cc2 == 0) == (cc == 0)).all().item())
+            det2 = detection_stage(cc2, planted, mv, w, local_rank, None, device)
+            split16 = {"option": "mf.split16 = 1 (off by default)", "dtype": "f16x3->f32",
+                       "ms_per_step": round(wall * 1e3, 2), "kernel_ms": round(kms, 2), "kernel_ms_exact_fp32": round(k_ms, 2),
+                       "speedup_kernel": round(k_ms / kms, 3),
+                       "value": round(T * n_corr / wall / 1e6, 1), "unit": "M network-CC-samples/s",
+                       "direct_form_tflops": round(flop_per_launch / (kms * 1e-3) / 1e12, 1),
+                       "x_fp32_mfma_peak": round(flop_per_launch / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 3),
+                       "f16_mfma_issue_frac_of_2500_tflops": round(
+                           3.0 * 2.0 * (16 * ((L + 38 + 15) // 16)) * S * C * T * n_corr / (kms * 1e-3) / 1e12 / 2500.0, 4),
+                       "max_abs_diff_vs_exact_over_sum_w": worst / sw, "tolerance": 2e-5,
+                       "exact_zeros_identical": same_zero,
+                       "planted": det2["planted"], "planted_found_at_exact_index": det2["planted_found_at_exact_index"],
+                       "detections": det2["detections"], "detections_exact_fp32": detect["detections"],
+                       "note": ("kernel_ms includes the band images of the template batch; the per-day split of the data is in "
+                                "ms_per_step (data preparation is part of a step).  The path is power-bound like the fp32 kernel: "
+                                "tools/ubench/mfma_split16.hip, profiles/r06_mf_split16.txt")}
+            del cc2
+        except Exception as e:                      # (an extra must not cost the line)
+            split16 = {"failed": str(e)}
     del cc, mf
     torch.cuda.empty_cache()
     # End to end through the host-pointer entry point (what the reference's call site sees:
@@ -724,6 +825,7 @@ def main():
                 bf.unpack_max(packed)
 
         bp_dt = timed(bp_step, args.steps, args.warmup)
+        bp_own_dt = own_dt[-1]
         bp_ms = _lib.profile_times_ms(_lib.KERNEL_BP_BEAM)
         s_act = float((geo["weights_sources"] != 0).sum(axis=1).mean())
         bk = float(np.mean(bp_ms)) if bp_ms else float("nan")
@@ -764,6 +866,8 @@ def main():
                                "plan": pinfo, "avg_launch_ms": round(bk, 3),
                                "algorithmic": "4*S_active*P gathered bytes per grid-point x sample",
                                "fp32_frac": round(2.0 * s_act * bcfg["P"] * K_all * Nb / (bk * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+        rank_stats.update({"bp_ms_per_step": round(bp_own_dt / args.steps * 1e3, 3), "bp_kernel_ms": round(bk, 3),
+                           "bp_frac": round(gather_tbs / lds_peak, 4)})
         if rank == 0:
             bp_obj["detection"] = bp_detection_stage(beam, arg, geo, bcfg)
         if rank == 0 and world == 1:
@@ -985,6 +1089,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.skip_cpu:
         cpu = cpu_baseline(cfg, args.cpu_seconds)
+    # every rank's own step time, kernel time and roofline fraction into `ranks` (a straggler GPU -- the boxes of
+    # one pool differ by +-5 % -- is then visible in a weak-scaling ratio)
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_stats)
+        merge_rank_stats(ranks_info, per_rank)
 
     # roofline.traffic measured in this run (separate PMC passes in child processes, after everything
     # else, with this process's device memory released); headline workloads only
@@ -1013,27 +1123,26 @@ def main():
 
     line = None
     if rank == 0:
-        line = {
-            "metric": "million network-CC-samples/s (matched filter)",
-            "value": round(mf_value, 2), "unit": "M CC-samples/s",
-            "n_gpus": (ranks_info["rccl_ranks"] if ranks_info else 1),
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(mf_dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE {MF_LABEL.get(args.mf_config, args.mf_config)}: {T} templates x {S} stations x {C} comp, "
-                                   f"L={L}, N={N} (1 day @ 100 Hz), step 1, per GPU",
-                       "same_per_gpu_workload_at_every_n": args.mf_config == "cfg2",
-                       "channel_cc_samples_per_s": round(mf_value * 1e6 * S * C, 0),
-                       "parallelism": (f"templates sharded x{world}: every rank holds {T} templates of a {world * T}-template "
-                                       "job, data replicated, no data-path collective; all-gather of merged peak records"
-                                       if world > 1 else "single GPU"),
-                       "row0_peak_cc": round(peak, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "mf_shapes": mf_shapes, "bp": bp_obj,
-            "detection": detect, "shares": shares, "compat": compat,
-            "ranks": ranks_info,
-        }
+        line = assemble_line(args=args, world=world, n_gpus=(ranks_info["rccl_ranks"] if ranks_info else 1), mf_value=mf_value,
+                             mf_dt=mf_dt, dims=(T, S, C, L, N), peak=peak, roofline=roofline, cpu=cpu, e2e=e2e,
+                             mf_shapes=mf_shapes, bp_obj=bp_obj, detect=detect, shares=shares, compat=compat,
+                             split16=split16, ranks_info=ranks_info)
     if dist is not None:
         dist.destroy_process_group()
+    # N > 1: the CPU baseline AFTER the process group is gone -- the other ranks have exited (a rank waiting in a
+    # collective spins on a host core, and the cgroup grants 16), rank 0 times the oracle alone, exactly as at N = 1
+    if line is not None and world > 1 and not args.skip_cpu:
+        try:
+            del data, tmpl, mv, w
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+        if isinstance(line["cpu_baseline"], dict):
+            line["cpu_baseline"]["measured_at_n"] = world
+            line["cpu_baseline"]["when"] = "after the timed regions, the process group destroyed: the other ranks' processes have exited"
+        if line.get("bp") is not None and not args.skip_bp:
+            line["bp"]["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
     if line is not None:
         def _clean(o):  # NaN is not JSON
             if isinstance(o, float) and not math.isfinite(o):

@@ -32,7 +32,7 @@ enum Option {
     OPT_BP_SMETA, OPT_BP_VERBOSE, OPT_BP_FAST_TILE, OPT_BP_HALVES, OPT_BP_DIRECT, OPT_MF_WAVE_KERNEL, OPT_MF_MAX_MFMA_STEP, OPT_MF_HOST_BATCH_KB,
     OPT_MF_HOST_PIECE_KB, OPT_MF_VERBOSE, OPT_MF_TILES_PER_WAVE, OPT_MF_BOUNDARY_PRIO, OPT_MF_FUSED_PROLOGUE, OPT_DEBUG_POISON_OUTPUT,
     OPT_DEBUG_VIRTUAL_DEVICES, OPT_MULTI_PEER_FANOUT, OPT_MF_HOST_PIECE_LAGS, OPT_BP_HOST_PIECE_SAMPLES,
-    OPT_HOST_CACHE_LIMIT_MB, OPT_BP_SLOT_PRIO, OPT_MF_CHANNEL_SPLIT, OPT_STATS_BUCKETED_MEDIAN, OPT_STATS_ROW_GRID_MIN_N, OPT_STATS_KURT_FULL_CHUNKS, OPT_MF_SPLIT16,
+    OPT_HOST_CACHE_LIMIT_MB, OPT_BP_SLOT_PRIO, OPT_MF_CHANNEL_SPLIT, OPT_STATS_BUCKETED_MEDIAN, OPT_STATS_ROW_GRID_MIN_N, OPT_STATS_KURT_FULL_CHUNKS, OPT_MF_SPLIT16, OPT_DEBUG_FAIL_PEER_COPY,
     // upstream-compatibility switches: the ONLY options that change results (off by default)
     OPT_MF_COMPAT_EXCLUSIVE_LAST_LAG, OPT_MF_COMPAT_SQRT_NORM, OPT_BP_COMPAT_FIRST_COMPUTED,
     OPT_MF_COMPAT_RANGE_ALL_CHANNELS, OPT_MF_COMPAT_SEQUENTIAL_CSUM, OPT_BP_COMPAT_STRICT_UPPER_ONLY,

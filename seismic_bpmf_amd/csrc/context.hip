@@ -260,6 +260,42 @@ void ensure_peer_access(int dst_physical, int src_physical)
 }
 }  // namespace
 
+namespace {
+// Does a device-to-device copy src -> dst work at all?  Probed once per ordered pair of PHYSICAL devices with a
+// 4 KB copy that is waited for: the hand-over between two distinct GPUs (hipDeviceEnablePeerAccess +
+// hipMemcpyPeerAsync over xGMI) had never executed when this was written -- no multi-GPU box was available in
+// rounds 1-6 -- and a platform that refuses it (IOMMU settings, an isolated partition, a container without the
+// other device's render node) must cost one warning, not the first 8-GPU measurement: a pair that fails the probe
+// uploads from the host on every device, like option multi.peer_fanout = 0.  Option debug.fail_peer_copy (tests)
+// makes every probe fail, same-device pairs included.
+std::vector<std::pair<std::pair<int, int>, bool>> g_peer_probed;     // under g_peer_mutex
+bool peer_copy_works(int dst_physical, int src_physical, void* d_dst, const void* d_src, size_t bytes, hipStream_t stream)
+{
+    const bool forced_failure = option(OPT_DEBUG_FAIL_PEER_COPY) != 0;
+    if (dst_physical == src_physical && !forced_failure) return true;
+    {
+        std::lock_guard<std::mutex> g(g_peer_mutex);
+        for (auto& p : g_peer_probed)
+            if (p.first.first == dst_physical && p.first.second == src_physical && !forced_failure) return p.second;
+    }
+    hipError_t e = forced_failure ? hipErrorPeerAccessUnsupported
+                                  : hipMemcpyPeerAsync(d_dst, dst_physical, d_src, src_physical, std::min<size_t>(bytes, 4096), stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    const bool ok = e == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        // (status stays 0: the text is a note for whoever asks bpmf_last_error() why the call was slower)
+        set_error("note: device-to-device copy of the day from GPU %d to GPU %d failed (%s); every device uploads from the "
+                  "host instead (as under multi.peer_fanout = 0)", src_physical, dst_physical, hipGetErrorString(e));
+    }
+    if (!forced_failure) {
+        std::lock_guard<std::mutex> g(g_peer_mutex);
+        g_peer_probed.push_back({{dst_physical, src_physical}, ok});
+    }
+    return ok;
+}
+}  // namespace
+
 bool fanout_peer_copy(FanoutScope& scope, DeviceContext* ctx, void* d_dst, size_t bytes, hipStream_t stream,
                       hipError_t* err, const char** what)
 {
@@ -270,10 +306,19 @@ bool fanout_peer_copy(FanoutScope& scope, DeviceContext* ctx, void* d_dst, size_
     hipEvent_t ready = nullptr;
     if (!scope.f->wait_published(&d_src, &src_physical, &ready)) return false;
     ensure_peer_access(ctx->physical, src_physical);
+    if (!peer_copy_works(ctx->physical, src_physical, d_dst, d_src, bytes, stream)) return false;   // upload from the host
     *what = "waiting for the first device's upload";
     if ((*err = hipStreamWaitEvent(stream, ready, 0)) != hipSuccess) return true;
     *what = "device-to-device copy of the data";
     *err = hipMemcpyPeerAsync(d_dst, ctx->physical, d_src, src_physical, bytes, stream);
+    if (*err != hipSuccess && ctx->physical != src_physical) {
+        // the probe passed and the real copy is refused at enqueue time: same fallback, same note
+        (void)hipGetLastError();
+        set_error("note: device-to-device copy of the day from GPU %d to GPU %d was refused (%s); this device uploads from "
+                  "the host instead", src_physical, ctx->physical, hipGetErrorString(*err));
+        *err = hipSuccess;
+        return false;
+    }
     return true;
 }
 
