@@ -747,12 +747,14 @@ def main():
             h_cc = sb.matched_filter(h_t, h_mv, h_w, h_new, 1, arch="gpu", check_zeros=False,
                                      device=[local_rank])
             e2e_ms.append((time.perf_counter() - t0) * 1e3)
+            mf_stats = _lib.host_call_stats()
             del h_new
         e2e = {"mf_ms": round(min(e2e_ms), 1), "mf_calls_ms": [round(x, 1) for x in e2e_ms],
                "mf_value": round(T * n_corr / (min(e2e_ms) * 1e-3) / 1e6, 1), "unit": "M CC-samples/s",
                "moves": f"H2D {h_d.nbytes / 1e9:.2f} GB data + templates, D2H {h_cc.nbytes / 1e9:.2f} GB cc_sums "
                         "(pageable host memory, a fresh copy of the day per call; pinned staging both ways inside bpmf_mf_run, "
                         "the day arriving in pieces while the first two template batches run)",
+               "breakdown_of_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in mf_stats.items()},
                "row0_peak_cc": round(float(h_cc[0].max()), 4)}
         del h_cc, h_t, h_mv, h_w, h_d
 
@@ -889,18 +891,34 @@ def main():
         bf.close()
         if world == 1 and dist is None and not args.skip_e2e:
             h_f, h_wp = feat.cpu().numpy(), wp.cpu().numpy()
-            ms = []
-            for _ in range(2):           # the second call finds its plan in the library's cache
+            ms, stats = [], []
+            for _ in range(4):           # the first call builds the plan; the later ones find it in the library's cache
                 h_new = h_f.copy()       # a new day is a NEW array (host memory the runtime has not page-locked before)
                 t0 = time.perf_counter()
                 hb, ha = sb.beamform(h_new, geo["moveouts"], h_wp, geo["weights_sources"], device="gpu",
                                      reduce="max", out_of_bounds="strict", device_id=[local_rank])
                 ms.append((time.perf_counter() - t0) * 1e3)
+                stats.append(_lib.host_call_stats())
                 del h_new
-            bp_obj["end_to_end"] = {"ms": round(ms[1], 1), "first_call_ms": round(ms[0], 1),
-                                    "value": K_all * Nb / (ms[1] * 1e-3),
+            later = sorted(ms[1:])
+            med = later[len(later) // 2]
+            rep = 1 + ms[1:].index(med)
+            bp_obj["end_to_end"] = {"ms": round(med, 1), "first_call_ms": round(ms[0], 1), "calls_ms": [round(x, 1) for x in ms],
+                                    "ms_is": "the median of the calls after the first (BPMF calls once per day in a long-running process)",
+                                    "resident_ms_per_step": round(bp_dt / args.steps * 1e3, 1),
+                                    "value": K_all * Nb / (med * 1e-3),
+                                    # where the reported call's time went, by the library's own account (bpmf_host_call_stats)
+                                    "breakdown_of_reported_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats[rep].items()},
+                                    "pinned_wait_ms_by_call": [round(st.get("pinned_wait_ms", 0.0), 1) for st in stats],
+                                    "breakdown_note": ("first_kernel_start_ms: entry -> first kernel enqueued; host_copy_ms: the copy pool filling the "
+                                                       "pinned pieces (overlaps earlier pieces' kernels); pinned_wait_ms: blocked until a piece's previous "
+                                                       "H2D had completed -- ~8 ms when the copies flow, 35-45 ms in the occasional call whose FIRST piece "
+                                                       "stalls on the device side (profiles/r06_bp_e2e.txt: seen in the second call of some processes and "
+                                                       "not of others on the same box, never under rocprofv3); device_wait_ms: last launch enqueued -> results "
+                                                       "in the caller's arrays"),
+                                    "host": {"loadavg_1min": round(os.getloadavg()[0], 1), "fill_threads": stats[rep].get("fill_threads")},
                                     "moves": f"H2D {h_f.nbytes / 1e9:.2f} GB features, D2H {(hb.nbytes + ha.nbytes) / 1e6:.0f} MB "
-                                             "maxbeam + argmax; first call also builds the plan",
+                                             "maxbeam + argmax, both through the pinned pieces; first call also builds the plan",
                                     "equals_resident_result": bool(np.array_equal(hb, beam.cpu().numpy()) and
                                                                    np.array_equal(ha, arg.cpu().numpy()))}
             del h_f, hb, ha

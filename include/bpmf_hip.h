@@ -69,6 +69,17 @@ int bpmf_profile_get_device(int which_kernel, int launch_index);
  * working set above the limit back at the end of the call that needed it.  The *_dev entry points hold nothing. */
 int bpmf_release_device_memory(int device);
 int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_bytes);
+/* Where the time of the calling thread's LAST host-pointer call went (bpmf_bp_run / bpmf_mf_run, or the first
+ * device's block of a *_run_multi call made from this thread), milliseconds on the host clock:
+ *   out[0] the whole call; out[1] from entry to the first kernel being enqueued (plan lookup, working set, the
+ *   first piece of the day through the pinned buffers); out[2] host threads copying the day into the pinned
+ *   pieces (summed over the pieces; overlaps the kernels of earlier pieces); out[3] waiting for the device after
+ *   the last launch was enqueued (kernels still running + the results' way back); out[4] pieces the day arrived
+ *   in; out[5] host threads that filled them; out[6] waiting for a pinned piece to be free again (its previous
+ *   copy still in flight); out[7] inside the runtime's asynchronous-copy calls of the pieces.  Returns the number of values written (<= n).  The reference has no
+ *   counterpart (its back-ends' calls are opaque, BPMF/template_search.py:549-558); bench.py reports these beside
+ *   the end-to-end times. */
+int bpmf_host_call_stats(double *out, int n);
 
 /* Execution options.  The library reads NOTHING from the environment.  An option selects among
  * code paths and sizes that produce identical results (kernel family, LDS budget, batch sizes of

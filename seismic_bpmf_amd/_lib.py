@@ -37,6 +37,7 @@ SIGNATURES = {
     "bpmf_profile_get_device": (C.c_int, [C.c_int, C.c_int]),
     "bpmf_release_device_memory": (C.c_int, [C.c_int]),
     "bpmf_device_memory_held": (C.c_int, [C.c_int, C.POINTER(_sz), C.POINTER(_sz)]),
+    "bpmf_host_call_stats": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "bpmf_mf_workspace_bytes": (_sz, [_sz, _sz, _sz, _sz, _sz]),
     "bpmf_mf_prepare_data_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _vp, _sz, _vp]),
     "bpmf_mf_run_dev": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, C.c_int,
@@ -124,6 +125,25 @@ def check(rc, what):
     if rc != 0:
         msg = lib().bpmf_last_error().decode("utf-8", "replace")
         raise BpmfHipError(f"{what} failed (status {rc}): {msg}")
+
+
+def last_error():
+    """bpmf_last_error() of the calling thread: the text of the last failure -- or, behind a call that returned 0, a
+    'note: ...' (e.g. the multi-device hand-over of the day fell back to host uploads)."""
+    return lib().bpmf_last_error().decode("utf-8", "replace")
+
+
+def host_call_stats():
+    """Where the time of this thread's last host-pointer call went (bpmf_host_call_stats), milliseconds."""
+    buf = (C.c_double * 8)()
+    k = lib().bpmf_host_call_stats(buf, 8)
+    names = ("total_ms", "first_kernel_start_ms", "host_copy_ms", "device_wait_ms", "pieces", "fill_threads",
+             "pinned_wait_ms", "copy_enqueue_ms")
+    out = {n: float(buf[i]) for i, n in enumerate(names[:k])}
+    for n in ("pieces", "fill_threads"):
+        if n in out:
+            out[n] = int(out[n])
+    return out
 
 
 def device_count():

@@ -2577,6 +2577,8 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     // Every call binds its thread to `device` first: the plan cache below may skip
     // bpmf_bp_plan_create, and a fresh host thread starts on device 0.
     BPMF_BIND_DEVICE(device);
+    t_call_stats = HostCallStats();
+    const double t_call0 = host_now_ms();
     // One host-pointer call per device at a time, on the device's own streams and working set
     // (context.h): nothing is created or destroyed per call, nothing runs on the null stream.
     DeviceContext* ctx = device_context(device);
@@ -2702,6 +2704,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
         DeviceContext* ctx; FanoutScope* fan; const float* host; char* d_feat; const float* d_wp; float* U;
         size_t N, C; int S, P; long long have = 0; int n_piece = 0; hipError_t err = hipSuccess; const char* what = "";
         bool published = false;
+        double t_call0 = 0.0;
         int need(long long samp_end, hipStream_t stream) override
         {
             samp_end = std::min<long long>((samp_end + 1023) / 1024 * 1024, (long long)N);
@@ -2723,6 +2726,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
                 return -2;
             }
             const int rc = launch_prestack((const float*)d_feat, d_wp, N, C, S, P, U, have, samp_end, stream);
+            if (have == 0) t_call_stats.first_kernel_ms = host_now_ms() - t_call0;      // the first kernels follow
             have = samp_end;
             return rc;
         }
@@ -2739,7 +2743,8 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     if (!rc) {
         host_feed.ctx = ctx; host_feed.fan = &fan; host_feed.host = features; host_feed.d_feat = base + o_f;
         host_feed.d_wp = (const float*)(base + o_wp); host_feed.U = (float*)(base + o_ws);
-        host_feed.N = N; host_feed.C = C; host_feed.S = (int)S; host_feed.P = (int)P;
+        host_feed.N = N; host_feed.C = C; host_feed.S = (int)S; host_feed.P = (int)P; host_feed.t_call0 = t_call0;
+        if (from_peer) t_call_stats.first_kernel_ms = host_now_ms() - t_call0;
         struct FeedScope {
             explicit FeedScope(BpFeed* f) { t_bp_feed = f; }
             ~FeedScope() { t_bp_feed = nullptr; }
@@ -2748,13 +2753,18 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
                              out_of_bounds, reduce, base + o_ws, b_ws, stream,
                              (float*)(base + o_beam), (int32_t*)(base + o_arg));
     }
-    if (!rc && (e = hipMemcpyAsync(beam_out, base + o_beam, b_beam, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H beam");
+    // The results' way back, through the pinned pieces (staged_download: the runtime's pageable path page-locks a
+    // destination it has not seen before, and a result array is a new allocation on every call)
+    const double t_enqueued = host_now_ms();
+    if (!rc && (e = staged_download(ctx, beam_out, base + o_beam, b_beam, stream)) != hipSuccess) fail(e, "D2H beam");
     if (!rc && reduce == BPMF_BP_REDUCE_MAX && arg_out &&
-        (e = hipMemcpyAsync(arg_out, base + o_arg, b_arg, hipMemcpyDeviceToHost, stream)) != hipSuccess) fail(e, "D2H argmax");
+        (e = staged_download(ctx, arg_out, base + o_arg, b_arg, stream)) != hipSuccess) fail(e, "D2H argmax");
     // (always drained, also after a failure: the working set and the plan go back to their caches)
     hipError_t es = hipStreamSynchronize(stream);
     (void)hipStreamSynchronize(ctx->s_copy);
     if (pl->side_stream) (void)hipStreamSynchronize(pl->side_stream);
+    t_call_stats.device_wait_ms = host_now_ms() - t_enqueued;
+    t_call_stats.total_ms = host_now_ms() - t_call0;
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
     fan.finish();         // a source's peers are through with its copy of the day before the working set may go

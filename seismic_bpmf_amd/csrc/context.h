@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -64,6 +65,20 @@ struct DeviceContext {
     // and then runs on torch-allocated tensors would otherwise strand it outside torch's allocator).
     void trim_after_call();
 };
+
+// bpmf_host_call_stats: where the time of the calling thread's last host-pointer call went (include/bpmf_hip.h)
+struct HostCallStats {
+    double total_ms = 0, first_kernel_ms = 0, host_copy_ms = 0, device_wait_ms = 0, pinned_wait_ms = 0, enqueue_ms = 0;
+    int pieces = 0, fill_threads = 0;
+};
+extern thread_local HostCallStats t_call_stats;
+inline double host_now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// host threads that copy a day into the pinned pieces: the CPUs this process may actually use (affinity mask and
+// cgroup quota), not hardware_concurrency() -- a GPU box shows 256 logical CPUs and grants 16
+unsigned usable_cpus();
 
 // The day of data of one *_run_multi call on several devices (option multi.peer_fanout): the FIRST device
 // of the list uploads it from the host once and publishes where it lies; every other device copies it
@@ -186,6 +201,10 @@ hipError_t fanout_publish(FanoutScope& scope, DeviceContext* ctx, const void* d_
 
 // memcpy on a few host threads (large blocks) -- dst / src pageable or pinned host memory
 void parallel_copy(char* dst, const char* src, size_t bytes);
+// every host thread of the copy pool has finished what it was doing (context.hip: CopyPool)
+void copy_pool_quiesce();
+// device memory -> the caller's pageable array through the pinned pieces; blocks until `host` holds the bytes
+hipError_t staged_download(DeviceContext* ctx, void* host, const void* d_src, size_t bytes, hipStream_t stream);
 
 // rows x [c0, c1) of a (rows, N) float32 array in PAGEABLE host memory -> the same rows and samples of the
 // device array `d_dst`, through the context's two pinned pieces: host threads fill one piece (row segments

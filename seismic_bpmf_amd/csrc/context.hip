@@ -3,6 +3,11 @@
 #include "../../include/bpmf_hip.h"
 
 #include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <sched.h>
 #include <cstring>
 #include <system_error>
 #include <thread>
@@ -67,6 +72,7 @@ int DeviceContext::reserve_pinned(size_t bytes)
     bytes = std::max<size_t>(bytes, 4096);
     if (pinned[0] && pinned[1] && bytes <= pinned_cap) return 0;
     drain(this);
+    copy_pool_quiesce();          // no host thread is still writing into a piece
     upload_inflight[0] = upload_inflight[1] = false;
     for (int i = 0; i < 2; ++i) {
         if (pinned[i]) (void)hipHostFree(pinned[i]);
@@ -87,27 +93,228 @@ int DeviceContext::reserve_pinned(size_t bytes)
     return 0;
 }
 
+thread_local HostCallStats t_call_stats;
+
+// CPUs this process may run on: the affinity mask cut by the cgroup's CPU quota (v2 cpu.max, v1 cfs quota).
+unsigned usable_cpus()
+{
+    static const unsigned cached = [] {
+        unsigned n = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int c = CPU_COUNT(&set);
+            if (c > 0) n = (unsigned)c;
+        }
+        double quota = 0.0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[64] = {0};
+            double period = 0.0;
+            if (fscanf(f, "%63s %lf", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / period;
+            fclose(f);
+        } else {
+            double q = -1.0, per = 0.0;
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &q) != 1) q = -1.0; fclose(g); }
+            if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &per) != 1) per = 0.0; fclose(g); }
+            if (q > 0 && per > 0) quota = q / per;
+        }
+        if (quota >= 1.0 && quota < (double)n) n = (unsigned)quota;
+        return std::max(1u, n);
+    }();
+    return cached;
+}
+
+namespace {
+// The host threads that copy between pageable and pinned memory (the day of data on its way up, the CC matrix
+// on its way down): created ONCE per process, on first use, and parked on a condition variable between jobs.
+// Rounds 4-5 spawned up to 8 std::threads per 64 MB piece and sized the team by hardware_concurrency() / 2
+// (128 on a box that grants 16 CPUs): on a loaded host -- the driver's round-5 bench ran at load average 39 --
+// thread creation queued behind the other processes and the first pieces of a day were exposed again (cfg3
+// through bpmf_bp_run: 183 ms against 150 resident).  The pool is leaked on purpose: a worker parked inside a
+// destroyed condition variable at process exit is worse than a few threads the OS reaps.
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool* p = new CopyPool();
+        return *p;
+    }
+    unsigned team() const { return n_workers + 1; }      // the workers and the calling thread
+    // fn(i) for i in [0, n): drawn by the workers and the caller; returns when every task is done.  One job at a
+    // time (callers on different devices take turns: a copy saturates the memory system anyway).
+    //
+    // `token` != nullptr marks the tasks as IDEMPOTENT copies INTO the buffer `token` (a pinned piece being filled
+    // from the caller's array): once nothing is left to draw the caller does NOT sleep until the slowest worker
+    // reports back -- on a host with more runnable threads than CPUs a worker that lost its CPU in the middle of a
+    // block is off for a scheduler period, and the caller's own wake-up costs another -- it copies the blocks that
+    // are still marked unfinished ITSELF (the same bytes to the same place) and returns.  A worker that comes back
+    // late finishes its block with the same bytes; the only thing that must never happen is that it is still
+    // writing when the buffer is filled with the NEXT piece that goes through it: a job into `token` first waits for
+    // the stragglers of the earlier jobs into the same token (two pieces ago: it has normally long finished), and
+    // quiesce() waits for all of them (before a pinned piece is freed or used for the way down).
+    void run(size_t n, const std::function<void(size_t)>& fn, const void* token = nullptr)
+    {
+        if (n == 0) return;
+        if (n == 1 || n_workers == 0) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> job_lock(job_mutex);
+        auto job = std::make_shared<Job>();
+        job->fn = fn;
+        job->n = n;
+        job->token = token;
+        job->state.reset(new std::atomic<unsigned char>[n]);
+        for (size_t i = 0; i < n; ++i) job->state[i].store(0, std::memory_order_relaxed);
+        {
+            std::unique_lock<std::mutex> g(m);
+            if (token) cv_done.wait(g, [&] { return stragglers_of(token) == 0; });
+            else cv_done.wait(g, [&] { return straggling.empty(); });
+            current = job;
+            ++generation;
+        }
+        cv.notify_all();
+        draw(*job);
+        if (token) {
+            // nothing left to draw: finish what others hold, without waiting for them
+            for (size_t i = 0; i < n; ++i)
+                if (job->state[i].load(std::memory_order_acquire) != 2) {
+                    job->fn(i);
+                    job->state[i].store(2, std::memory_order_release);
+                }
+            std::lock_guard<std::mutex> g(m);
+            current.reset();
+            if (job->inside > 0) straggling.push_back(job);     // (its workers take themselves off the list)
+        } else {
+            std::unique_lock<std::mutex> g(m);
+            cv_done.wait(g, [&] { return job->inside == 0 && job->next.load() >= n; });
+            current.reset();
+        }
+    }
+    // every straggler of every earlier job has finished
+    void quiesce()
+    {
+        std::unique_lock<std::mutex> g(m);
+        cv_done.wait(g, [&] { return straggling.empty(); });
+    }
+private:
+    struct Job {
+        std::function<void(size_t)> fn;
+        size_t n = 0;
+        const void* token = nullptr;
+        std::atomic<size_t> next{0};
+        std::unique_ptr<std::atomic<unsigned char>[]> state;      // 0 not drawn, 1 drawn, 2 done
+        int inside = 0;                                           // workers inside draw() (under m)
+    };
+    CopyPool()
+    {
+        const unsigned cpus = usable_cpus();
+        const unsigned want = std::min(11u, cpus > 2 ? cpus - 2 : (cpus > 1 ? 1u : 0u));
+        for (unsigned i = 0; i < want; ++i) {
+            try {
+                std::thread([this] { worker(); }).detach();
+                ++n_workers;
+            } catch (const std::system_error&) {
+                break;            // no thread to be had: the caller copies alone
+            }
+        }
+    }
+    size_t stragglers_of(const void* token) const
+    {
+        size_t k = 0;
+        for (auto& j : straggling) k += j->token == token;
+        return k;
+    }
+    static void draw(Job& job)
+    {
+        for (;;) {
+            const size_t i = job.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= job.n) return;
+            job.state[i].store(1, std::memory_order_relaxed);
+            job.fn(i);
+            job.state[i].store(2, std::memory_order_release);
+        }
+    }
+    void worker()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [&] { return generation != seen && current && current->next.load() < current->n; });
+                seen = generation;
+                job = current;
+                ++job->inside;
+            }
+            draw(*job);
+            {
+                std::lock_guard<std::mutex> g(m);
+                if (--job->inside == 0)
+                    for (size_t k = 0; k < straggling.size(); ++k)
+                        if (straggling[k] == job) { straggling.erase(straggling.begin() + k); break; }
+            }
+            cv_done.notify_all();
+        }
+    }
+    std::mutex job_mutex, m;
+    std::condition_variable cv, cv_done;
+    std::shared_ptr<Job> current;
+    std::vector<std::shared_ptr<Job>> straggling;
+    unsigned long long generation = 0;
+    unsigned n_workers = 0;
+};
+}  // namespace
+
+void copy_pool_quiesce() { CopyPool::get().quiesce(); }
+
 void parallel_copy(char* dst, const char* src, size_t bytes)
 {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
-    if (bytes < (8u << 20) || nth == 1) {
+    CopyPool& pool = CopyPool::get();
+    if (bytes < (8u << 20) || pool.team() == 1) {
+        pool.quiesce();
         memcpy(dst, src, bytes);
         return;
     }
-    std::vector<std::thread> th;
-    const size_t per = (bytes / nth + 4095) & ~(size_t)4095;
-    for (size_t i = 0; i < nth; ++i) {
-        const size_t o = i * per;
-        if (o >= bytes) break;
-        auto piece = [=] { memcpy(dst + o, src + o, std::min(per, bytes - o)); };
-        try {
-            th.emplace_back(piece);
-        } catch (const std::system_error&) {
-            piece();               // no thread to be had (process / cgroup limit): this piece is copied here
+    // 2 MB blocks, drawn by whoever is free (a thread that loses its CPU for a while holds up one block, not an
+    // eighth of the piece)
+    const size_t blk = (size_t)2 << 20, n = (bytes + blk - 1) / blk;
+    pool.run(n, [=](size_t i) { memcpy(dst + i * blk, src + i * blk, std::min(blk, bytes - i * blk)); });
+}
+
+// Device memory -> the caller's PAGEABLE array through the context's pinned pieces (the way down of
+// staged_upload_rows): the runtime's own pageable path page-locks a destination it has not seen before -- a result
+// array is a new allocation on every call -- and took 40 ms for the 35 MB of a cfg3 day's (max-beam, arg-max)
+// on the second call of a process (tools/probe_bp_e2e.py, profiles/r06_bp_e2e.txt) where the copy itself is
+// 0.7 ms.  Blocks until `host` holds the bytes.  Needs reserve_pinned() first.
+hipError_t staged_download(DeviceContext* ctx, void* host, const void* d_src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    const size_t cap = ctx->pinned_cap.load();
+    if (cap == 0) return hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    // (the pieces may still be read by this call's last uploads)
+    for (int i = 0; i < 2; ++i)
+        if (ctx->upload_inflight[i]) {
+            if ((e = hipEventSynchronize(ctx->ev_piece[i])) != hipSuccess) return e;
+            ctx->upload_inflight[i] = false;
         }
+    copy_pool_quiesce();
+    const size_t n_piece = (bytes + cap - 1) / cap;
+    auto enqueue = [&](size_t q) {
+        const size_t o = q * cap, len = std::min(cap, bytes - o);
+        e = hipMemcpyAsync(ctx->pinned[q & 1], (const char*)d_src + o, len, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_piece[q & 1], stream);
+    };
+    enqueue(0);
+    for (size_t q = 0; q < n_piece && e == hipSuccess; ++q) {
+        if ((e = hipEventSynchronize(ctx->ev_piece[q & 1])) != hipSuccess) break;
+        if (q + 1 < n_piece) enqueue(q + 1);
+        if (e != hipSuccess) break;
+        const size_t o = q * cap, len = std::min(cap, bytes - o);
+        parallel_copy((char*)host + o, ctx->pinned[q & 1], len);
     }
-    for (auto& t : th) t.join();
+    return e;
 }
 
 hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* host, size_t rows, size_t N, size_t c0,
@@ -119,43 +326,42 @@ hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* hos
     size_t w = cap / (rows * sizeof(float));
     if (w == 0) return hipErrorInvalidValue;
     if (w > 1024) w &= ~(size_t)1023;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nth = std::max<size_t>(1, std::min<size_t>(8, hw ? hw / 2 : 4));
+    CopyPool& pool = CopyPool::get();
+    t_call_stats.fill_threads = (int)pool.team();
     hipError_t e = hipSuccess;
     size_t q = ctx->upload_seq;
     for (size_t a = c0; a < c1 && e == hipSuccess; a += w, ++q) {
         const size_t len = std::min(w, c1 - a);
         char* pin = ctx->pinned[q & 1];
         if (ctx->upload_inflight[q & 1]) {                       // the copy that last read this piece
+            const double tw = host_now_ms();
             if ((e = hipEventSynchronize(ctx->ev_piece[q & 1])) != hipSuccess) break;
             ctx->upload_inflight[q & 1] = false;
+            const double dw = host_now_ms() - tw;
+            t_call_stats.pinned_wait_ms += dw;
+            if (option(OPT_BP_VERBOSE) != 0 && dw > 1.0)
+                fprintf(stderr, "[bpmf] staged upload: piece %d waited %.1f ms for its pinned buffer\n", t_call_stats.pieces, dw);
         }
-        // row segments -> the piece, packed; the rows are dealt to the threads
-        auto fill = [&](size_t r0, size_t r1) {
-            for (size_t r = r0; r < r1; ++r)
-                memcpy(pin + r * len * sizeof(float), host + r * N + a, len * sizeof(float));
-        };
-        if (rows * len * sizeof(float) < (8u << 20) || nth == 1 || rows == 1) {
-            if (rows == 1) parallel_copy(pin, (const char*)(host + a), len * sizeof(float));
-            else fill(0, rows);
+        const double t0 = host_now_ms();
+        // row segments -> the piece, packed: blocks of at most 1 MB of a row, drawn by whoever is free
+        const size_t row_bytes = len * sizeof(float);
+        if (rows * row_bytes < (4u << 20) || pool.team() == 1) {
+            for (size_t r = 0; r < rows; ++r) memcpy(pin + r * row_bytes, host + r * N + a, row_bytes);
         } else {
-            std::vector<std::thread> th;
-            const size_t per = (rows + nth - 1) / nth;
-            for (size_t t = 0; t < nth; ++t) {
-                const size_t r0 = t * per, r1 = std::min(rows, r0 + per);
-                if (r0 >= r1) break;
-                try {
-                    th.emplace_back(fill, r0, r1);
-                } catch (const std::system_error&) {
-                    fill(r0, r1);
-                }
-            }
-            for (auto& t : th) t.join();
+            const size_t blk = (size_t)1 << 20, per_row = (row_bytes + blk - 1) / blk;
+            pool.run(rows * per_row, [=](size_t i) {
+                const size_t r = i / per_row, o = (i % per_row) * blk;
+                memcpy(pin + r * row_bytes + o, (const char*)(host + r * N + a) + o, std::min(blk, row_bytes - o));
+            }, pin);
         }
+        const double t1 = host_now_ms();
+        t_call_stats.host_copy_ms += t1 - t0;
+        ++t_call_stats.pieces;
         e = hipMemcpy2DAsync(d_dst + a, N * sizeof(float), pin, len * sizeof(float), len * sizeof(float), rows,
                              hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_piece[q & 1], stream);
         if (e == hipSuccess) ctx->upload_inflight[q & 1] = true;
+        t_call_stats.enqueue_ms += host_now_ms() - t1;       // (the runtime's own time inside the copy call)
     }
     ctx->upload_seq = q;
     return e;
@@ -170,6 +376,7 @@ void DeviceContext::trim_after_call()
 void DeviceContext::release_memory()
 {
     drain(this);
+    copy_pool_quiesce();
     if (dev_buf) (void)hipFree(dev_buf);
     dev_buf = nullptr;
     dev_cap = 0;
@@ -372,6 +579,16 @@ extern "C" int bpmf_release_device_memory(int device)
         c->release_memory();
     }
     return 0;
+}
+
+extern "C" int bpmf_host_call_stats(double* out, int n)
+{
+    const bpmf::HostCallStats& st = bpmf::t_call_stats;
+    const double v[8] = {st.total_ms, st.first_kernel_ms, st.host_copy_ms, st.device_wait_ms, (double)st.pieces,
+                         (double)st.fill_threads, st.pinned_wait_ms, st.enqueue_ms};
+    int k = 0;
+    for (; out && k < n && k < 8; ++k) out[k] = v[k];
+    return k;
 }
 
 extern "C" int bpmf_device_memory_held(int device, size_t* device_bytes, size_t* pinned_bytes)

@@ -1493,6 +1493,8 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     }
     if (int rc = mf_check_sizes(step, L, N, T, S, C, n_corr)) return rc;
     BPMF_BIND_DEVICE(device);
+    t_call_stats = HostCallStats();
+    const double t_call0 = host_now_ms();
     const size_t n_ch = S * C;
     const size_t row_bytes = n_corr * (network_sum ? 1 : n_ch) * sizeof(float);   // per template
     // options mf.host_batch_kb / mf.host_piece_kb: sizes of a batch's output and of a pinned piece
@@ -1638,6 +1640,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
                 hi = std::min<long long>(hi, (long long)n_offsets);
                 if (hi <= done[b]) continue;
                 rc = launch_range(b, done[b], hi, done[b] > 0);
+                if (t_call_stats.first_kernel_ms == 0.0) t_call_stats.first_kernel_ms = host_now_ms() - t_call0;
                 done[b] = hi;
             }
         }
@@ -1667,6 +1670,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     const double t_start = now();
     double t_wait = 0.0, t_copy = 0.0;
     if (!rc) rc = launch(0);
+    if (t_call_stats.first_kernel_ms == 0.0) t_call_stats.first_kernel_ms = host_now_ms() - t_call0;
     for (size_t b = 0; b < n_batch && !rc; ++b) {
         if (b + 1 < n_batch) rc = launch(b + 1);   // its buffer was drained one iteration ago
         if (rc) break;
@@ -1697,6 +1701,8 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
     // (always drained, also after a failure: the working set goes back to its cache)
     (void)hipStreamSynchronize(s_run);
     (void)hipStreamSynchronize(s_copy);
+    t_call_stats.device_wait_ms = t_wait * 1e3;      // (waiting for drained pieces of the CC matrix)
+    t_call_stats.total_ms = host_now_ms() - t_call0;
     if (verbose)
         fprintf(stderr, "[bpmf] mf_run: %zu batches of at most %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);

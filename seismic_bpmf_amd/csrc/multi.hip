@@ -138,8 +138,11 @@ int run_blocks(const std::vector<int>& dev, Fn fn, bool share_data = false)
             bpmf::FanoutArm arm(fan.get(), !first ? bpmf::DataFanout::NONE
                                                   : (q == 0 ? bpmf::DataFanout::SOURCE : bpmf::DataFanout::PEER));
             try {
+                bpmf::last_error_buf()[0] = 0;
                 rc[i] = fn(i);
-                if (rc[i]) msg[i] = bpmf_last_error();
+                // (a status-0 block may leave a NOTE -- the peer copy of the day fell back to host uploads,
+                // context.hip -- which the caller's thread passes on)
+                if (rc[i] || strncmp(bpmf_last_error(), "note:", 5) == 0) msg[i] = bpmf_last_error();
             } catch (const std::exception& e) {
                 rc[i] = -3;
                 msg[i] = std::string("exception in a device block: ") + e.what();
@@ -172,6 +175,11 @@ int run_blocks(const std::vector<int>& dev, Fn fn, bool share_data = false)
         if (rc[i]) {
             set_error("%s", msg[i].c_str());
             return rc[i];
+        }
+    for (size_t i = 0; i < n_blocks; ++i)
+        if (!msg[i].empty()) {
+            set_error("%s", msg[i].c_str());        // status 0 with a note
+            break;
         }
     return 0;
 }
@@ -266,8 +274,8 @@ extern "C" int bpmf_bp_run_multi(const float* features, const int32_t* moveouts,
     if (rc) return rc;
     // Ascending source blocks and a strict >: block 0 carries the (0, source 0) starting point of
     // the sequential scan, and a later block only replaces a value it beats.
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nth = std::max<size_t>(1, std::min<size_t>(16, hw ? hw / 2 : 4));
+    // (threads by the CPUs the process may use -- affinity and cgroup quota --, not hardware_concurrency())
+    const size_t nth = std::max<size_t>(1, std::min<size_t>(16, bpmf::usable_cpus()));
     const std::vector<size_t> tb = block_bounds(N, N < (1u << 20) ? 1 : nth);
     std::vector<std::thread> th;
     auto merge = [&](size_t lo, size_t hi) {

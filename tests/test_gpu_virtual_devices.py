@@ -251,3 +251,50 @@ def test_configs4_sized_day_on_8_virtual_devices(oracle_lib, hip_opts):
     wb, wa = oracle_lib.beamform(seg, tau, wp, ws, "flexible", "max")
     assert np.array_equal(ob[i0:i0 + W], wb[:W]) and np.array_equal(oa[i0:i0 + W], wa[:W])
     _lib.release_device_memory(-1)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_a_refused_peer_copy_falls_back_to_host_uploads_with_a_note(oracle_lib, hip_opts, k):
+    """Round 6: a platform that refuses the device-to-device copy of the day -- the branch no
+    box has run between two physical GPUs yet -- must not fail the call: the peers upload from the host, the
+    result is the same, and bpmf_last_error() carries a note.  Option debug.fail_peer_copy makes the probe of
+    every pair fail."""
+    from seismic_bpmf_amd import _lib, beamform, matched_filter
+    rng = np.random.default_rng(900 + k)
+    tp, mv, w, d = _mf_case(rng)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1)
+    hip_opts("debug.virtual_devices", k)
+    hip_opts("debug.fail_peer_copy", 1)
+    got = matched_filter(tp, mv, w, d, 1, arch="gpu", device=None, check_zeros=False)
+    note = _lib.last_error()
+    assert np.array_equal(got, want)
+    assert note.startswith("note: device-to-device copy of the day") and "uploads from the host" in note, note
+    f, tau, wp, ws = _bp_case(rng)
+    wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    mb, ma = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="strict", device_id=None)
+    assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+    assert _lib.last_error().startswith("note: device-to-device copy")
+    hip_opts.reset("debug.fail_peer_copy")
+    got = matched_filter(tp, mv, w, d, 1, arch="gpu", device=None, check_zeros=False)
+    assert np.array_equal(got, want) and not _lib.last_error().startswith("note:")
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_cache_limit_with_peer_fanout_keeps_the_source_copy_until_the_peers_are_through(oracle_lib, hip_opts, k):
+    """Round-5 advisor finding: under host.cache_limit_mb the source device gave its working set -- the copy of
+    the day its peers were still reading -- back BEFORE it had waited for them.  Many small multi-device calls
+    with the limit at 1 MB: every result exact, nothing held afterwards."""
+    from seismic_bpmf_amd import _lib, beamform, matched_filter
+    rng = np.random.default_rng(950 + k)
+    tp, mv, w, d = _mf_case(rng)
+    want = oracle_lib.matched_filter(tp, mv, w, d, 1)
+    f, tau, wp, ws = _bp_case(rng)
+    wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    _lib.release_device_memory(-1)               # (contexts of earlier tests, on more logical devices, keep theirs)
+    hip_opts("debug.virtual_devices", k)
+    hip_opts("host.cache_limit_mb", 1)
+    for _ in range(8):
+        assert np.array_equal(matched_filter(tp, mv, w, d, 1, arch="gpu", device=None, check_zeros=False), want)
+        mb, ma = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="strict", device_id=None)
+        assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+    assert _lib.device_memory_held(-1)[0] == 0
