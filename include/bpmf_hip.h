@@ -327,6 +327,17 @@ int bpmf_extract_candidates_mad_dev(const float *d_series, const float *d_thr_wi
                                     size_t shift, uint32_t capacity, bpmf_stream_t stream,
                                     uint32_t *d_count, bpmf_candidate *d_records);
 
+/* The optional validation of MatchedFilter.select_cc_indexes (BPMF/similarity_search.py:253-272) on the device:
+ * for detection q, how many samples of row d_rows[q] of the (n_rows, n) matrix lie strictly below d_level[q] in
+ * [d_start[q], d_start[q] + d_len_left[q]) -> d_below[2 q] and in the d_len_right[q] samples behind -> d_below[2 q + 1]
+ * (float32 compares, like the reference's `cc1 < cc_at_mean_plus_1sig[cc_idx[i]]`; one workgroup per detection; a
+ * few thousand detections of a few hundred samples each: the CC rows stay in HBM).  The host keeps a detection when
+ * min(below_left / len_left, below_right / len_right) >= anomalous_cdf_at_mean_plus_1sig. */
+int bpmf_count_below_dev(const float *d_series, size_t n_rows, size_t n, size_t n_detections,
+                         const int32_t *d_rows, const int64_t *d_start, const int32_t *d_len_left,
+                         const int32_t *d_len_right, const float *d_level, bpmf_stream_t stream,
+                         int32_t *d_below);
+
 /* ------------------------------------------------- robust statistics (stats.hip) --- */
 /* np.median and MAD (median of |x - median|, float32 like NumPy) of every row of a (rows, n)
  * device array; skip_zeros != 0: over the samples != 0 only (`a[a != 0]`).  NaN for an empty

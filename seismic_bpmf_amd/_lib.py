@@ -73,6 +73,7 @@ SIGNATURES = {
                                             C.c_int, C.c_int, _i]),
     "bpmf_extract_candidates_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp,
                                               _vp, _vp]),
+    "bpmf_count_below_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bpmf_extract_candidates_mad_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, C.c_uint32, _vp,
                                                   _vp, _vp]),
     "bpmf_row_median_mad_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp]),

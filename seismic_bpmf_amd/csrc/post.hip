@@ -461,6 +461,56 @@ extern "C" int bpmf_extract_candidates_dev(const float* d_series, const float* d
     return 0;
 }
 
+// Validation windows of select_cc_indexes (BPMF/similarity_search.py:253-272): per detection, the samples strictly
+// below a level in two adjacent windows of one CC row.
+__global__ __launch_bounds__(256) void count_below_kernel(const float* __restrict__ x, size_t n, const int32_t* __restrict__ rows,
+                                                          const long long* __restrict__ start, const int32_t* __restrict__ len_l,
+                                                          const int32_t* __restrict__ len_r, const float* __restrict__ level,
+                                                          int32_t* __restrict__ below)
+{
+    const size_t q = blockIdx.x;
+    const float* row = x + (size_t)rows[q] * n + start[q];
+    const int nl = len_l[q], nr = len_r[q];
+    const float v = level[q];
+    int cl = 0, cr = 0;
+    for (int i = threadIdx.x; i < nl + nr; i += 256) {
+        const bool b = row[i] < v;
+        if (i < nl) cl += b;
+        else cr += b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cl += __shfl_xor(cl, o);
+        cr += __shfl_xor(cr, o);
+    }
+    __shared__ int part[8];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = cl; part[4 + (threadIdx.x >> 6)] = cr; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        below[2 * q] = part[0] + part[1] + part[2] + part[3];
+        below[2 * q + 1] = part[4] + part[5] + part[6] + part[7];
+    }
+}
+
+extern "C" int bpmf_count_below_dev(const float* d_series, size_t n_rows, size_t n, size_t n_detections,
+                                    const int32_t* d_rows, const int64_t* d_start, const int32_t* d_len_left,
+                                    const int32_t* d_len_right, const float* d_level, bpmf_stream_t stream_,
+                                    int32_t* d_below)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_detections == 0) return 0;
+    if (!d_series || !d_rows || !d_start || !d_len_left || !d_len_right || !d_level || !d_below || n_rows == 0 ||
+        n_detections > 0x7fffffffull) {
+        set_error("bpmf_count_below_dev: bad argument");
+        return -1;
+    }
+    // (the caller guarantees row < n_rows, start >= 0 and start + len_left + len_right <= n)
+    count_below_kernel<<<dim3((unsigned)n_detections), dim3(256), 0, stream>>>(
+        d_series, n, d_rows, (const long long*)d_start, d_len_left, d_len_right, d_level, d_below);
+    BPMF_LAUNCH_CHECK();
+    return 0;
+}
+
 // The same extraction against the window values of the MAD threshold (bpmf_tdt_mad_dev): sample i
 // takes window min(clamp(i, half, n - (window - half) - 1) / shift, n_win - 1)
 // (BPMF/similarity_search.py:1100-1112).

@@ -81,19 +81,87 @@ def row_excess_kurtosis(cc):
     return kurtosis_from_moments_rows(parts.cpu().numpy())
 
 
+def validation_windows(index, n, win):
+    """The two windows MatchedFilter.select_cc_indexes inspects around CC index `index` of a series of n samples
+    (BPMF/similarity_search.py:256-263): (start, len_left, len_right) with left = [start, start + len_left) and
+    right the len_right samples behind it."""
+    half = win // 2
+    i0 = np.maximum(0, np.asarray(index, dtype=np.int64) - half)
+    i1 = i0 + win
+    late = i1 >= n
+    i0 = np.where(late, n - 1 - win, i0)
+    return i0, half, win - half
+
+
+def validate_detections(cc, merged, bounds, c_index, c_thr, *, n_dev, threshold_type, cut, win):
+    """The anomalous-CDF validation of select_cc_indexes (BPMF/similarity_search.py:253-272) for the merged
+    detections {row: cc indices} of a CC matrix in HBM: returns the same dict with the failed detections removed.
+    `c_index` / `c_thr` / `bounds`: the candidate arrays of cc_detections (the threshold AT a detection is the
+    candidate record's).  Level and fractions as the reference computes them: float32 threshold / n_dev (x 1.48),
+    float32 compares, count / float(len) in float64."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    n = int(cc.shape[-1])
+    if win < 2 or win > n - 1:
+        raise ValueError(f"validation window of {win} CC samples on a series of {n}: the reference's slices need "
+                         "2 <= int(window_for_validation_Tmax / min_freq_hz) <= n_corr - 1")
+    rows, idxs, lvl = [], [], []
+    for t, idx in merged.items():
+        if len(idx) == 0:
+            continue
+        b0, b1 = bounds[t], bounds[t + 1]
+        pos = b0 + np.searchsorted(c_index[b0:b1], idx)
+        one_sigma = c_thr[pos].astype(np.float32) / np.float32(n_dev)
+        if threshold_type == "mad":
+            one_sigma = one_sigma * np.float32(1.48)
+        rows.append(np.full(len(idx), t, dtype=np.int32))
+        idxs.append(np.asarray(idx, dtype=np.int64))
+        lvl.append(one_sigma.astype(np.float32))
+    if not rows:
+        return merged
+    rows, idxs, lvl = np.concatenate(rows), np.concatenate(idxs), np.concatenate(lvl)
+    start, n_left, n_right = validation_windows(idxs, n, win)
+    dev = cc.device
+    d_rows = torch.as_tensor(rows, device=dev)
+    d_start = torch.as_tensor(start.astype(np.int64), device=dev)
+    d_nl = torch.full((len(rows),), n_left, dtype=torch.int32, device=dev)
+    d_nr = torch.full((len(rows),), n_right, dtype=torch.int32, device=dev)
+    d_lvl = torch.as_tensor(lvl, device=dev)
+    below = torch.empty((len(rows), 2), dtype=torch.int32, device=dev)
+    x = cc if cc.is_contiguous() else cc.contiguous()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().bpmf_count_below_dev(C.c_void_p(x.data_ptr()), int(x.shape[0]), n, len(rows),
+                                             C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_start.data_ptr()),
+                                             C.c_void_p(d_nl.data_ptr()), C.c_void_p(d_nr.data_ptr()),
+                                             C.c_void_p(d_lvl.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream),
+                                             C.c_void_p(below.data_ptr()))
+    _lib.check(rc, "bpmf_count_below_dev")
+    below = below.cpu().numpy().astype(np.float64)
+    frac = np.minimum(below[:, 0] / float(n_left), below[:, 1] / float(n_right))
+    keep = ~(frac < cut)
+    out = dict(merged)
+    for t in np.unique(rows):
+        m = rows == t
+        out[int(t)] = idxs[m][keep[m]]
+    return out
+
+
 def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                               threshold_window_dur, minimum_interevent_time, n_dev=8.0,
                               overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
                               remove_edges=True, data_buffer_sec=None, data_duration_sec=None,
-                              sanity_check=True, max_kurto=100.0, threshold_type="rms"):
+                              sanity_check=True, max_kurto=100.0, threshold_type="rms",
+                              anomalous_cdf_at_mean_plus_1sig=0.0, window_for_validation_Tmax=100.0, min_freq_hz=None):
     """Matched-filter search of one day: returns ({template: cc indices}, cc device tensor).
 
     `remove_edges` (the reference's default, BPMF/similarity_search.py:274-285) drops detections
     inside the `data_buffer_sec` margins the day was loaded with (`cfg.DATA_BUFFER_SEC`) and past
     `data_duration_sec + data_buffer_sec`; it needs `data_buffer_sec` (pass remove_edges=False for a
-    day loaded without margins).  The optional anomalous-CDF
-    validation of :253-272 is available through postprocess.select_cc_indexes on a downloaded
-    row; it is off in this device pipeline.  `sanity_check` (the reference's default, :633-642): a
+    day loaded without margins).  The optional anomalous-CDF validation of :253-272
+    (`anomalous_cdf_at_mean_plus_1sig` > 0 with `min_freq_hz`; off by default like the reference's class default)
+    runs on the device too, see cc_detections.  `sanity_check` (the reference's default, :633-642): a
     template whose CC series has an excess kurtosis above `max_kurto` -- most of the day missing --
     yields no detection (the reference zeroes its CCs before the peak selection); `threshold_type`:
     the RMS threshold of libc.c (default) or the MAD threshold of similarity_search.py:1079-1113; the kurtosis is
@@ -112,21 +180,31 @@ def matched_filter_detections(templates, moveouts, weights, data, *, step=1, sr,
                         max_cc_threshold=max_cc_threshold, white_noise=white_noise, device=device,
                         remove_edges=remove_edges, data_buffer_sec=data_buffer_sec,
                         data_duration_sec=data_duration_sec, sanity_check=sanity_check, max_kurto=max_kurto,
-                        threshold_type=threshold_type)
+                        threshold_type=threshold_type, anomalous_cdf_at_mean_plus_1sig=anomalous_cdf_at_mean_plus_1sig,
+                        window_for_validation_Tmax=window_for_validation_Tmax, min_freq_hz=min_freq_hz)
     return out, cc
 
 
 def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, minimum_interevent_time,
                   n_dev=8.0, overlap=0.25, max_cc_threshold=0.80, white_noise=None, device=None,
                   remove_edges=True, data_buffer_sec=None, data_duration_sec=None, sanity_check=True,
-                  max_kurto=100.0, threshold_type="rms", with_values=False, timings=None):
+                  max_kurto=100.0, threshold_type="rms", with_values=False, timings=None,
+                  anomalous_cdf_at_mean_plus_1sig=0.0, window_for_validation_Tmax=100.0, min_freq_hz=None):
     """The detection stage of matched_filter_detections on a (T, n_corr) CC matrix that already lies in
     HBM (``MatchedFilter.find_detections``, BPMF/similarity_search.py:548-666): NaN scrub, threshold and
     candidates on the device, the reference's pair-wise merge, kurtosis sanity check, edge removal.
     `moveouts` / `weights` are those of the rows of `cc`.  Returns {row: cc indices}; with
     `with_values` {row: (cc indices, cc values float32, threshold values float32)}.  `timings`: a dict
     that receives "threshold_ms" / "candidates_ms" / "merge_ms" / "candidates" (the device is synchronised
-    around the stages only when it is given)."""
+    around the stages only when it is given).
+
+    `anomalous_cdf_at_mean_plus_1sig` > 0 (the class default of the reference is 0.0 = off, similarity_search.py:40;
+    its select_cc_indexes defaults to 0.50): the validation of :253-272 between the merge and the edge removal --
+    around every merged detection, two adjacent windows of the CC row (together int(window_for_validation_Tmax /
+    min_freq_hz) samples, the reference's own unit) must each hold at least that fraction of samples below
+    threshold / n_dev (x 1.48 under the MAD threshold), or the threshold is deemed to have failed there and the
+    detection is dropped.  The counts are taken on the device (bpmf_count_below_dev: one workgroup per detection),
+    the CC rows stay in HBM; needs `min_freq_hz` (cfg.MIN_FREQ_HZ)."""
     import time
     if remove_edges and data_buffer_sec is None:
         raise ValueError("remove_edges=True needs data_buffer_sec (the reference trims cfg.DATA_BUFFER_SEC); "
@@ -180,12 +258,23 @@ def cc_detections(cc, moveouts, weights, *, step=1, sr, threshold_window_dur, mi
     hi_edge = pp.sec_to_samp(data_duration_sec + data_buffer_sec, sr) if remove_edges and data_duration_sec is not None else None
     empty = (np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.float32)) if with_values \
         else np.zeros(0, dtype=np.int64)
+    merged = {}
+    for t in range(n_t):
+        if not rejected[t]:
+            b0, b1 = bounds[t], bounds[t + 1]
+            merged[t] = merge_candidates(c_index[b0:b1], c_cc[b0:b1], wins[t])
+    if anomalous_cdf_at_mean_plus_1sig > 0.0:
+        if min_freq_hz is None:
+            raise ValueError("anomalous_cdf_at_mean_plus_1sig > 0 needs min_freq_hz (the reference's cfg.MIN_FREQ_HZ)")
+        merged = validate_detections(cc, merged, bounds, c_index, c_thr, n_dev=n_dev, threshold_type=threshold_type,
+                                     cut=anomalous_cdf_at_mean_plus_1sig,
+                                     win=int(1.0 / min_freq_hz * window_for_validation_Tmax))
     for t in range(n_t):
         if rejected[t]:
             out[t] = empty
             continue
         b0, b1 = bounds[t], bounds[t + 1]
-        idx = merge_candidates(c_index[b0:b1], c_cc[b0:b1], wins[t])
+        idx = merged[t]
         if remove_edges:                        # (data_buffer_sec is given: checked on entry)
             idx = idx[idx * step >= lo_edge]
             if hi_edge is not None:

@@ -67,8 +67,10 @@ class OracleBP:
         pass
 
 
-def mf_detector(cc, moveouts, weights, *, step, window, n_dev, search_win):
-    """Host mirror of the reference's MAD threshold + select_cc_indexes, rows -> (idx, cc, thr)."""
+def mf_detector(cc, moveouts, weights, *, step, window, n_dev, search_win, anomalous_cdf=0.0):
+    """Host mirror of the reference's MAD threshold + select_cc_indexes (its anomalous-CDF validation included:
+    the keyword travels through sharded_matched_filter_detections' detection_kwargs like cc_detections' own
+    anomalous_cdf_at_mean_plus_1sig does), rows -> (idx, cc, thr)."""
     from seismic_bpmf_amd import postprocess as pp
     cc = cc.numpy() if isinstance(cc, torch.Tensor) else cc
     out = {}
@@ -81,7 +83,7 @@ def mf_detector(cc, moveouts, weights, *, step, window, n_dev, search_win):
         thr = pp.time_dependent_threshold_mad(row, window, n_dev, overlap=0.5, white_noise=wn).astype(np.float32)
         idx = pp.select_cc_indexes(row, thr, search_win, step=step, sr=SR, data_duration_sec=0.0, n_dev_threshold=n_dev,
                                    min_freq_hz=2.0, data_buffer_sec=0.0, threshold_type="mad", remove_edges=False,
-                                   anomalous_cdf_at_mean_plus_1sig=0.0)
+                                   anomalous_cdf_at_mean_plus_1sig=anomalous_cdf)
         out[t] = (idx, row[idx].astype(np.float32), thr[idx])
     return out
 
@@ -158,7 +160,7 @@ def _worker(rank, world, port, q):
     src = world - 1                              # the day lives on the LAST rank only: everyone else gets it by broadcast
     det, info = workflow.sharded_matched_filter_detections(
         m["templates"], m["moveouts"], m["weights"], m["data"] if rank == src else None, engine=OracleMF(),
-        detector=mf_detector, data_src=src, step=1, window=600, n_dev=6.0, search_win=40)
+        detector=mf_detector, data_src=src, step=1, window=600, n_dev=6.0, search_win=40, anomalous_cdf=0.45)
     f, tau, wp, ws = bp_case(world)
     peaks, srcs, beam, arg = workflow.sharded_backprojection_detections(
         f if rank == 0 else None, tau, wp, ws, sr=SR, minimum_interevent_time=1.0, engine_factory=OracleBP,
@@ -192,7 +194,7 @@ def test_sharded_workflows_equal_the_single_process_detections(oracle_lib, world
     assert [tuple(r[1]) for r in results] == [tuple(b) for b in bounds]
     assert bounds != parallel.shard_bounds(T, world)             # the weighting is exercised
     cc = oracle_lib.matched_filter(m["templates"], m["moveouts"], m["weights"], m["data"], 1)
-    want = mf_detector(cc, m["moveouts"], m["weights"], step=1, window=600, n_dev=6.0, search_win=40)
+    want = mf_detector(cc, m["moveouts"], m["weights"], step=1, window=600, n_dev=6.0, search_win=40, anomalous_cdf=0.45)
     n_det = sum(len(v[0]) for v in want.values())
     assert n_det >= 3 * T // 4                                    # the planted events are found
     for rank, _, n_rec, det, *_ in results:

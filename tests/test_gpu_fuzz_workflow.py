@@ -155,6 +155,69 @@ def test_fuzz_workflow_matched_filter_detections(oracle_lib, seed):
         assert np.array_equal(got[t], want), f"seed {seed} template {t}: T={T} S={S} C={C} L={L} N={N} step={step}"
 
 
+@pytest.mark.parametrize("seed", _fuzz_seeds(10))
+def test_fuzz_cc_detections_with_the_anomalous_cdf_validation(oracle_lib, seed):
+    """Round 6: the optional validation of MatchedFilter.select_cc_indexes
+    (BPMF/similarity_search.py:253-272) inside the device pipeline -- workflow.cc_detections(...,
+    anomalous_cdf_at_mean_plus_1sig=, window_for_validation_Tmax=, min_freq_hz=), the counts by
+    bpmf_count_below_dev -- against postprocess.select_cc_indexes (pinned to the reference's Python, golden
+    select_cc_indexes_py.npz holds validation cases) on the same CC rows and thresholds.  CC rows with stretches
+    where the threshold fails (a block of large values, as a gap in the data makes them), detections near both
+    ends of the series (the clipped windows), both threshold types, edge removal behind the validation."""
+    import torch
+    from seismic_bpmf_amd import postprocess as pp, workflow
+    rng = np.random.default_rng(36_000 + seed)
+    T, n = int(rng.integers(1, 6)), int(rng.choice([30_000, 61_234]))
+    S, C = int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    sr, step = 100.0, int(rng.choice([1, 1, 2]))
+    cc_h = (0.08 * rng.standard_normal((T, n))).astype(np.float32)
+    for t in range(T):
+        for _ in range(int(rng.integers(2, 9))):                    # isolated detections
+            cc_h[t, int(rng.integers(0, n))] = rng.uniform(0.5, 0.95)
+        for _ in range(int(rng.integers(0, 4))):                    # stretches where the noise level is 5 x higher
+            a = int(rng.integers(0, n - 400))
+            b = a + int(rng.integers(50, 400))
+            cc_h[t, a:b] *= 5.0
+            cc_h[t, int(rng.integers(a, b))] = rng.uniform(0.6, 0.9)
+        cc_h[t, int(rng.integers(0, 20))] = 0.9                     # the clipped windows at both ends
+        cc_h[t, n - 1 - int(rng.integers(0, 20))] = 0.9
+    mv = rng.integers(0, 300, (T, S, C)).astype(np.int32)
+    w = np.full((T, S, C), 1.0 / (S * C), np.float32)
+    window_dur, min_iet = float(rng.choice([20.0, 60.0])), float(rng.choice([0.5, 2.0]))
+    overlap, n_dev = float(rng.choice([0.0, 0.25])), float(rng.choice([6.0, 8.0, 7.3]))
+    min_freq, tmax = float(rng.choice([0.5, 2.0, 4.0])), float(rng.choice([100.0, 250.0, 37.0]))
+    cut = float(rng.choice([0.5, 0.7, 0.3]))
+    kind = str(rng.choice(["rms", "mad"]))
+    wn = rng.standard_normal(500 if kind == "rms" else n).astype(np.float32)
+    edges = bool(rng.integers(0, 2))
+    kw = dict(remove_edges=edges, data_buffer_sec=5.0 if edges else None, data_duration_sec=n * step / sr - 10.0 if edges else None)
+    cc = torch.as_tensor(cc_h, device="cuda")
+    got = workflow.cc_detections(cc, mv, w, step=step, sr=sr, threshold_window_dur=window_dur, minimum_interevent_time=min_iet,
+                                 n_dev=n_dev, overlap=overlap, white_noise=wn, sanity_check=False, threshold_type=kind,
+                                 anomalous_cdf_at_mean_plus_1sig=cut, window_for_validation_Tmax=tmax, min_freq_hz=min_freq, **kw)
+    plain = workflow.cc_detections(cc, mv, w, step=step, sr=sr, threshold_window_dur=window_dur, minimum_interevent_time=min_iet,
+                                   n_dev=n_dev, overlap=overlap, white_noise=wn, sanity_check=False, threshold_type=kind, **kw)
+    window = int(pp.sec_to_samp(window_dur, sr))
+    dropped = 0
+    for t in range(T):
+        if kind == "rms":
+            thr = oracle_lib.time_dependent_threshold(cc_h[t], window, n_dev, overlap, wn)
+        else:
+            thr = pp.time_dependent_threshold_mad(cc_h[t], window, n_dev, overlap=overlap, white_noise=wn).astype(np.float32)
+        thr = np.minimum(thr, np.float32(0.80 * w[t].sum()))
+        win = workflow.search_window(mv[t].reshape(S, -1), int(pp.sec_to_samp(min_iet, sr)), step)
+        want = pp.select_cc_indexes(cc_h[t], thr, win, step=step, sr=sr, data_duration_sec=(n * step / sr - 10.0) if edges else 1e9,
+                                    n_dev_threshold=n_dev, min_freq_hz=min_freq, data_buffer_sec=5.0 if edges else 0.0,
+                                    remove_edges=edges, threshold_type=kind, anomalous_cdf_at_mean_plus_1sig=cut,
+                                    window_for_validation_Tmax=tmax)
+        assert np.array_equal(got[t], want), f"seed {seed} row {t}: n={n} step={step} {kind} cut={cut} win={int(tmax / min_freq)}"
+        dropped += len(plain[t]) - len(got[t])
+    print(f"seed {seed}: the validation dropped {dropped} detections")
+    with pytest.raises(ValueError, match="min_freq_hz"):
+        workflow.cc_detections(cc, mv, w, step=step, sr=sr, threshold_window_dur=window_dur, minimum_interevent_time=min_iet,
+                               anomalous_cdf_at_mean_plus_1sig=0.5, remove_edges=False)
+
+
 def _fuzz_row(rng, n):
     """One row of a distribution the guesses of the order-statistics kernels may or may not cope with."""
     kind = int(rng.integers(0, 12))
