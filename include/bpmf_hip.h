@@ -378,9 +378,11 @@ int bpmf_saturate_rows_dev(const float *d_x, const float *d_median, const float 
  * more zeros than n_noise (checked with one small D2H and a stream synchronise when n_noise < n:
  * hand over n values, as the reference draws them, to stay asynchronous).
  * Limits: rows <= 65535 per call (gridDim.y; callers with more rows chunk them -- ThresholdGPU
- * does), n < 2^31.  The workspace holds a zero-filled COPY of the series, rows * n floats, besides
- * the small per-row arrays (bpmf_tdt_mad_workspace_bytes: ~17 GB for 500 rows of a day at 100 Hz):
- * bound it by calling with fewer rows at a time. */
+ * does), n < 2^31.  The workspace holds NO copy of the series (since round 5 the zeros are replaced where the
+ * medians read them): per row the zero-rank tables (~n / 32 bytes), the window values, and -- for rows of at
+ * least option stats.row_grid_min_n samples -- the buffers the two-read row statistics collect the middle of
+ * a row in (~n / 6 bytes + 100 KB); bpmf_tdt_mad_workspace_bytes: ~1 GB for 500 rows of a day at 100 Hz, a few
+ * KB per row for short rows.  Bound it by calling with fewer rows at a time. */
 size_t bpmf_tdt_mad_num_windows(size_t n, size_t window, size_t shift);
 size_t bpmf_tdt_mad_workspace_bytes(size_t rows, size_t n, size_t window, size_t shift);
 int bpmf_tdt_mad_dev(const float *d_series, const float *d_white_noise, size_t n_noise,

@@ -12,7 +12,7 @@ The package has no CPU implementation: without ``lib/libbpmf_hip.so`` (built by
 ``python -m seismic_bpmf_amd.build``) and a HIP device every entry point raises.
 """
 from ._lib import (BpmfHipError, device_count, device_info, device_memory_held,  # noqa: F401
-                   release_device_memory, set_option, get_option)
+                   release_device_memory, set_option, get_option, compat_profile)
 from .beampower import BeamformerGPU, beamform  # noqa: F401
 from .matched_filter import MatchedFilterGPU, accept_cpu_arch, matched_filter  # noqa: F401
 

@@ -232,3 +232,51 @@ def profile_devices(which):
 def profile_times_ms(which):
     """Durations (ms) of every logged (and closed) launch of dominant kernel `which` since profile_enable."""
     return [ms for _, ms in _closed_launches(which)]
+
+
+# ---- convention profiles (DESIGN.md section 3, INTEGRATION.md sections A and F) ----
+# The arithmetic of both hot paths lives in two third-party packages that are not in the reference tree; seven
+# conventions rest on recollection (SURVEY.md Appendix A) and each has a switch.  A profile sets them all at once.
+COMPAT_SWITCHES = ("mf.compat_exclusive_last_lag", "mf.compat_sqrt_norm", "mf.compat_range_all_channels",
+                   "mf.compat_sequential_csum", "bp.compat_first_computed", "bp.compat_strict_upper_only",
+                   "bp.compat_range_all_stations")
+COMPAT_PROFILES = {
+    # this build's own conventions (every switch off): what the oracle, the goldens and the headline numbers use
+    "build": {},
+    # what SURVEY.md Appendix A recollects of upstream's C (UNVERIFIED -- nothing in this image can confirm it;
+    # tools/diff_upstream.py is the check on a machine that has the packages): the lag loop stops BEFORE
+    # N - L - mv_max, moveout range over ALL channels, cc = num / sqrt(E_t * E_d) above 1e-6, one sequential
+    # double prefix sum; the beamformer's max scan starts from the first computed beam
+    "upstream-recollected": {"mf.compat_exclusive_last_lag": 1, "mf.compat_sqrt_norm": 1,
+                             "mf.compat_range_all_channels": 1, "mf.compat_sequential_csum": 1,
+                             "bp.compat_first_computed": 1},
+}
+
+
+def compat_profile(name=None):
+    """Select a set of conventions for BOTH hot paths, process-wide (bpmf_set_option on all seven `*.compat_*`
+    switches): "build" (the default: this build's own conventions) or "upstream-recollected" (the five
+    alternatives SURVEY.md Appendix A recollects of fast_matched_filter / beampower; costs x 1.14 at cfg2 -- the
+    IEEE square root and divide per channel and lag -- and ~50 ms per day for the sequential prefix sum).
+    Without an argument: the name of the profile the current switches amount to, or None.  The import shims
+    (shims/fast_matched_filter, shims/beampower) run whatever is selected here."""
+    if name is None:
+        now = {n: get_option(n)[0] for n in COMPAT_SWITCHES}
+        for prof, on in COMPAT_PROFILES.items():
+            if all(now[n] == on.get(n, 0) for n in COMPAT_SWITCHES):
+                return prof
+        return None
+    if name not in COMPAT_PROFILES:
+        raise ValueError(f"unknown profile {name!r}: one of {sorted(COMPAT_PROFILES)}")
+    for n in COMPAT_SWITCHES:
+        set_option(n, COMPAT_PROFILES[name].get(n, 0))
+    return name
+
+
+def profile_of_switches(names_on):
+    """The profile whose switched-on options are exactly `names_on` (an iterable of option names), or None."""
+    on = set(names_on)
+    for prof, sw in COMPAT_PROFILES.items():
+        if on == {n for n, v in sw.items() if v}:
+            return prof
+    return None

@@ -1204,7 +1204,8 @@ static bool mf_uses_mfma(size_t step, size_t L, size_t N, size_t T, size_t n_cor
     const int need_t = (mf_band_len((int)L) + MF_THREADS - 1) / MF_THREADS;
     const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);
     const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;
-    return step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && !(sqrt_norm && !network_sum) && need_r <= 24 &&
+    (void)sqrt_norm; (void)network_sum;       // (round 6: the MFMA epilogues store per-channel CCs under the switch too)
+    return step <= max_mfma_step && !(flags & BPMF_MF_FORCE_DIRECT) && need_r <= 24 &&
            need_t <= 9 && T * (n_lag_blocks + 8) < 0x7fffffffull && N < ((size_t)1 << 30) - 8192;
 }
 
@@ -1318,8 +1319,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const size_t max_mfma_step = (size_t)option(OPT_MF_MAX_MFMA_STEP);  // beyond this (64) the direct kernel wins
     // (the MFMA kernels address the data through buffer descriptors with 32-bit byte offsets:
     // traces of 2^30 samples or more take the generic kernel)
-    // option mf.compat_sqrt_norm: num / sqrtf(E_t * E_d) in the epilogue of the MFMA kernels too (network
-    // sums; per-channel output with the switch on takes the generic kernel)
+    // option mf.compat_sqrt_norm: num / sqrtf(E_t * E_d) in the epilogue of the MFMA kernels too (network sums and,
+    // since round 6, per-channel output: the inter-template CC keeps MFMA speed under the upstream-recollected profile)
     const bool sqrt_norm = option(OPT_MF_COMPAT_SQRT_NORM) != 0;
     const bool use_mfma = mf_uses_mfma(step, L, N, T, n_corr, network_sum, flags);
     (void)max_mfma_step;
@@ -1385,7 +1386,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         dim3 grid((unsigned)(8 * ((T * nb_cnt + 7) / 8)));
         const bool big_lds = lds > 64 * 1024;  // long templates: opt in to > 64 KB dynamic LDS
 #define BPMF_MF_LAUNCH2(NS, R, TT, S1) \
-    do { if (NS && sqrt_norm) BPMF_MF_LAUNCH3(NS, R, TT, S1, NS); else BPMF_MF_LAUNCH3(NS, R, TT, S1, false); } while (0)
+    do { if (sqrt_norm) BPMF_MF_LAUNCH3(NS, R, TT, S1, true); else BPMF_MF_LAUNCH3(NS, R, TT, S1, false); } while (0)
 #define BPMF_MF_LAUNCH3(NS, R, TT, S1, SQ)                                                        \
     do {                                                                                              \
         auto kfn = mf_mfma_kernel<NS, R, TT, S1, SQ>;                                                 \
@@ -1427,7 +1428,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
         (int)n_ch, (long long)n_corr, (int)step, d_cc_out, (int)n_blocks_w, (int)option(OPT_MF_BOUNDARY_PRIO), \
         d_moveouts, d_weights, exclusive_last, (int)nbw_lo)
 #define BPMF_MF_WAVE_LAUNCH3(NS, S1, R, NT, FU) \
-    do { if (NS && sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, NS, FU); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false, FU); } while (0)
+    do { if (sqrt_norm) BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, true, FU); else BPMF_MF_WAVE_LAUNCH4(NS, S1, R, NT, false, FU); } while (0)
 #define BPMF_MF_WAVE_LAUNCH(NS, S1)                                                              \
     do {                                                                                         \
         if (ntile == 4) BPMF_MF_WAVE_LAUNCH3(NS, S1, 20, 4, false);                              \

@@ -132,16 +132,23 @@ def broadcast_day(array, src, device, group=None):
     gsrc = src if group is None else dist.get_global_rank(group, src)
     shape = torch.zeros(4, dtype=torch.int64, device=device)
     t = None
+    problem = None
     if rank == src:
+        # (a bad argument on the source must not leave the other ranks inside the shape broadcast until the backend's
+        # timeout: the source broadcasts a status word -- shape[3] = 0 -- and EVERY rank raises behind it)
         if array is None:
-            raise ValueError(f"rank {src} is the source of the broadcast and must pass the array")
-        t = array if isinstance(array, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32))
-        t = t.to(device=device, dtype=torch.float32).contiguous()
-        if t.dim() != 3:
-            raise ValueError("the day must be (S, C, N)")
-        shape[:3] = torch.tensor(t.shape, dtype=torch.int64)
-        shape[3] = 1
+            problem = f"rank {src} is the source of the broadcast and must pass the array"
+        else:
+            t = array if isinstance(array, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(array, dtype=np.float32))
+            t = t.to(device=device, dtype=torch.float32).contiguous()
+            if t.dim() != 3:
+                problem = "the day must be (S, C, N)"
+            else:
+                shape[:3] = torch.tensor(t.shape, dtype=torch.int64)
+                shape[3] = 1
     dist.broadcast(shape, src=gsrc, group=group)
+    if int(shape[3].item()) != 1:
+        raise ValueError(problem or f"broadcast_day: rank {src} (the source) reported a bad argument; nothing was broadcast")
     if rank != src:
         t = torch.empty(tuple(int(x) for x in shape[:3].tolist()), dtype=torch.float32, device=device)
     dist.broadcast(t, src=gsrc, group=group)

@@ -96,7 +96,10 @@ class ThresholdGPU:
         # the medians read them, there is no filled copy of the matrix any more) and the buffers the row statistics
         # collect the middle of a row in (n / 10 bytes per row) -- stays under
         # `mad_workspace_limit` bytes (4 GiB by default; one row always goes)
-        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // max(1, n // 6 + 32768))))
+        # (per-row bytes from the library itself: short rows take the one-workgroup statistics and need next to nothing,
+        # long ones ~n / 6 + 100 KB)
+        per_row = max(1, int(self.lib.bpmf_tdt_mad_workspace_bytes(64, n, W, shift)) // 64)
+        chunk = int(max(1, min(rows, 65535, self.mad_workspace_limit // per_row)))
         nbytes = self.lib.bpmf_tdt_mad_workspace_bytes(chunk, n, W, shift)
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None

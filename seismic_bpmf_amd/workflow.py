@@ -344,10 +344,17 @@ def sharded_matched_filter_detections(templates, moveouts, weights, data, *, gro
     "records_gathered": n, "broadcast_ms": float or None}.
 
     `engine` / `detector`: stand-ins for the per-rank MatchedFilterGPU and for cc_detections (the CPU tests
-    of the choreography over gloo pass oracle-backed ones); None = the HIP path."""
+    of the choreography over gloo pass oracle-backed ones); None = the HIP path.
+
+    threshold_type="mad" needs an explicit `white_noise` here: without one every rank would draw its own
+    (np.random, as the reference does per call) and the ranks' detections would not be those of one process."""
     import time
     import torch
     from . import parallel
+    if detector is None and str(detection_kwargs.get("threshold_type", "rms")).lower() == "mad" and \
+            detection_kwargs.get("white_noise") is None:
+        raise ValueError("sharded_matched_filter_detections: threshold_type='mad' needs white_noise (the same array on "
+                         "every rank); each rank would otherwise draw its own")
     smf = parallel.ShardedMatchedFilter(group=group, device=device, local=engine)
     t_b = None
     if data_src is None:
@@ -392,17 +399,19 @@ def sharded_backprojection_detections(features, moveouts, weights_phases, weight
     from . import parallel
     sb = parallel.ShardedBeamformer(moveouts, weights_sources, group=group, device=device,
                                     local_factory=engine_factory)
-    if features_src is not None:
-        features = sb.broadcast_features(features, src=features_src)
-    beam, arg = sb.run(features, weights_phases, "max", out_of_bounds)
-    mpd = int(pp.sec_to_samp(minimum_interevent_time, sr))
-    if detector is not None:
-        peaks, peak_sources = detector(beam, arg)
-    else:
-        window = None if threshold is not None else int(pp.sec_to_samp(threshold_window_dur, sr))
-        peaks, peak_sources, _ = beam_detections_device(beam, arg, mpd=mpd, threshold=threshold, window=window,
-                                                       n_dev=n_dev, overlap=overlap, device=device)
-    sb.close()
+    try:                                 # (the per-rank engine -- plan and working set -- goes whatever happens)
+        if features_src is not None:
+            features = sb.broadcast_features(features, src=features_src)
+        beam, arg = sb.run(features, weights_phases, "max", out_of_bounds)
+        mpd = int(pp.sec_to_samp(minimum_interevent_time, sr))
+        if detector is not None:
+            peaks, peak_sources = detector(beam, arg)
+        else:
+            window = None if threshold is not None else int(pp.sec_to_samp(threshold_window_dur, sr))
+            peaks, peak_sources, _ = beam_detections_device(beam, arg, mpd=mpd, threshold=threshold, window=window,
+                                                           n_dev=n_dev, overlap=overlap, device=device)
+    finally:
+        sb.close()
     return peaks, peak_sources, beam, arg
 
 

@@ -248,3 +248,45 @@ def test_two_rank_sharded_matched_filter_gathers_the_single_process_detections(o
     for rank, _, parts in results:
         got = [tuple(r) for p in parts for r in p.tolist()]
         assert [(int(a), int(b), c) for a, b, c in got] == want, rank
+
+
+def _bad_broadcast_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from seismic_bpmf_amd import parallel
+    out = []
+    for bad in (np.zeros((4, 100), np.float32), None):          # not (S, C, N); no array at all
+        try:
+            parallel.broadcast_day(bad if rank == 0 else None, 0, torch.device("cpu"))
+            out.append("returned")
+        except ValueError as e:
+            out.append(str(e))
+    # the group is still usable: a good broadcast behind the two refused ones
+    day = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    got = parallel.broadcast_day(day if rank == 0 else None, 0, torch.device("cpu"))
+    out.append(bool(np.array_equal(got.numpy(), day)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_bad_day_on_the_source_rank_raises_on_every_rank_instead_of_hanging_the_others():
+    """Round-5 advisor: broadcast_day validated on the source only and raised BEFORE the first collective -- the
+    other ranks sat in the shape broadcast until the backend's timeout.  Now the source broadcasts a status word
+    and every rank raises behind it; the group stays usable."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_broadcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "(S, C, N)" in results[0][0] and "must pass the array" in results[0][1]
+    assert "bad argument" in results[1][0] and "bad argument" in results[1][1]
+    assert results[0][2] is True and results[1][2] is True

@@ -300,3 +300,46 @@ def test_bp_range_all_stations(oracle_lib, hip_opts, fast, direct):
     hip_opts.reset("bp.compat_range_all_stations")
     got = beamform(f, tau, wp, ws, device="gpu", out_of_bounds="strict")
     assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1])
+
+
+def test_compat_profile_sets_the_recollected_conventions_of_both_paths(oracle_lib):
+    """seismic_bpmf_amd.compat_profile("upstream-recollected") (round 6): one call switches both hot paths to the
+    five conventions SURVEY.md Appendix A recollects; the results equal the oracle's under the same flags, bit for
+    bit, through the drop-in calls; "build" switches back."""
+    import seismic_bpmf_amd as sb
+    from seismic_bpmf_amd import _lib
+    rng = np.random.default_rng(606)
+    tp = rng.standard_normal((3, 4, 3, 96)).astype(np.float32)
+    mv = rng.integers(-20, 400, (3, 4, 3)).astype(np.int32)
+    w = rng.random((3, 4, 3)).astype(np.float32)
+    w[0, 1] = 0.0
+    mv[0, 1] = 3000                      # an unweighted channel that shapes the lag range under range_all_channels
+    d = rng.standard_normal((4, 3, 20_000)).astype(np.float32)
+    f = np.abs(rng.standard_normal((5, 2, 6000))).astype(np.float32)
+    tau = rng.integers(0, 150, (60, 5, 2)).astype(np.int32)
+    wp = np.zeros((5, 2, 2), np.float32)
+    wp[:, 0, 0] = wp[:, 1, 1] = 1.0
+    ws = (rng.random((60, 5)) < 0.6).astype(np.float32)
+    assert sb.compat_profile() == "build"
+    try:
+        assert sb.compat_profile("upstream-recollected") == "upstream-recollected"
+        assert sb.compat_profile() == "upstream-recollected"
+        mf_flags = (oracle_lib.COMPAT_EXCLUSIVE_LAST_LAG | oracle_lib.COMPAT_SQRT_NORM |
+                    oracle_lib.COMPAT_RANGE_ALL_CHANNELS | oracle_lib.COMPAT_SEQUENTIAL_CSUM)
+        for ns in (True, False):
+            got = sb.matched_filter(tp, mv, w, d, 1, check_zeros=False, network_sum=ns)
+            with oracle_lib.compat(mf_flags):
+                want = oracle_lib.matched_filter(tp, mv, w, d, 1, ns)
+            assert np.array_equal(got, want), f"network_sum={ns}"
+        gb, ga = sb.beamform(f, tau, wp, ws, device="gpu")
+        with oracle_lib.compat(oracle_lib.COMPAT_FIRST_COMPUTED):
+            wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+        assert np.array_equal(gb, wb) and np.array_equal(ga, wa)
+        _lib.set_option("mf.compat_sqrt_norm", 0)
+        assert sb.compat_profile() is None               # a hand-made mixture has no name
+    finally:
+        sb.compat_profile("build")
+    assert sb.compat_profile() == "build"
+    assert np.array_equal(sb.matched_filter(tp, mv, w, d, 1, check_zeros=False), oracle_lib.matched_filter(tp, mv, w, d, 1, True))
+    with pytest.raises(ValueError):
+        sb.compat_profile("upstream")

@@ -88,6 +88,22 @@ def test_kit_names_the_conventions_of_a_stand_in_upstream(oracle_lib, tmp_path, 
     assert rep["equal_on_every_case_flags"] == [bp_flags], rep["equal_on_every_case"]
 
 
+@pytest.mark.parametrize("mf_flags,bp_flags,profile", [(1 | 2 | 8 | 16, 4, "upstream-recollected"), (0, 0, "build")])
+def test_kit_names_the_profile_when_one_matches(oracle_lib, tmp_path, mf_flags, bp_flags, profile):
+    """seismic_bpmf_amd.compat_profile (round 6): a stand-in upstream that implements exactly the conventions of a
+    named profile is reported by that name, for both paths."""
+    import diff_upstream as kit
+    from seismic_bpmf_amd import _lib
+    _write_stand_ins(str(tmp_path), mf_flags, bp_flags)
+    for which, flags in (("mf", mf_flags), ("bp", bp_flags)):
+        rep = kit.diff_path(which, extra_path=[str(tmp_path)], quiet=True)
+        assert rep["equal_on_every_case_flags"] == [flags]
+        assert rep.get("profile") == profile
+    on = [n for b, (n, _) in oracle_lib.COMPAT_OPTIONS.items() if (mf_flags | bp_flags) & b]
+    assert _lib.profile_of_switches(on) == profile
+    assert _lib.profile_of_switches(["mf.compat_sqrt_norm"]) is None
+
+
 def _real(which):
     import diff_upstream as kit
     mod, why = kit.find_upstream(which)

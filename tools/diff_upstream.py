@@ -327,6 +327,17 @@ def diff_path(which, write=False, extra_path=(), quiet=False):
         say(f"[{which}] ==> bit-equal on every case with: {flag_names(f) or '(the defaults: no switch needed)'}")
         for n in flag_names(f):
             say(f'        _lib.set_option("{n}", 1)')
+        # a named profile (seismic_bpmf_amd.compat_profile) whose switches of THIS path are exactly these?
+        try:
+            from seismic_bpmf_amd import _lib as _plib
+            mine = {n for n in flag_names(f)}
+            for prof, sw in _plib.COMPAT_PROFILES.items():
+                if {n for n, v in sw.items() if v and n.startswith(which + ".")} == mine:
+                    say(f'[{which}] ==> that is profile "{prof}" for this path: seismic_bpmf_amd.compat_profile("{prof}")')
+                    report["profile"] = prof
+                    break
+        except Exception:
+            pass
     else:
         say(f"[{which}] ==> no single combination is bit-equal on every case: see the per-case lines; the closest "
             "combinations bound what a float32 tolerance must cover")
