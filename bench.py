@@ -803,6 +803,39 @@ def main():
                                             "achieved": round(flop / (kms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
                                             "unit": "TFLOP/s", "frac": round(flop / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                                             "frac_whole_call": round(flop / wall / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+            if name == "tutorial":
+                # the SAME call as a BPMF user makes it (nb8 cell 18: MatchedFilter.compute_cc_time_series ->
+                # fmf.matched_filter, BPMF/similarity_search.py:526-533): through the import shim, NumPy in / out.
+                # BASELINE.md's one published figure -- 4.30 s on 24 CPU threads -- is for exactly this call
+                # (context, not a target: other hardware)
+                sys.path.insert(0, os.path.join(ROOT, "shims"))
+                try:
+                    import fast_matched_filter as fmf_shim
+                    h = [x.cpu().numpy() for x in (t2, m2, w2, d2)]
+                    want = o2.cpu().numpy()
+                    calls, st = [], None
+                    for _ in range(4):
+                        dn = h[3].copy()
+                        t0 = time.perf_counter()
+                        got = fmf_shim.matched_filter(h[0], h[1], h[2], dn, 1, arch="gpu", check_zeros=False)
+                        calls.append((time.perf_counter() - t0) * 1e3)
+                        st = _lib.host_call_stats()
+                        del dn
+                    later = sorted(calls[1:])
+                    mf_shapes["tutorial_shim"] = {
+                        "workload": f"fast_matched_filter.matched_filter (shims/) NumPy in / out: {T2} x {S2} x {C2}, L={L2}, N={N2}; "
+                                    f"H2D {h[3].nbytes / 1e6:.0f} MB, D2H {got.nbytes / 1e6:.0f} MB",
+                        "ms": round(later[len(later) // 2], 2), "calls_ms": [round(x, 2) for x in calls],
+                        "kernel_ms_resident": round(kms, 3), "resident_call_ms": round(wall * 1e3, 3),
+                        "value": round(T2 * (N2 - L2 + 1) / (later[len(later) // 2] * 1e-3) / 1e6, 1), "unit": "M CC-samples/s",
+                        "breakdown_of_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()},
+                        "difference_is": "the day's way up (PCIe, through the pinned pieces), the per-day preparation (prefix sums, norms: "
+                                         "a resident engine does it once per day, this call every time), the CC matrix's way down, Python",
+                        "equals_resident_result": bool(np.array_equal(got, want)),
+                        "published_reference": "4.30 s for this call on 24 CPU threads (tutorial nb8 cell 18; BASELINE.md)"}
+                    del h, got, want
+                finally:
+                    sys.path.remove(os.path.join(ROOT, "shims"))
             del d2, t2, m2, w2, o2, mf2
         torch.cuda.empty_cache()
 
@@ -923,6 +956,66 @@ def main():
                                                                    np.array_equal(ha, arg.cpu().numpy()))}
             del h_f, hb, ha
         if rank == 0 and world == 1 and dist is None and not args.skip_e2e:
+            # untimed extra: the tutorial's own backprojection (nb5 cell 33: bf.backproject -> beampower.beamform,
+            # BPMF/template_search.py:549-558): 35 490 sources (nb4 cell 32) x one day at 25 Hz x 8 stations x 2 phases
+            # (PhaseNet features: 2 channels, one per phase; all 8 stations weighted), reduce="max" -- resident, and
+            # through the import shim with NumPy in / out and int64 moveouts as BPMF delivers them
+            try:
+                tg = syn.make_bp_geometry((39, 35, 26), 8, 2, 25.0, n_closest=8)
+                Nt = 2_160_000
+                ft = torch.randn((8, 2, Nt), device=device, generator=torch.Generator(device=device).manual_seed(11)).abs_()
+                wpt = syn.phase_weights(8, 2, 2)
+                bft = sb.BeamformerGPU(tg["moveouts"], tg["weights_sources"], device=local_rank)
+                wpt_d = torch.as_tensor(wpt, device=device)
+                tb, ta = bft.run(ft, wpt_d, "max", "strict")
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    bft.run(ft, wpt_d, "max", "strict", out=(tb, ta))
+                torch.cuda.synchronize()
+                t_res = (time.perf_counter() - t0) / 3 * 1e3
+                _lib.profile_enable(False)
+                tk = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_BP_BEAM)))
+                tinfo = bft.plan_info()
+                Kt = tg["moveouts"].shape[0]
+                gb = 4.0 * 8 * 2 * Kt * Nt / (tk * 1e-3) / 1e12
+                tpeak = LDS_B32_PEAK_TBS * (2.0 if tinfo["gather_bytes"] == 8 else 1.0)
+                sys.path.insert(0, os.path.join(ROOT, "shims"))
+                try:
+                    import beampower as bp_shim
+                    hft, mv64 = ft.cpu().numpy(), tg["moveouts"].astype(np.int64)
+                    calls, st = [], None
+                    for _ in range(4):
+                        hn = hft.copy()
+                        t0 = time.perf_counter()
+                        sb_, sa_ = bp_shim.beampower.beamform(hn, mv64, wpt, tg["weights_sources"], device="gpu", reduce="max")
+                        calls.append((time.perf_counter() - t0) * 1e3)
+                        st = _lib.host_call_stats()
+                        del hn
+                    later = sorted(calls[1:])
+                    same = bool(np.array_equal(sb_, tb.cpu().numpy()) and np.array_equal(sa_, ta.cpu().numpy()))
+                finally:
+                    sys.path.remove(os.path.join(ROOT, "shims"))
+                bp_obj["tutorial"] = {
+                    "workload": f"{Kt} sources x {Nt} samples (1 day @ 25 Hz) x 8 stations x 2 phases, 2 channels, all stations weighted, reduce=max",
+                    "resident_ms": round(t_res, 2), "kernel_ms": round(tk, 2),
+                    "value": Kt * Nt / (t_res * 1e-3), "unit": "grid-points x samples / s",
+                    "roofline": {"bound": "lds-gather", "achieved": round(gb, 2), "peak": round(tpeak, 1), "unit": "TB/s",
+                                 "frac": round(gb / tpeak, 4)},
+                    "shim": {"through": "beampower.beampower.beamform (shims/), NumPy in / out, int64 moveouts",
+                             "ms": round(later[len(later) // 2], 2), "calls_ms": [round(x, 2) for x in calls],
+                             "breakdown_of_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()},
+                             "difference_is": f"H2D {hft.nbytes / 1e6:.0f} MB of features in pieces beside the kernels, D2H {(sb_.nbytes + sa_.nbytes) / 1e6:.0f} MB, the "
+                                              "int64 -> int32 cast and comparison of the 4.5 MB moveout table (the plan is found in the library's cache "
+                                              "after the first call, which builds it), Python",
+                             "equals_resident_result": same},
+                    "published_reference": "none: nb5 cell 33 prints no timing (BASELINE.md)"}
+                bft.close()
+                del ft, tb, ta, hft
+                torch.cuda.empty_cache()
+            except Exception as e:                      # (an extra must not cost the line)
+                bp_obj["tutorial"] = {"failed": str(e)}
             # untimed extra: the stage in FRONT of the beamformer in the vanilla workflow -- saturated envelopes of
             # the day (BPMF/template_search.py:1525-1617: analytic signal, per-channel median / MAD, standardise,
             # clip) on configs[2]'s 60 channels x 4.32 M samples, resident in HBM

@@ -76,7 +76,8 @@ int bpmf_device_memory_held(int device, size_t *device_bytes, size_t *pinned_byt
  *   pieces (summed over the pieces; overlaps the kernels of earlier pieces); out[3] waiting for the device after
  *   the last launch was enqueued (kernels still running + the results' way back); out[4] pieces the day arrived
  *   in; out[5] host threads that filled them; out[6] waiting for a pinned piece to be free again (its previous
- *   copy still in flight); out[7] inside the runtime's asynchronous-copy calls of the pieces.  Returns the number of values written (<= n).  The reference has no
+ *   copy still in flight); out[7] inside the runtime's asynchronous-copy calls of the pieces;
+ *   out[8] finding (or building) the backprojection plan; out[9] reserving the device working set and the pinned pieces.  Returns the number of values written (<= n).  The reference has no
  *   counterpart (its back-ends' calls are opaque, BPMF/template_search.py:549-558); bench.py reports these beside
  *   the end-to-end times. */
 int bpmf_host_call_stats(double *out, int n);

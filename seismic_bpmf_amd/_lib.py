@@ -136,10 +136,10 @@ def last_error():
 
 def host_call_stats():
     """Where the time of this thread's last host-pointer call went (bpmf_host_call_stats), milliseconds."""
-    buf = (C.c_double * 8)()
-    k = lib().bpmf_host_call_stats(buf, 8)
+    buf = (C.c_double * 10)()
+    k = lib().bpmf_host_call_stats(buf, 10)
     names = ("total_ms", "first_kernel_start_ms", "host_copy_ms", "device_wait_ms", "pieces", "fill_threads",
-             "pinned_wait_ms", "copy_enqueue_ms")
+             "pinned_wait_ms", "copy_enqueue_ms", "plan_ms", "reserve_ms")
     out = {n: float(buf[i]) for i, n in enumerate(names[:k])}
     for n in ("pieces", "fill_threads"):
         if n in out:

@@ -1338,12 +1338,47 @@ bool build_plan_halves(const int32_t* mv, const float* ws, const std::vector<int
     return true;
 }
 
+// The tables of a plan travel through ONE pinned scratch buffer of the process (grow-only, under a mutex), not
+// straight from the std::vectors that hold them: a pageable source makes the runtime page-lock the vector's pages for
+// the copy, the vector is freed when the plan is built, and the NEXT host-pointer call of the process found its
+// first piece of the day stalled for 20-40 ms (tools/probe_bp_e2e.py, profiles/r06_bp_e2e.txt: always the call
+// behind the one that built a plan, never later ones).
+struct PlanScratch {
+    std::mutex m;
+    char* p = nullptr;
+    size_t cap = 0;
+};
+PlanScratch& plan_scratch()
+{
+    static PlanScratch* s = new PlanScratch();      // (leaked: pinned memory must not be freed from a static destructor)
+    return *s;
+}
+
 template <typename Tv>
 int upload(const std::vector<Tv>& v, Tv** d)
 {
     size_t b = std::max<size_t>(v.size(), 1) * sizeof(Tv);
     BPMF_HIP_CHECK(hipMalloc((void**)d, b));
-    if (!v.empty()) BPMF_HIP_CHECK(hipMemcpy(*d, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    if (v.empty()) return 0;
+    const size_t bytes = v.size() * sizeof(Tv);
+    PlanScratch& sc = plan_scratch();
+    std::lock_guard<std::mutex> g(sc.m);
+    if (sc.cap < bytes) {
+        if (sc.p) (void)hipHostFree(sc.p);
+        sc.p = nullptr;
+        sc.cap = 0;
+        const size_t want = align_up(std::max<size_t>(bytes + bytes / 4, (size_t)4 << 20), (size_t)1 << 20);
+        if (hipHostMalloc((void**)&sc.p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            sc.p = nullptr;
+            // (no pinned memory to be had: the runtime's own pageable path)
+            BPMF_HIP_CHECK(hipMemcpy(*d, v.data(), bytes, hipMemcpyHostToDevice));
+            return 0;
+        }
+        sc.cap = want;
+    }
+    memcpy(sc.p, v.data(), bytes);
+    BPMF_HIP_CHECK(hipMemcpy(*d, sc.p, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -2630,6 +2665,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     }
     if (!pl)
         if (int rc = bpmf_bp_plan_create(moveouts, w_sources, K, S, P, device, 0, &pl)) return rc;
+    t_call_stats.plan_ms = host_now_ms() - t_call0;
     auto release_plan = [&]() {
         std::lock_guard<std::mutex> g(g_plan_cache_mutex);
         const size_t cap = plan_cache_capacity();
@@ -2679,11 +2715,13 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     const size_t o_f = 0, o_wp = o_f + align_up(b_f, 256), o_ws = o_wp + align_up(b_wp, 256),
                  o_beam = o_ws + align_up(b_ws, 256), o_arg = o_beam + align_up(b_beam, 256),
                  total = o_arg + b_arg;
+    const double t_res0 = host_now_ms();
     char* base = ctx->reserve_device(total);
     if (!base || ctx->reserve_pinned(std::min<size_t>((size_t)64 << 20, std::max<size_t>(b_f, 4096)))) {
         release_plan();
         return -2;
     }
+    t_call_stats.reserve_ms = host_now_ms() - t_res0;
     int rc = 0;
     hipStream_t stream = ctx->s_run;
     hipError_t e = hipSuccess;
@@ -2737,7 +2775,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
         from_peer = fanout_peer_copy(fan, ctx, base + o_f, b_f, stream, &e, &what);
         if (from_peer && e != hipSuccess) fail(e, what);
     }
-    if (!rc && (e = hipMemcpyAsync(base + o_wp, w_phases, b_wp, hipMemcpyHostToDevice, stream)) != hipSuccess) fail(e, "H2D weights_phases");
+    if (!rc && (e = staged_upload_rows(ctx, (float*)(base + o_wp), w_phases, 1, b_wp / 4, 0, b_wp / 4, stream)) != hipSuccess) fail(e, "H2D weights_phases");
     if (!rc && reduce == BPMF_BP_REDUCE_NONE &&
         (e = hipMemsetAsync(base + o_beam, 0, b_beam, stream)) != hipSuccess) fail(e, "memset");
     if (!rc) {

@@ -68,7 +68,7 @@ struct DeviceContext {
 
 // bpmf_host_call_stats: where the time of the calling thread's last host-pointer call went (include/bpmf_hip.h)
 struct HostCallStats {
-    double total_ms = 0, first_kernel_ms = 0, host_copy_ms = 0, device_wait_ms = 0, pinned_wait_ms = 0, enqueue_ms = 0;
+    double total_ms = 0, first_kernel_ms = 0, host_copy_ms = 0, device_wait_ms = 0, pinned_wait_ms = 0, enqueue_ms = 0, plan_ms = 0, reserve_ms = 0;
     int pieces = 0, fill_threads = 0;
 };
 extern thread_local HostCallStats t_call_stats;

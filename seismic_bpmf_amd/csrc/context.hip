@@ -584,10 +584,10 @@ extern "C" int bpmf_release_device_memory(int device)
 extern "C" int bpmf_host_call_stats(double* out, int n)
 {
     const bpmf::HostCallStats& st = bpmf::t_call_stats;
-    const double v[8] = {st.total_ms, st.first_kernel_ms, st.host_copy_ms, st.device_wait_ms, (double)st.pieces,
-                         (double)st.fill_threads, st.pinned_wait_ms, st.enqueue_ms};
+    const double v[10] = {st.total_ms, st.first_kernel_ms, st.host_copy_ms, st.device_wait_ms, (double)st.pieces,
+                          (double)st.fill_threads, st.pinned_wait_ms, st.enqueue_ms, st.plan_ms, st.reserve_ms};
     int k = 0;
-    for (; out && k < n && k < 8; ++k) out[k] = v[k];
+    for (; out && k < n && k < 10; ++k) out[k] = v[k];
     return k;
 }
 

@@ -1562,9 +1562,12 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
         rc = -2;
     };
 #define MF_TRY(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) fail(e_, what); } while (0)
-    if (!rc) MF_TRY(hipMemcpyAsync(base + o_tp, templates, b_tp, hipMemcpyHostToDevice, s_run), "H2D templates");
-    if (!rc) MF_TRY(hipMemcpyAsync(base + o_mv, moveouts, b_mv, hipMemcpyHostToDevice, s_run), "H2D moveouts");
-    if (!rc) MF_TRY(hipMemcpyAsync(base + o_w, weights, b_w, hipMemcpyHostToDevice, s_run), "H2D weights");
+    // (through the pinned pieces, like the day: a pageable source makes the runtime page-lock the caller's pages for the
+    // copy, and arrays that are temporaries of the Python wrapper -- the int32 moveouts, the broadcast weights -- are
+    // freed when the call returns: the NEXT call's first copy then stalls for tens of milliseconds, bp.hip: upload())
+    if (!rc) MF_TRY(staged_upload_rows(ctx, (float*)(base + o_tp), templates, 1, b_tp / 4, 0, b_tp / 4, s_run), "H2D templates");
+    if (!rc) MF_TRY(staged_upload_rows(ctx, (float*)(base + o_mv), (const float*)moveouts, 1, b_mv / 4, 0, b_mv / 4, s_run), "H2D moveouts");
+    if (!rc) MF_TRY(staged_upload_rows(ctx, (float*)(base + o_w), weights, 1, b_w / 4, 0, b_w / 4, s_run), "H2D weights");
     // ---- The day of data.  A peer of a multi-device call copies it from the first device; a small problem
     // uploads it in one go.  A day-long series arrives IN PIECES on the copy stream while the first
     // template batch is computed on the lags whose windows have arrived (launches of bpmf_mf_run_dev over
