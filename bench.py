@@ -945,9 +945,8 @@ def main():
                                     "pinned_wait_ms_by_call": [round(st.get("pinned_wait_ms", 0.0), 1) for st in stats],
                                     "breakdown_note": ("first_kernel_start_ms: entry -> first kernel enqueued; host_copy_ms: the copy pool filling the "
                                                        "pinned pieces (overlaps earlier pieces' kernels); pinned_wait_ms: blocked until a piece's previous "
-                                                       "H2D had completed -- ~8 ms when the copies flow, 35-45 ms in the occasional call whose FIRST piece "
-                                                       "stalls on the device side (profiles/r06_bp_e2e.txt: seen in the second call of some processes and "
-                                                       "not of others on the same box, never under rocprofv3); device_wait_ms: last launch enqueued -> results "
+                                                       "H2D had completed (~10 ms over the 17 pieces of a cfg3 day; rounds 4-5 lost 20-40 ms here in the call behind a plan build: "
+                                                       "the plan's tables went up from pageable vectors, profiles/r06_bp_e2e.txt); device_wait_ms: last launch enqueued -> results "
                                                        "in the caller's arrays"),
                                     "host": {"loadavg_1min": round(os.getloadavg()[0], 1), "fill_threads": stats[rep].get("fill_threads")},
                                     "moves": f"H2D {h_f.nbytes / 1e9:.2f} GB features, D2H {(hb.nbytes + ha.nbytes) / 1e6:.0f} MB "

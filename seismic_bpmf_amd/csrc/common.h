@@ -22,7 +22,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // Execution options (util.hip, C ABI: bpmf_set_option / bpmf_get_option).  Every option selects
 // among code paths and sizes that produce IDENTICAL results -- kernel family, LDS budget, staging
 // batch sizes, group ranges per tile; none of them can change an output bit, and the library reads
-// nothing from the environment.  The exception are the `*.compat_*` switches at the end (off
+// nothing from the environment.  The exceptions: option mf.split16 (off by default; matched-filter numerators on the
+// fp16 matrix pipe from hi/lo splits: results within 3e-7 of the exact path instead of bit-identical, mf_split.h), and
+// the `*.compat_*` switches at the end (off
 // by default): each replaces one convention of this build that rests on recollection only by the
 // alternative the upstream packages may implement.  The defaults are the tuned production values; the GPU tests use
 // the options to force every kernel family through the same parity cases.

@@ -11,7 +11,7 @@ def kernel_stats(path, out):
             name = r["Name"].split("(")[0].replace("void ", "")
             f.write(f'{name},{r["Calls"]},{float(r["TotalDurationNs"])/1e6:.3f},{float(r["AverageNs"])/1e6:.4f},{r["Percentage"]}\n')
 
-def kernel_stats_by_grid(trace_path, out, kernels=("mf_mfma", "bp_beam_fast", "bp_beam_wps2")):
+def kernel_stats_by_grid(trace_path, out, kernels=("mf_mfma", "mf_split", "bp_beam_fast", "bp_beam_wps2")):
     """rocprofv3's kernel_stats.csv averages ALL launches of a kernel, and bench.py launches the
     hot kernels at several sizes (the timed steps at the full workload, plus the end-to-end call's
     batches, the planted-event checks and the small configs[0] runs of the CPU-baseline leg).  This
