@@ -8,15 +8,18 @@
 // "0 where r_t * r_d >= 1000" rule, the weighted channel sum in channel order.
 //
 // Numerator.  Every sample x (of the data and of the templates, each channel scaled by a power of two so that
-// its largest magnitude lies in [2^14, 2^15)) is split as  x = hi + lo + e,  hi = fp16(x), lo = fp16(x - hi),
-// |e| <= 2^-22 |x| (lo is a normal fp16 number for every |x| >= 2^-3, i.e. down to 4e-6 of the channel's
-// maximum, and loses bits gradually below).  Three fp16 MFMA products accumulate in ONE fp32 accumulator,
+// its largest magnitude lies in [2^14, 2^15)) is split as  x = hi + lo + e,  hi = fp16(x), lo = x - hi rounded to
+// fp16, |e| <= 2^-22 |x|.  Three fp16 MFMA products accumulate in ONE fp32 accumulator,
 //     num = sum (hi_t hi_d + hi_t lo_d + lo_t hi_d),
 // leaving out only the lo * lo term (<= 2^-22 |t||d| per term): |d num| <~ 3 * 2^-22 * sum |t d|  <=  7.2e-7 *
 // sqrt(E_t E_d), i.e. a CC error of the size of the fp32 chain's own rounding and far inside 2e-5 (SURVEY
 // App. C MF-5).  v_mfma_f32_32x32x16_f16 runs at 16x the rate of the exact-fp32 MFMA; with three products 16/3.
-// (A second accumulator for the cross products, lo scaled by 2^11, would keep lo normal for any dynamic range;
-// it costs 32 VGPRs the kernel does not have at two waves per SIMD.)
+// The DATA's lo is stored scaled by 2^11 (lo' = fp16((x - hi) * 2^11), of the magnitude of x itself): stored plain it
+// would be an fp16 subnormal for every sample below 2^-17 of its channel's maximum and lose its bits -- a quiet
+// window of a channel that also holds a glitch 10^7 times larger came out 3e-4 wrong (found by the fuzz sweep, seed
+// 560).  The product that consumes it, hi_t * lo_d, takes hi_t * 2^-11 instead (one v_pk_mul_f16 per A register
+// and k-step: the VALU is idle beside the MFMAs; a template's coefficients span a few binades, the scaled ones stay
+// normal).  With that the split resolves a sample down to 2^-50 of its channel's maximum.
 //
 // Tile algebra (v_mfma_f32_32x32x16_f16): one 32 x 32 tile = 1024 consecutive lags of one (template, channel):
 //     Out[b][a] = sum_m A[b][m] * D[m][a],   lag = 32 a + b
@@ -28,7 +31,7 @@
 // sums in registers -- the structure of mf_mfma_wave_kernel.
 //
 // Layout in HBM (prepared once per day / per template batch):
-//   split data  [channel][q][2][8] fp16: q-chunk q = samples 8q .. 8q+7 as 8 hi values then 8 lo values (32 B);
+//   split data  [channel][q][2][8] fp16: q-chunk q = samples 8q .. 8q+7 as 8 hi values then the 8 lo values times 2^11 (32 B);
 //               a window is ONE contiguous stream of 16-byte chunks.
 //   band image  [template][channel][4096 B]: the LDS image of the band, per plane (hi: bytes 0.., lo: 2048..)
 //               an EVEN copy E (dword n = elements 2n, 2n+1 of Br) and an ODD copy O (dword n = elements 2n+1,
@@ -100,12 +103,14 @@ __host__ __device__ inline float pow2f(int s)           // 2^s, |s| <= 126
     return v.f;
 }
 
-// x * 2^s -> (hi, lo) as two fp16 bit patterns
-__device__ __forceinline__ void split_one(float v, unsigned short& hi, unsigned short& lo)
+constexpr float LO_SCALE = 2048.0f;          // the data's lo halves are stored times 2^11 (see above)
+
+// x * 2^s -> (hi, lo * lo_scale) as two fp16 bit patterns (lo_scale: LO_SCALE for data, 1 for templates)
+__device__ __forceinline__ void split_one(float v, float lo_scale, unsigned short& hi, unsigned short& lo)
 {
     const _Float16 h = (_Float16)v;
     const float res = v - (float)h;                     // exact
-    const _Float16 l = (_Float16)res;
+    const _Float16 l = (_Float16)(res * lo_scale);      // (a power of two: exact)
     hi = __builtin_bit_cast(unsigned short, h);
     lo = __builtin_bit_cast(unsigned short, l);
 }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void sp_split_data_kernel(const float* __restr
     }
     unsigned short hi[8], lo[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) split_one(v[i] * sc, hi[i], lo[i]);
+    for (int i = 0; i < 8; ++i) split_one(v[i] * sc, LO_SCALE, hi[i], lo[i]);
     u32x4 oh, ol;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(64) void sp_band_kernel(const float* __restrict__ t
         const int l = i - BAND_LEAD - r;
         if (l < 0 || l >= L) return 0u;
         unsigned short hi, lo;
-        split_one(x[l] * sc, hi, lo);
+        split_one(x[l] * sc, 1.0f, hi, lo);
         return p ? lo : hi;
     };
     for (int w = lane; w < BAND_BYTES / 4; w += 64) {
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
     {                                                                                        \
         SP_WAIT(5); SP_SB;                                                                   \
         const f16x8 ah = sp_h8(f[cur].a[0][0], f[cur].a[0][1]);                              \
+        const f16x8 hs = ah * (_Float16)(1.0f / LO_SCALE);      /* for the product with the data's lo * 2^11 */ \
         SP_MFMA(acc[0], ah, sp_h8(f[cur].b[0][0]));                                          \
         SP_SB;                                                                               \
         SP_RD2(f[nxt].a[0][0], ap, (dw)); SP_RD2(f[nxt].a[0][1], ap, (dw) + 2);              \
@@ -397,11 +403,11 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
         SP_SB;                                                                               \
         SP_RD128(f[nxt].b[0][0], bp, (off)); SP_RD128(f[nxt].b[1][0], bp, (off) + 4608);     \
         SP_WAIT(7); SP_SB;                                                                   \
-        SP_MFMA(acc[0], ah, sp_h8(f[cur].b[0][1]));                                          \
+        SP_MFMA(acc[0], hs, sp_h8(f[cur].b[0][1]));                                          \
         SP_SB;                                                                               \
         SP_RD128(f[nxt].b[0][1], bp, (off) + 16); SP_RD128(f[nxt].b[1][1], bp, (off) + 4608 + 16); \
         SP_WAIT(8); SP_SB;                                                                   \
-        SP_MFMA(acc[1], ah, sp_h8(f[cur].b[1][1]));                                          \
+        SP_MFMA(acc[1], hs, sp_h8(f[cur].b[1][1]));                                          \
         SP_SB;                                                                               \
         SP_RD2(f[nxt].a[1][0], ap2, (dw)); SP_RD2(f[nxt].a[1][1], ap2, (dw) + 2);            \
         SP_WAIT(8); SP_SB;                                                                   \

@@ -213,3 +213,54 @@ def test_split16_configs0_in_full(oracle_lib, split16):
         lo, hi = max(0, i0 - 64), i0 + 65
         assert int(got[t, lo:hi].argmax()) == int(want[t, lo:hi].argmax())
     assert [int(r.argmax()) for r in got] == [int(r.argmax()) for r in want]
+
+
+def _fuzz_seeds(default):
+    import os
+    spec = os.environ.get("BPMF_FUZZ_SEEDS")
+    if not spec:
+        return range(default)
+    a, b = spec.split(":")
+    return range(int(a), int(b))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds(40))
+def test_fuzz_split16_random_shapes_signed_moveouts(oracle_lib, split16, seed):
+    """The generator of tests/test_gpu_fuzz.py::test_mf_random_shapes_signed_moveouts under mf.split16: moveouts of both
+    signs (first valid lags that are not multiples of 8: the remainder baked into the band image), template lengths on
+    both sides of every k-step boundary and of the 378-sample limit, steps, gaps, dead channels, series shorter than a
+    wave's 2048 lags, channels in wildly different units.  Bar: the tolerance, plus exact zeros exactly where the oracle has
+    them."""
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(17_000 + seed)
+    T = int(rng.integers(1, 7))
+    S = int(rng.integers(1, 5))
+    C = int(rng.integers(1, 4))
+    L = int(rng.choice([1, 3, 8, 9, 10, 16, 26, 27, 31, 48, 64, 100, 128, 200, 250, 251, 256, 257, 266, 267, 300, 378, 379, 400]))
+    N = int(L + rng.choice([0, 1, 2, 3, 5, 255, 1000, 2047, 2048, 2049, 8191, 8192, 8193, 9000, 20000]))
+    step = int(rng.choice([1, 1, 1, 1, 2, 3, 4, 7, 16, 17, 64]))
+    lo = -int(rng.choice([0, 1, 2, 3, 5, 7, 8, 9, 50, 255, 257, 1023, 1026, max(1, N // 2), N + 3]))
+    hi = int(rng.choice([0, 1, 2, 3, 7, 8, 100, 1025, max(1, N // 2), N + 3]))
+    tp = rng.standard_normal((T, S, C, L)).astype(np.float32)
+    data = rng.standard_normal((S, C, N)).astype(np.float32)
+    data *= (10.0 ** rng.uniform(-6, 4, (S, C, 1))).astype(np.float32)
+    tp *= (10.0 ** rng.uniform(-4, 3, (T, S, C, 1))).astype(np.float32)
+    if seed % 5 == 0:
+        a = int(rng.integers(0, max(1, N - 1)))
+        data[:, :, a:a + L + int(rng.integers(0, 2 * L + 2))] = 0.0
+    if seed % 9 == 0:
+        tp[0, 0] = 0.0
+    if seed % 4 == 0 and N > 10:
+        data[0, 0, int(rng.integers(0, N))] *= np.float32(3.0e4)          # a glitch
+    mv = rng.integers(lo, hi + 1, (T, S, C)).astype(np.int32)
+    w = rng.random((T, S, C)).astype(np.float32)
+    w[rng.random((T, S, C)) < 0.2] = 0.0
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, data, step, arch="gpu", network_sum=ns, check_zeros=False)
+        want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=ns)
+        what = f"seed {seed} ns={ns} (T={T} S={S} C={C} L={L} N={N} step={step} mv in [{lo},{hi}])"
+        assert got.shape == want.shape and np.isfinite(got).all(), what
+        assert np.array_equal(got == 0.0, want == 0.0), what + f": {((got == 0) != (want == 0)).sum()} exact zeros differ"
+        diff = np.abs(got.astype(np.float64) - want)
+        scale = 1.0 if not ns else np.maximum(np.abs(w).reshape(T, -1).sum(axis=1), 1e-30)[:, None]
+        assert (diff / scale).max(initial=0.0) <= TOL_CC, what + f": {(diff / scale).max():.3e}"
