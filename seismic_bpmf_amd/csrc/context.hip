@@ -321,6 +321,17 @@ hipError_t staged_upload_rows(DeviceContext* ctx, float* d_dst, const float* hos
                               size_t c1, hipStream_t stream)
 {
     if (c1 <= c0 || rows == 0) return hipSuccess;
+    // An array that is ALREADY page-locked (hipHostMalloc / hipHostRegister: a torch pinned tensor seen through
+    // NumPy) needs no staging: the DMA engine reads it where it lies.
+    {
+        hipPointerAttribute_t a0, a1;
+        const bool pinned_src = hipPointerGetAttributes(&a0, host) == hipSuccess && a0.type == hipMemoryTypeHost &&
+                                hipPointerGetAttributes(&a1, host + rows * N - 1) == hipSuccess && a1.type == hipMemoryTypeHost;
+        (void)hipGetLastError();          // (a pageable pointer makes the query fail: not an error of this call)
+        if (pinned_src)
+            return hipMemcpy2DAsync(d_dst + c0, N * sizeof(float), host + c0, N * sizeof(float), (c1 - c0) * sizeof(float), rows,
+                                    hipMemcpyHostToDevice, stream);
+    }
     const size_t cap = ctx->pinned_cap.load();
     // samples per pinned piece (whole rows' segments; a multiple of 1024 samples where the piece allows)
     size_t w = cap / (rows * sizeof(float));

@@ -417,6 +417,26 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
         SP_MFMA(acc[1], al, sp_h8(f[cur].b[1][0]));                                          \
         SP_SB;                                                                               \
     }
+// the odd last k-step: nothing behind it to read ahead for (R1..R8 outstanding on entry, none joins)
+#define SP_STEP_LAST(cur)                                                                    \
+    {                                                                                        \
+        SP_WAIT(5); SP_SB;                                                                   \
+        const f16x8 ah = sp_h8(f[cur].a[0][0], f[cur].a[0][1]);                              \
+        const f16x8 hs = ah * (_Float16)(1.0f / LO_SCALE);                                   \
+        SP_MFMA(acc[0], ah, sp_h8(f[cur].b[0][0]));                                          \
+        SP_WAIT(4); SP_SB;                                                                   \
+        SP_MFMA(acc[1], ah, sp_h8(f[cur].b[1][0]));                                          \
+        SP_WAIT(3); SP_SB;                                                                   \
+        SP_MFMA(acc[0], hs, sp_h8(f[cur].b[0][1]));                                          \
+        SP_WAIT(2); SP_SB;                                                                   \
+        SP_MFMA(acc[1], hs, sp_h8(f[cur].b[1][1]));                                          \
+        SP_WAIT(0); SP_SB;                                                                   \
+        const f16x8 al = sp_h8(f[cur].a[1][0], f[cur].a[1][1]);                              \
+        SP_MFMA(acc[0], al, sp_h8(f[cur].b[0][0]));                                          \
+        SP_SB;                                                                               \
+        SP_MFMA(acc[1], al, sp_h8(f[cur].b[1][0]));                                          \
+        SP_SB;                                                                               \
+    }
             SP_SB;
             if (prio & 1) __builtin_amdgcn_s_setprio(0);
             if ((prio & 2) && kprio) __builtin_amdgcn_s_setprio(2);
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
                 ap2 += 64;
                 bp += 144;
             }
-            if (nks & 1) { SP_STEP(0, 1, 8, 64); }
+            if (nks & 1) { SP_STEP_LAST(0); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             SP_SB;
             if (prio & 1) __builtin_amdgcn_s_setprio(1);
@@ -438,6 +458,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
 #undef SP_WAIT
 #undef SP_MFMA
 #undef SP_STEP
+#undef SP_STEP_LAST
 
 #pragma unroll
             for (int u = 0; u < NT; ++u) {

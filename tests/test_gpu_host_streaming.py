@@ -122,3 +122,36 @@ def test_pieces_on_several_virtual_devices(oracle_lib, hip_opts):
     mb, ma = beamform(f, tau, wp, ws, device="gpu")
     wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
     assert np.array_equal(mb, wb) and np.array_equal(ma, wa)
+
+
+def test_a_day_that_is_already_page_locked_is_not_staged(oracle_lib, hip_opts):
+    """Round 6: staged_upload_rows asks hipPointerGetAttributes first -- a page-locked source (a torch pinned tensor seen
+    through NumPy) goes to the device without the copy into the context's pinned pieces; same results, next to nothing in host_copy_ms."""
+    import torch
+    from seismic_bpmf_amd import _lib, beamform, matched_filter
+    rng = np.random.default_rng(4242)
+    S, C, N = 6, 3, 400_000
+    f_pin = torch.empty((S, C, N), dtype=torch.float32).pin_memory()
+    f_pin.copy_(torch.from_numpy(np.abs(rng.standard_normal((S, C, N))).astype(np.float32)))
+    f = f_pin.numpy()
+    tau = rng.integers(0, 300, (500, S, 2)).astype(np.int32)
+    wp = np.zeros((S, C, 2), np.float32)
+    wp[:, 0, 0] = 1.0
+    wp[:, 1:, 1] = 1.0
+    ws = (rng.random((500, S)) < 0.7).astype(np.float32)
+    hip_opts("bp.host_piece_samples", 131072)
+    b_pin, a_pin = beamform(f, tau, wp, ws, device="gpu", device_id=[0])
+    st = _lib.host_call_stats()
+    assert st["host_copy_ms"] < 0.05, st             # (only the few hundred bytes of weights_phases were staged)
+    b_page, a_page = beamform(f.copy(), tau, wp, ws, device="gpu", device_id=[0])
+    assert _lib.host_call_stats()["host_copy_ms"] > 0.2
+    wb, wa = oracle_lib.beamform(f, tau, wp, ws, "strict", "max")
+    assert np.array_equal(b_pin, wb) and np.array_equal(a_pin, wa)
+    assert np.array_equal(b_page, wb) and np.array_equal(a_page, wa)
+    d_pin = torch.empty((4, 3, 300_000), dtype=torch.float32).pin_memory()
+    d_pin.copy_(torch.from_numpy(rng.standard_normal((4, 3, 300_000)).astype(np.float32)))
+    tp = rng.standard_normal((3, 4, 3, 64)).astype(np.float32)
+    mv = rng.integers(0, 200, (3, 4, 3)).astype(np.int32)
+    w = rng.random((3, 4, 3)).astype(np.float32)
+    got = matched_filter(tp, mv, w, d_pin.numpy(), 1, check_zeros=False, device=[0])
+    assert np.array_equal(got, oracle_lib.matched_filter(tp, mv, w, d_pin.numpy(), 1))

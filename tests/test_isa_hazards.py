@@ -168,3 +168,40 @@ def test_mf_kernels_touch_no_register_in_flight(tmp_path):
         stored = sum(2 if t.startswith("ds_write2") else 1 for t in kernels[kn] if t.startswith("ds_write"))
         assert stored == n_writes, (kn, stored)       # (the compiler pairs some into ds_write2st64_b32)
         assert not any("scratch_" in t for t in kernels[kn])
+
+
+@pytest.mark.timeout(900)
+def test_split_kernel_touches_no_register_in_flight(tmp_path):
+    """mf_split.hip (option mf.split16, round 6): operands by inline-asm ds_read2_b32 / ds_read_b128 behind counted
+    lgkmcnt(5 / 6 / 7 / 8 / 8) waits, one k-step ahead.  Every instantiation: no register touched while its read is in
+    flight, nothing in scratch, at most 256 VGPRs (two waves per SIMD), 12 MFMAs per unrolled pair of k-steps + 6 in
+    the odd tail."""
+    import re
+    from seismic_bpmf_amd.build import ARCH, CSRC, find_hipcc
+    out = tmp_path / "mf_split.s"
+    cmd = [find_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+           "--cuda-device-only", "-o", str(out), os.path.join(CSRC, "mf_split.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = out.read_text()
+    kernels = check_inflight.split_kernels(text)
+    names = [n for n in kernels if "mf_split_kernel" in n]
+    assert len(names) == 4                       # network sum x step 1
+    for n in names:
+        body = kernels[n]
+        assert sum(t.startswith("v_mfma_f32_32x32x16_f16") for t in body) == 18
+        assert sum(t.startswith("ds_read_b128") for t in body) == 12 and sum(t.startswith("ds_read2_b32") for t in body) == 12
+        # the network-sum variants (the hot ones) keep everything in registers; the per-channel-output variants (the
+        # inter-template CC: tiny problems) spill a few address registers around their scattered stores
+        if "mf_split_kernelILb1E" in n:
+            assert not any("scratch_" in t for t in body)
+        bad = check_inflight.check_kernel(body)
+        assert not bad, f"{n}: {bad[:4]}"
+    meta = text[text.index("amdhsa.kernels"):]
+    for b in meta.split("  - .agpr_count")[1:]:
+        if "mf_split_kernel" in b:
+            assert int(re.search(r"\.vgpr_count:\s+(\d+)", b).group(1)) <= 256
+            if "mf_split_kernelILb1E" in b:
+                assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", b).group(1)) == 0
+            else:
+                assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", b).group(1)) <= 128
