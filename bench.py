@@ -265,7 +265,9 @@ def cpu_baseline(cfg, target_seconds):
         lib = oracle.load()
         march = "x86-64-v3"
     facts = host_cpu_facts()
-    cores = max(1, min(lib.bpmf_oracle_max_threads(), facts["usable_cpus"]))
+    # (the CPUs the process may use; NOT omp_get_max_threads(): a launcher exports OMP_NUM_THREADS=1 to its ranks, and an earlier
+    # one-thread timing leaves the runtime at 1 -- the oracle is told its thread count on every call)
+    cores = max(1, facts["usable_cpus"])
     S, C, L = cfg["S"], cfg["C"], cfg["L"]
 
     def run(inp, nth):
@@ -347,7 +349,9 @@ def cpu_baseline_bp(bcfg, geo, target_seconds):
         lib = oracle.load()
         march = "x86-64-v3"
     facts = host_cpu_facts()
-    cores = max(1, min(lib.bpmf_oracle_max_threads(), facts["usable_cpus"]))
+    # (the CPUs the process may use; NOT omp_get_max_threads(): a launcher exports OMP_NUM_THREADS=1 to its ranks, and an earlier
+    # one-thread timing leaves the runtime at 1 -- the oracle is told its thread count on every call)
+    cores = max(1, facts["usable_cpus"])
     S, C, P = bcfg["S"], bcfg["C"], bcfg["P"]
     K = min(geo["moveouts"].shape[0], 2000)
     mv, ws = geo["moveouts"][:K], geo["weights_sources"][:K]
@@ -1097,7 +1101,7 @@ def main():
                     raise SystemExit(f"bench: dense BP result of {name} differs from the bp_direct reference window")
                 dbf.close()
                 del dbeam, darg, rb, ra
-        if rank == 0 and world == 1 and not args.skip_cpu:
+        if rank == 0 and dist is None and not args.skip_cpu:
             bp_obj["cpu_baseline"] = cpu_baseline_bp(bcfg, geo, max(2.0, args.cpu_seconds / 3))
 
     # ---------------------------------------------------------------- N > 1: shares of configs[3] / [4]
@@ -1197,7 +1201,7 @@ def main():
             torch.cuda.empty_cache()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.skip_cpu:
+    if rank == 0 and dist is None and not args.skip_cpu:
         cpu = cpu_baseline(cfg, args.cpu_seconds)
     # every rank's own step time, kernel time and roofline fraction into `ranks` (a straggler GPU -- the boxes of
     # one pool differ by +-5 % -- is then visible in a weak-scaling ratio)
@@ -1241,7 +1245,8 @@ def main():
         dist.destroy_process_group()
     # N > 1: the CPU baseline AFTER the process group is gone -- the other ranks have exited (a rank waiting in a
     # collective spins on a host core, and the cgroup grants 16), rank 0 times the oracle alone, exactly as at N = 1
-    if line is not None and world > 1 and not args.skip_cpu:
+    # (taken whenever a process group was initialised -- BPMF_BENCH_FORCE_DIST=1 runs it with one rank on a one-GPU box)
+    if line is not None and dist is not None and not args.skip_cpu:
         try:
             del data, tmpl, mv, w
         except Exception:
