@@ -760,6 +760,20 @@ def main():
                         "the day arriving in pieces while the first two template batches run)",
                "breakdown_of_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in mf_stats.items()},
                "row0_peak_cc": round(float(h_cc[0].max()), 4)}
+        # the same drop-in call under option mf.split16 (untimed extra of the untimed extra: one call, the day uploaded in one
+        # piece -- a channel's scale is its maximum over the whole day -- then the split kernel; never `value`)
+        try:
+            h_cc = None                      # (one 17 GB result array at a time)
+            with _lib.options(**{"mf.split16": 1}):
+                h_new = h_d.copy()
+                t0 = time.perf_counter()
+                h_cc = sb.matched_filter(h_t, h_mv, h_w, h_new, 1, arch="gpu", check_zeros=False, device=[local_rank])
+                e2e["mf_split16_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+                e2e["mf_split16_breakdown"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in _lib.host_call_stats().items()}
+                e2e["mf_split16_row0_peak_cc"] = round(float(h_cc[0].max()), 4)
+                del h_new
+        except Exception as e:                      # (an extra must not cost the line)
+            e2e["mf_split16_ms"] = f"failed: {e}"
         del h_cc, h_t, h_mv, h_w, h_d
 
     # untimed extras: the matched filter off its headline shape -- BASELINE
