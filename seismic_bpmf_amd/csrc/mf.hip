@@ -17,6 +17,8 @@
 #include <thread>
 #include <chrono>
 #include <vector>
+#include <mutex>
+#include <utility>
 #include <cstring>
 #include <algorithm>
 #include "../../include/bpmf_hip.h"
@@ -1195,6 +1197,30 @@ static int mf_check_sizes(size_t step, size_t L, size_t N, size_t T, size_t S, s
 thread_local long long t_mf_off_lo = 0, t_mf_off_hi = -1;
 thread_local bool t_mf_continue = false;
 
+// Which workspaces hold a day that was prepared WITH its fp16 split (option mf.split16): a caller of the *_dev entry
+// points that prepares a day with the option off and runs with it on (BPMF_MF_DATA_PREPARED) would otherwise correlate
+// whatever the split region holds.  Keyed by the workspace's base address; bpmf_mf_prepare_data_dev sets / clears it.
+static std::mutex g_split_days_mutex;
+struct SplitDay { const void* data; size_t N, n_ch; };
+static std::vector<std::pair<const void*, SplitDay>> g_split_days;
+static void split_day_note(const void* ws_base, const void* data, size_t N, size_t n_ch, bool with_split)
+{
+    std::lock_guard<std::mutex> g(g_split_days_mutex);
+    for (size_t i = 0; i < g_split_days.size(); ++i)
+        if (g_split_days[i].first == ws_base) { g_split_days.erase(g_split_days.begin() + i); break; }
+    if (with_split) {
+        if (g_split_days.size() >= 64) g_split_days.erase(g_split_days.begin());
+        g_split_days.push_back({ws_base, {data, N, n_ch}});
+    }
+}
+static bool split_day_known(const void* ws_base, const void* data, size_t N, size_t n_ch)
+{
+    std::lock_guard<std::mutex> g(g_split_days_mutex);
+    for (auto& e : g_split_days)
+        if (e.first == ws_base) return e.second.data == data && e.second.N == N && e.second.n_ch == n_ch;
+    return false;
+}
+
 // the launch of bpmf_mf_run_dev takes the MFMA kernels (which can be restricted to a range of lag blocks)
 static bool mf_uses_mfma(size_t step, size_t L, size_t N, size_t T, size_t n_corr, int network_sum, int flags)
 {
@@ -1282,7 +1308,9 @@ extern "C" int bpmf_mf_prepare_data_dev(const float* d_data, size_t L, size_t N,
         return rc;
     }
     // option mf.split16: the day as fp16 (hi, lo) pairs, each channel scaled by a power of two (mf_split.h)
-    if (ws.sp_day && sp::usable(L, N)) return sp::prepare_day(d_data, N, n_ch, ws.sp_day, stream);
+    const bool with_split = ws.sp_day && sp::usable(L, N);
+    split_day_note(d_workspace, d_data, N, n_ch, with_split);
+    if (with_split) return sp::prepare_day(d_data, N, n_ch, ws.sp_day, stream);
     return 0;
 }
 
@@ -1339,6 +1367,11 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N) && !sqrt_norm;
     if (split16 && ranged) {
         set_error("bpmf_mf_run_dev: internal error: a range of lag blocks under mf.split16");
+        return -1;
+    }
+    if (split16 && !split_day_known(d_workspace, d_data, N, n_ch)) {
+        set_error("bpmf_mf_run_dev: option mf.split16 is on but the day in this workspace was prepared without it (or is "
+                  "another day): call bpmf_mf_prepare_data_dev again, or drop BPMF_MF_DATA_PREPARED");
         return -1;
     }
     const bool wave_kernel = !split16 && use_mfma && option(OPT_MF_WAVE_KERNEL) != 0 && mf_kpad((int)L) <= 272;

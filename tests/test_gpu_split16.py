@@ -264,3 +264,42 @@ def test_fuzz_split16_random_shapes_signed_moveouts(oracle_lib, split16, seed):
         diff = np.abs(got.astype(np.float64) - want)
         scale = 1.0 if not ns else np.maximum(np.abs(w).reshape(T, -1).sum(axis=1), 1e-30)[:, None]
         assert (diff / scale).max(initial=0.0) <= TOL_CC, what + f": {(diff / scale).max():.3e}"
+
+
+def test_split16_refuses_a_day_that_was_prepared_without_it(hip_opts):
+    """A caller of the *_dev entry points who prepares a day with the option off and then runs with it on (flag
+    BPMF_MF_DATA_PREPARED) must get an error, not the correlation of whatever the split region holds."""
+    from seismic_bpmf_amd import _lib
+    from seismic_bpmf_amd.matched_filter import MatchedFilterGPU
+    rng = np.random.default_rng(3)
+    tp, mv, w, d = _case(rng, 2, 3, 3, 64, 30_000, 0, 100, scales=False)
+    eng = MatchedFilterGPU()
+    eng.set_data(d)
+    hip_opts("mf.split16", 1)
+    eng.run(tp, mv, w)                               # sizes the workspace for the option and prepares WITH the split
+    hip_opts("mf.split16", 0)
+    eng.run(tp, mv, w)                               # prepared again, without it
+    hip_opts("mf.split16", 1)
+    key = list(eng._prepared_for)
+    key[-1] = 1                                      # pretend the prepared state matched the option
+    eng._prepared_for = tuple(key)
+    with pytest.raises(_lib.BpmfHipError, match="prepared without it"):
+        eng.run(tp, mv, w)
+    eng._prepared_for = None
+    eng.run(tp, mv, w)                               # prepares, runs
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_split16_on_several_devices_equals_one_device(oracle_lib, split16, k):
+    """bpmf_mf_run_multi under the option (templates block-partitioned over k logical devices, the day handed on device
+    to device): every device prepares its own split of the day; the rows equal the one-device call's bit for bit (the
+    same kernel on the same template) and lie within the tolerance of the oracle."""
+    from seismic_bpmf_amd import _lib, matched_filter
+    rng = np.random.default_rng(50 + k)
+    tp, mv, w, d = _case(rng, 7, 4, 3, 200, 50_000, -20, 600)
+    one = matched_filter(tp, mv, w, d, 1, check_zeros=False, device=0)
+    split16("debug.virtual_devices", k)
+    multi = matched_filter(tp, mv, w, d, 1, check_zeros=False, device=None)
+    assert np.array_equal(multi, one)
+    _check(multi, oracle_lib.matched_filter(tp, mv, w, d, 1, True), w, f"split16 on {k} devices")
+    _lib.release_device_memory(-1)
