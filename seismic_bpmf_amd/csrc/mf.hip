@@ -1162,7 +1162,7 @@ static MfWorkspace mf_carve(void* base, size_t L, size_t N, size_t T, size_t n_c
     ws.e_t = (float*)(p + o);    o += align_up(T * n_ch * sizeof(float), 256);
     ws.range = (int2*)(p + o);   o += align_up(T * sizeof(int2), 256);
     ws.chan_rec = (int4*)(p + o); o += align_up(T * (n_ch + 2) * sizeof(int4), 256);
-    if (split16) { ws.sp_batch = p + o; o += align_up(sp::batch_region_bytes(T, n_ch), 256); }
+    if (split16) { ws.sp_batch = p + o; o += align_up(sp::batch_region_bytes(T, n_ch, L), 256); }
     ws.bytes = o;
     return ws;
 }
@@ -1363,7 +1363,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     if (off_hi <= off_lo) return 0;
     const bool first_piece = !(ranged && t_mf_continue);
     // option mf.split16: the split-precision kernel takes every launch the MFMA kernels would take for templates of
-    // at most 378 samples (not under mf.compat_sqrt_norm: its norm arrays hold energies)
+    // whatever length (in segments of at most 376 samples; not under mf.compat_sqrt_norm: its norm arrays hold energies)
     const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N) && !sqrt_norm;
     if (split16 && ranged) {
         set_error("bpmf_mf_run_dev: internal error: a range of lag blocks under mf.split16");

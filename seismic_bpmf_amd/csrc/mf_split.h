@@ -76,7 +76,17 @@ constexpr int S_CLAMP = 100;
 constexpr float SP_MAX_NORM = 1000.0f;      // = MAX_NORM of common.h: r_t * r_d >= this -> CC = 0
 
 __host__ __device__ inline int nks_of(int L) { return (L + 38 + 15) / 16; }
-__host__ __device__ inline int max_template_len() { return 16 * MAX_KS - 38; }   // 378
+__host__ __device__ inline int max_segment_len() { return (16 * MAX_KS - 38) / 8 * 8; }   // 376: what one band image holds
+// Templates longer than a band image are correlated in SEGMENTS of equal length (a multiple of 8 samples, so that every
+// segment's window keeps the remainder r of its channel): n_seg K loops per channel into the same accumulators, the
+// window and the band image re-staged per segment, the epilogue behind the last one.
+__host__ __device__ inline int n_segments_of(int L) { return (L + max_segment_len() - 1) / max_segment_len(); }
+__host__ __device__ inline int segment_len_of(int L)
+{
+    const int n = n_segments_of(L);
+    return ((L + n - 1) / n + 7) / 8 * 8;
+}
+__host__ __device__ inline int max_template_len() { return 4096; }
 __host__ __device__ inline int band_e_dwords(int nks) { return 8 * nks + 32; }
 // first dword index >= the length of E that is 17 (mod 32)
 __host__ __device__ inline int band_o_off(int nks)
@@ -173,11 +183,13 @@ __global__ __launch_bounds__(256) void sp_split_data_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ per-template preparation
-// One wave per (template, channel): the 4 KB band image and sct[t, ch] = 2^-s.
+// One wave per (template, channel, segment): the 4 KB band image and sct[t, ch] = 2^-s (one scale per template channel).
 __global__ __launch_bounds__(64) void sp_band_kernel(const float* __restrict__ tmpl, const int* __restrict__ mv,
-                                                     int L, unsigned* __restrict__ bands, float* __restrict__ sct)
+                                                     int L, int n_seg, int seg_len, unsigned* __restrict__ bands,
+                                                     float* __restrict__ sct)
 {
-    const size_t tc = blockIdx.x;
+    const size_t tc = blockIdx.x / (unsigned)n_seg;
+    const int seg = (int)(blockIdx.x % (unsigned)n_seg);
     const int lane = threadIdx.x;
     const float* x = tmpl + tc * (size_t)L;
     unsigned m = 0;
@@ -186,16 +198,17 @@ __global__ __launch_bounds__(64) void sp_band_kernel(const float* __restrict__ t
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     const int s = scale_exp_of(m);
     const float sc = pow2f(s);
-    if (lane == 0) sct[tc] = pow2f(-s);
+    if (lane == 0 && seg == 0) sct[tc] = pow2f(-s);
     const int mvc = mv[tc];
     const int r = ((mvc % 8) + 8) % 8;
-    const int nks = nks_of(L);
+    const int nks = nks_of(seg_len);
     const int e_d = band_e_dwords(nks), o_off = band_o_off(nks);
-    unsigned* img = bands + tc * (BAND_BYTES / 4);
-    // element i of Br (zero outside the template), plane p
+    unsigned* img = bands + (size_t)blockIdx.x * (BAND_BYTES / 4);
+    // element i of this segment's Br (zero outside the segment / the template), plane p
     auto elem = [&](int i, int p) -> unsigned {
-        const int l = i - BAND_LEAD - r;
-        if (l < 0 || l >= L) return 0u;
+        const int ls = i - BAND_LEAD - r;
+        const int l = seg * seg_len + ls;
+        if (ls < 0 || ls >= seg_len || l >= L) return 0u;
         unsigned short hi, lo;
         split_one(x[l] * sc, 1.0f, hi, lo);
         return p ? lo : hi;
@@ -249,12 +262,13 @@ __device__ __forceinline__ f16x8 sp_h8(i32x4 v) { return __builtin_bit_cast(f16x
 // cc = (num * 2^-s_t * 2^-s_d) * (r_t * r_d) where r_t * r_d < 1000, else 0; sum = fmaf(w, cc, sum).
 // ABLATE (tools/ubench/mfma_split16.hip only; the library instantiates 0): 1 = no norms / scaling in the epilogue,
 // 2 = also no staging (the K loop alone, on whatever the LDS holds)
-template <bool NETWORK_SUM, bool STEP1, int ABLATE = 0>
+// SEGMENTED: templates of more than one segment (n_seg > 1); false folds the segment logic away
+template <bool NETWORK_SUM, bool STEP1, int ABLATE = 0, bool SEGMENTED = false>
 __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
     const u32x4* __restrict__ sdata, const unsigned* __restrict__ bands, const float* __restrict__ sct,
     const float* __restrict__ scd, const int4* __restrict__ chan_rec, const float* __restrict__ e_d,
     const int2* __restrict__ range, int L, long long N, int T, int n_ch, long long n_corr, int step,
-    float* __restrict__ out, int n_lag_blocks, int lag_block0, int prio)
+    float* __restrict__ out, int n_lag_blocks, int lag_block0, int prio, int n_seg, int seg_len)
 {
     extern __shared__ __attribute__((aligned(16))) char sp_smem[];
     const int tid = threadIdx.x;
@@ -262,7 +276,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 31;          // tile column (B operand) / band row (A operand)
     const int g = lane >> 5;          // k group of the operands / row group of the results
-    const int nks = nks_of(L);
+    const int nks = nks_of(seg_len);
     // prio bit 1 (experiment): every other workgroup runs its K loops at a raised issue priority
     const bool kprio = (((blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 1u) != 0;
 
@@ -300,10 +314,11 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
         const int4* __restrict__ recs = chan_rec + (size_t)t * (n_ch + 2);
 
         u32x4 rd[W_LOADS], rt[B_LOADS];
-        auto issue_stage = [&](int ch, int mvc) {
+        auto issue_stage = [&](int ch, int mvc, int sg) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((const char*)sdata + (size_t)ch * row_bytes), 0, (int)row_bytes, 0x00020000);
-            const long long q0 = (lag0 >> 3) + (long long)(mvc >> 3);      // floor((lag0 + mvc) / 8): lag0 % 8 == 0
+            // floor((lag0 + mvc + sg * seg_len) / 8): lag0 and seg_len are multiples of 8
+            const long long q0 = (lag0 >> 3) + (long long)(mvc >> 3) + (long long)sg * (seg_len >> 3);
             const unsigned o = (unsigned)(q0 * 32 + 16 * lane);           // wraps like the hardware's offset
             if (q0 >= 0) {
 #pragma unroll
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
                     oo += 1024u;
                 }
             }
-            const u32x4* bi = (const u32x4*)(bands + ((size_t)t * n_ch + ch) * (BAND_BYTES / 4)) + lane;
+            const u32x4* bi = (const u32x4*)(bands + (((size_t)t * n_ch + ch) * n_seg + sg) * (BAND_BYTES / 4)) + lane;
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) rt[i] = bi[64 * i];
         };
@@ -333,10 +348,13 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
 
         int4 rec = recs[0];
         int4 rec1 = recs[1];
-        int ri = 0;
-        if (ABLATE < 2 && rec.x >= 0) issue_stage(rec.x, rec.y);
+        int ri = 0, seg = 0;
+        f32x16 acc[NT];
+        f32x4 ed[NT][4];
+        if (ABLATE < 2 && rec.x >= 0) issue_stage(rec.x, rec.y, 0);
         while (rec.x >= 0) {
             const int ch = rec.x;
+            const bool last_seg = !SEGMENTED || seg == n_seg - 1;
             if constexpr (ABLATE < 2) write_stage();
             const float w = __int_as_float(rec.z);
             const int mvc = rec.y;
@@ -345,8 +363,9 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
             const float s_d = scd[ch];
             const int4 rec2 = recs[ri + 2];
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
-            f32x4 ed[NT][4];
-            if constexpr (ABLATE >= 1) {
+            // (the window norms are needed behind the channel's LAST segment only)
+            if (!last_seg) {
+            } else if constexpr (ABLATE >= 1) {
 #pragma unroll
                 for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -366,13 +385,18 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
                         else ed[u][i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                     }
             }
-            if (ABLATE < 2 && rec1.x >= 0) issue_stage(rec1.x, rec1.y);
+            // the next thing to correlate: this channel's next segment, or the next channel's first
+            if constexpr (ABLATE < 2) {
+                if (!last_seg) issue_stage(rec.x, rec.y, seg + 1);
+                else if (rec1.x >= 0) issue_stage(rec1.x, rec1.y, 0);
+            }
 
-            f32x16 acc[NT];
+            if (!SEGMENTED || seg == 0) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u)
+                for (int u = 0; u < NT; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+            }
 
             unsigned ap = a_rd, ap2 = a_rd + BAND_PLANE, bp = b_rd;
             Frags f[2];
@@ -460,6 +484,11 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
 #undef SP_STEP
 #undef SP_STEP_LAST
 
+            if (!last_seg) {            // more of this template channel to come: the accumulators go on
+                ++seg;
+                continue;
+            }
+            seg = 0;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
 #pragma unroll

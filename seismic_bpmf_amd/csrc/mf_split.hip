@@ -29,9 +29,10 @@ size_t day_region_bytes(size_t N, size_t n_ch)
     return align_up(n_ch * split_row_bytes(N), 256) + 3 * align_up(n_ch * 4, 256);
 }
 
-size_t batch_region_bytes(size_t T, size_t n_ch)
+size_t batch_region_bytes(size_t T, size_t n_ch, size_t L)
 {
-    return align_up(T * n_ch * (size_t)BAND_BYTES, 256) + align_up(T * n_ch * sizeof(float), 256);
+    const size_t n_seg = L ? (size_t)n_segments_of((int)std::min<size_t>(L, (size_t)max_template_len())) : 1;
+    return align_up(T * n_ch * n_seg * (size_t)BAND_BYTES, 256) + align_up(T * n_ch * sizeof(float), 256);
 }
 
 bool usable(size_t L, size_t N)
@@ -65,28 +66,33 @@ int run(const float* d_templates, const int32_t* d_moveouts, const void* day_reg
         hipStream_t stream)
 {
     const DayRegion r = carve_day(const_cast<void*>(day_region), N, n_ch);
+    const int n_seg = n_segments_of((int)L), seg_len = segment_len_of((int)L);
     unsigned* bands = (unsigned*)batch_region;
-    float* sct = (float*)((char*)batch_region + align_up(T * n_ch * (size_t)BAND_BYTES, 256));
-    if (T * n_ch >= 0x7fffffffull || T * (nb_cnt + 8) >= 0x7fffffffull) {
+    float* sct = (float*)((char*)batch_region + align_up(T * n_ch * (size_t)n_seg * (size_t)BAND_BYTES, 256));
+    if (T * n_ch * (size_t)n_seg >= 0x7fffffffull || T * (nb_cnt + 8) >= 0x7fffffffull) {
         set_error("mf.split16: grid too large");
         return -1;
     }
-    sp_band_kernel<<<dim3((unsigned)(T * n_ch)), dim3(64), 0, stream>>>(d_templates, d_moveouts, (int)L, bands, sct);
+    sp_band_kernel<<<dim3((unsigned)(T * n_ch * (size_t)n_seg)), dim3(64), 0, stream>>>(d_templates, d_moveouts, (int)L, n_seg,
+                                                                                      seg_len, bands, sct);
     BPMF_LAUNCH_CHECK();
     const dim3 grid((unsigned)(8 * ((T * nb_cnt + 7) / 8)));
 #define BPMF_SP_LAUNCH(NS, S1)                                                                                       \
+    do { if (n_seg > 1) BPMF_SP_LAUNCH2(NS, S1, true); else BPMF_SP_LAUNCH2(NS, S1, false); } while (0)
+#define BPMF_SP_LAUNCH2(NS, S1, SG)                                                                                  \
     do {                                                                                                             \
-        auto kfn = mf_split_kernel<NS, S1, 0>;                                                                       \
+        auto kfn = mf_split_kernel<NS, S1, 0, SG>;                                                                   \
         /* (62 464 bytes of dynamic LDS: below the 64 KB that need no opt-in) */                                     \
         kfn<<<grid, dim3(THREADS), WG_LDS, stream>>>(r.planes, bands, sct, r.scd, chan_rec, e_d, range, (int)L,      \
                                                      (long long)N, (int)T, (int)n_ch, (long long)n_corr, (int)step,   \
-                                                     d_cc_out, (int)nb_cnt, (int)nb_lo, 0);                           \
+                                                     d_cc_out, (int)nb_cnt, (int)nb_lo, 0, n_seg, seg_len);           \
     } while (0)
     if (network_sum && step == 1) BPMF_SP_LAUNCH(true, true);
     else if (network_sum) BPMF_SP_LAUNCH(true, false);
     else if (step == 1) BPMF_SP_LAUNCH(false, true);
     else BPMF_SP_LAUNCH(false, false);
 #undef BPMF_SP_LAUNCH
+#undef BPMF_SP_LAUNCH2
     BPMF_LAUNCH_CHECK();
     return 0;
 }

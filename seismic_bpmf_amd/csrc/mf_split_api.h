@@ -8,11 +8,11 @@ namespace sp {
 
 // The per-day region (behind the window norms, in front of everything that depends on the template count):
 // the split data [n_ch][ceil(N / 8)][2][8] fp16, the channel maxima, scale exponents and 2^-s.
-// The per-batch region (at the end): the band images [T][n_ch][4096 B] and 2^-s of every template channel.
+// The per-batch region (at the end): the band images [T][n_ch][segments][4096 B] and 2^-s of every template channel.
 size_t day_region_bytes(size_t N, size_t n_ch);
-size_t batch_region_bytes(size_t T, size_t n_ch);
+size_t batch_region_bytes(size_t T, size_t n_ch, size_t L);
 
-// can this launch take the split kernel?  (L + 38 <= 416, any step the MFMA kernels take, N < 2^30 - 8192)
+// can this launch take the split kernel?  (templates of up to 4096 samples, in segments of at most 376; N < 2^30 - 8192)
 bool usable(size_t L, size_t N);
 
 // once per day, behind bpmf_mf_prepare_data_dev's own kernels: channel maxima -> scales -> split planes

@@ -190,14 +190,27 @@ def test_split16_resident_engine_reuses_the_prepared_day(oracle_lib, split16):
     torch.cuda.synchronize()
 
 
-def test_split16_long_templates_fall_back_to_the_exact_kernels(oracle_lib, split16):
-    """L > 378 does not fit the split kernel's band: the exact-fp32 kernels answer, bit for bit."""
+@pytest.mark.parametrize("L,N", [(379, 20_000), (400, 30_000), (752, 25_000), (753, 25_000), (1040, 30_000), (2040, 40_000)])
+def test_split16_long_templates_in_segments(oracle_lib, split16, L, N):
+    """Templates longer than one band image (376 samples) are correlated in equal segments into the same accumulators
+    (2 .. 6 segments here, lengths on both sides of a segment boundary); beyond 2065 samples -- the limit of every MFMA
+    kernel -- the generic exact kernel answers, bit for bit."""
     from seismic_bpmf_amd import matched_filter
-    rng = np.random.default_rng(31)
-    tp, mv, w, d = _case(rng, 2, 3, 3, 400, 30_000, 0, 100, scales=False)
+    rng = np.random.default_rng(31 + L)
+    tp, mv, w, d = _case(rng, 2, 3, 3, L, N, -40, 300)
+    for ns in (True, False):
+        got = matched_filter(tp, mv, w, d, 1, check_zeros=False, network_sum=ns)
+        want = oracle_lib.matched_filter(tp, mv, w, d, 1, ns)
+        assert not np.array_equal(got, want)                 # (the split kernel ran)
+        _check(got, want, w, f"split16 L={L} ns={ns}", per_channel=not ns)
+
+
+def test_split16_templates_beyond_every_mfma_kernel_take_the_exact_generic_kernel(oracle_lib, split16):
+    from seismic_bpmf_amd import matched_filter
+    rng = np.random.default_rng(32)
+    tp, mv, w, d = _case(rng, 2, 2, 2, 2100, 9000, 0, 50, scales=False)
     got = matched_filter(tp, mv, w, d, 1, check_zeros=False)
-    want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
-    assert np.array_equal(got, want)
+    assert np.array_equal(got, oracle_lib.matched_filter(tp, mv, w, d, 1, True))
 
 
 def test_split16_configs0_in_full(oracle_lib, split16):
@@ -228,7 +241,7 @@ def _fuzz_seeds(default):
 def test_fuzz_split16_random_shapes_signed_moveouts(oracle_lib, split16, seed):
     """The generator of tests/test_gpu_fuzz.py::test_mf_random_shapes_signed_moveouts under mf.split16: moveouts of both
     signs (first valid lags that are not multiples of 8: the remainder baked into the band image), template lengths on
-    both sides of every k-step boundary and of the 378-sample limit, steps, gaps, dead channels, series shorter than a
+    both sides of every k-step boundary and of the segment boundaries (376, 752), steps, gaps, dead channels, series shorter than a
     wave's 2048 lags, channels in wildly different units.  Bar: the tolerance, plus exact zeros exactly where the oracle has
     them."""
     from seismic_bpmf_amd import matched_filter
@@ -236,7 +249,7 @@ def test_fuzz_split16_random_shapes_signed_moveouts(oracle_lib, split16, seed):
     T = int(rng.integers(1, 7))
     S = int(rng.integers(1, 5))
     C = int(rng.integers(1, 4))
-    L = int(rng.choice([1, 3, 8, 9, 10, 16, 26, 27, 31, 48, 64, 100, 128, 200, 250, 251, 256, 257, 266, 267, 300, 378, 379, 400]))
+    L = int(rng.choice([1, 3, 8, 9, 10, 16, 26, 27, 31, 48, 64, 100, 128, 200, 250, 251, 256, 257, 266, 267, 300, 376, 377, 378, 379, 400, 752, 753, 1100]))
     N = int(L + rng.choice([0, 1, 2, 3, 5, 255, 1000, 2047, 2048, 2049, 8191, 8192, 8193, 9000, 20000]))
     step = int(rng.choice([1, 1, 1, 1, 2, 3, 4, 7, 16, 17, 64]))
     lo = -int(rng.choice([0, 1, 2, 3, 5, 7, 8, 9, 50, 255, 257, 1023, 1026, max(1, N // 2), N + 3]))

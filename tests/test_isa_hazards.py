@@ -186,7 +186,7 @@ def test_split_kernel_touches_no_register_in_flight(tmp_path):
     text = out.read_text()
     kernels = check_inflight.split_kernels(text)
     names = [n for n in kernels if "mf_split_kernel" in n]
-    assert len(names) == 4                       # network sum x step 1
+    assert len(names) == 8                       # network sum x step 1 x segmented templates
     for n in names:
         body = kernels[n]
         assert sum(t.startswith("v_mfma_f32_32x32x16_f16") for t in body) == 18

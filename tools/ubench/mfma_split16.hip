@@ -49,7 +49,8 @@ int main(int argc, char** argv)
     const int max_mv = 3000;
     const long long n_corr = N - L + 1, nwin = n_corr;
     if (L > max_template_len()) { fprintf(stderr, "L too long\n"); return 1; }
-    printf("split16 ubench: T %d, channels %d, L %d, N %lld, k-steps %d\n", T, n_ch, L, N, nks_of(L));
+    const int n_seg = n_segments_of(L), seg_len = segment_len_of(L);
+    printf("split16 ubench: T %d, channels %d, L %d, N %lld, k-steps %d\n", T, n_ch, L, N, nks_of(seg_len) * n_seg);
 
     {
         float* d_o; float h = -1.0f;
@@ -142,7 +143,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&d_sexp, n_ch * 4));
     CK(hipMalloc(&d_max, n_ch * 4));
     CK(hipMalloc(&d_mv, mv.size() * 4));
-    CK(hipMalloc(&d_bands, (size_t)T * n_ch * BAND_BYTES));
+    CK(hipMalloc(&d_bands, (size_t)T * n_ch * n_seg * BAND_BYTES));
     CK(hipMalloc(&d_split, (size_t)n_ch * NQ * 32));
     CK(hipMalloc(&d_rec, rec.size() * sizeof(int4)));
     CK(hipMalloc(&d_range, range.size() * sizeof(int2)));
@@ -169,7 +170,7 @@ int main(int argc, char** argv)
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("split of the day (%d x %lld samples): %.3f ms\n", n_ch, N, ms);
     CK(hipEventRecord(e0));
-    sp_band_kernel<<<T * n_ch, 64>>>(d_tmpl, d_mv, L, d_bands, d_sct);
+    sp_band_kernel<<<T * n_ch * n_seg, 64>>>(d_tmpl, d_mv, L, n_seg, seg_len, d_bands, d_sct);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -182,7 +183,7 @@ int main(int argc, char** argv)
         for (int it = 0; it < iters + 1; ++it) {
             if (it == 1) CK(hipEventRecord(e0));
             kfn<<<grid, THREADS, WG_LDS>>>(d_split, d_bands, d_sct, d_scd, d_rec, d_rd, d_range, L, N, T, n_ch, n_corr, 1,
-                                           d_out, n_lag_blocks, 0, prio);
+                                           d_out, n_lag_blocks, 0, prio, n_seg, seg_len);
         }
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -194,9 +195,13 @@ int main(int argc, char** argv)
                "kernel 2.62e11 channel-lags/s at cfg2: x %.2f)\n", what, prio, ms, chlags / (ms * 1e-3),
                2.0 * L * chlags / (ms * 1e-3) / 1e12, 2.0 * L * chlags / (ms * 1e-3) / 1e12 / 157.3, chlags / (ms * 1e-3) / 2.62e11);
     };
-    run(mf_split_kernel<true, true, 2>, "K loop alone      ", 0);
-    run(mf_split_kernel<true, true, 1>, "no norms          ", 0);
-    for (int prio = 3; prio >= 0; --prio) run(mf_split_kernel<true, true, 0>, "full kernel       ", prio);
+    if (n_seg > 1) {
+        for (int prio = 1; prio >= 0; --prio) run(mf_split_kernel<true, true, 0, true>, "full kernel (segments)", prio);
+    } else {
+        run(mf_split_kernel<true, true, 2>, "K loop alone      ", 0);
+        run(mf_split_kernel<true, true, 1>, "no norms          ", 0);
+        for (int prio = 3; prio >= 0; --prio) run(mf_split_kernel<true, true, 0>, "full kernel       ", prio);
+    }
     // check sampled lags against float64 (and the fp32 chain against the same)
     std::vector<float> out((size_t)T * n_corr);
     CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
