@@ -72,7 +72,7 @@ constexpr int WG_LDS = WAVES * WAVE_LDS;                    // 62 464: two workg
 constexpr int MAX_KS = 26;                  // k-steps of 16: L + 38 <= 416
 constexpr int BAND_LEAD = 40;               // Br[i] = tmpl[i - BAND_LEAD - r]
 constexpr int S_TARGET = 14;                // largest magnitude of a channel scaled into [2^14, 2^15)
-constexpr int S_CLAMP = 100;
+constexpr int S_CLAMP = 60;                 // |s| <= 60: the product of a template's and a channel's 2^-s stays a normal float
 constexpr float SP_MAX_NORM = 1000.0f;      // = MAX_NORM of common.h: r_t * r_d >= this -> CC = 0
 
 __host__ __device__ inline int nks_of(int L) { return (L + 38 + 15) / 16; }
@@ -259,7 +259,7 @@ __device__ __forceinline__ f16x8 sp_h8(i32x4 v) { return __builtin_bit_cast(f16x
 
 // chan_rec: the records of mf_prologue_kernel {channel, moveout, weight bits, r_t bits} closed by {-1, ..} x 2;
 // e_d: the reciprocal window norms r_d of the fp32 path; range: valid CC indices per template.
-// cc = (num * 2^-s_t * 2^-s_d) * (r_t * r_d) where r_t * r_d < 1000, else 0; sum = fmaf(w, cc, sum).
+// cc = (num * 2^-(s_t + s_d)) * (r_t * r_d) where r_t * r_d < 1000, else 0; sum = fmaf(w, cc, sum).
 // ABLATE (tools/ubench/mfma_split16.hip only; the library instantiates 0): 1 = no norms / scaling in the epilogue,
 // 2 = also no staging (the K loop alone, on whatever the LDS holds)
 // SEGMENTED: templates of more than one segment (n_seg > 1); false folds the segment logic away
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
             const float rt_n = __int_as_float(rec.w);
             const float s_t = sct[(size_t)t * n_ch + ch];
             const float s_d = scd[ch];
+            const float s_td = s_t * s_d;              // (exact: powers of two, |exponent| <= 120)
             const int4 rec2 = recs[ri + 2];
             const float* edc = e_d + (size_t)ch * (size_t)nwin;
             // (the window norms are needed behind the channel's LAST segment only)
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
             for (int u = 0; u < NT; ++u) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float num = (acc[u][r] * s_t) * s_d;
+                    const float num = acc[u][r] * s_td;
                     const float nrm = rt_n * ed[u][r >> 2][r & 3];
                     float cc = nrm < SP_MAX_NORM ? num * nrm : 0.0f;
                     if (NETWORK_SUM && STEP1 && wave_inside) {
