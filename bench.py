@@ -723,6 +723,14 @@ def main():
                        "x_fp32_mfma_peak": round(flop_per_launch / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 3),
                        "f16_mfma_issue_frac_of_2500_tflops": round(
                            3.0 * 2.0 * (16 * ((L + 38 + 15) // 16)) * S * C * T * n_corr / (kms * 1e-3) / 1e12 / 2500.0, 4),
+                       # the same contract as the headline's: algorithmic (direct-form) flops per launch / the kernel's own launch time,
+                       # against the dense fp16 MFMA peak divided by the three products a direct-form multiply-add costs on this path
+                       "roofline": {"kernel": "mf_split_kernel", "bound": "mfma", "achieved": round(flop_per_launch / (kms * 1e-3) / 1e12, 2),
+                                    "peak": round(2500.0 / 3.0, 1), "unit": "TFLOP/s", "frac": round(flop_per_launch / (kms * 1e-3) / 1e12 / (2500.0 / 3.0), 4),
+                                    "traffic": None, "avg_launch_ms": round(kms, 3),
+                                    "peak_is": "2.5 PFLOP/s dense fp16 MFMA (MI355X_MICROARCH.md) / 3 products per direct-form flop; the Toeplitz band "
+                                               "(304 deep for 256 samples) is inside `achieved`, as in the headline; traffic: profiles/r06_mf_split16_pmc.txt "
+                                               "(41.5 GB fetched per 100 templates, not measured in this run)"},
                        "max_abs_diff_vs_exact_over_sum_w": worst / sw, "tolerance": 2e-5,
                        "exact_zeros_identical": same_zero,
                        "planted": det2["planted"], "planted_found_at_exact_index": det2["planted_found_at_exact_index"],
