@@ -2805,6 +2805,7 @@ static int bpmf_bp_run_impl(const float* features, const int32_t* moveouts, cons
     t_call_stats.total_ms = host_now_ms() - t_call0;
     if (!rc && es != hipSuccess) fail(es, "synchronize");
     release_plan();
+    copy_pool_quiesce();  // no host thread of the copy pool still reads the caller's arrays (a straggler of an idempotent fill) when the call returns
     fan.finish();         // a source's peers are through with its copy of the day before the working set may go
     ctx->trim_after_call();
     return rc;
@@ -2820,9 +2821,11 @@ extern "C" int bpmf_bp_run(const float* features, const int32_t* moveouts, const
     try {
         return bpmf_bp_run_impl(features, moveouts, w_phases, w_sources, N, K, S, C, P, out_of_bounds, reduce, device, beam_out, arg_out);
     } catch (const std::exception& e) {
+        copy_pool_quiesce();      // (no pool thread may still read the caller's arrays)
         set_error("bpmf_bp_run: exception: %s", e.what());
         return -3;
     } catch (...) {
+        copy_pool_quiesce();
         set_error("bpmf_bp_run: unknown exception");
         return -3;
     }

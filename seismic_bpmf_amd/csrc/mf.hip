@@ -1744,6 +1744,7 @@ static int bpmf_mf_run_impl(const float* templates, const int32_t* moveouts, con
         fprintf(stderr, "[bpmf] mf_run: %zu batches of at most %zu templates, %.3f s after setup: waiting for the "
                         "device %.3f s, host copies %.3f s\n", n_batch, TB, now() - t_start, t_wait, t_copy);
 #undef MF_TRY
+    copy_pool_quiesce();  // no host thread of the copy pool still reads the caller's arrays (a straggler of an idempotent fill) when the call returns
     fan.finish();         // a source's peers are through with its copy of the day before the working set may go
     ctx->trim_after_call();
     return rc;
@@ -1759,9 +1760,11 @@ extern "C" int bpmf_mf_run(const float* templates, const int32_t* moveouts, cons
     try {
         return bpmf_mf_run_impl(templates, moveouts, weights, data, step, L, N, T, S, C, n_corr, network_sum, flags, device, cc_out);
     } catch (const std::exception& e) {
+        copy_pool_quiesce();      // (no pool thread may still read the caller's arrays)
         set_error("bpmf_mf_run: exception: %s", e.what());
         return -3;
     } catch (...) {
+        copy_pool_quiesce();
         set_error("bpmf_mf_run: unknown exception");
         return -3;
     }
