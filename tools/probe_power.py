@@ -1,5 +1,5 @@
 """Socket power and shader clock (rocm-smi, sampled twice a second) while one of the two hot kernels runs back to back:
-is the clock the BP kernel sustains (1.9 - 2.1 GHz of 2.4) a power cap?  usage: python tools/probe_power.py mf|bp [seconds]"""
+is the clock the BP kernel sustains (1.9 - 2.1 GHz of 2.4) a power cap?  usage: python tools/probe_power.py mf|mf_split16|bp [seconds]"""
 import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,7 +10,9 @@ from seismic_bpmf_amd import synthetic as syn
 which = sys.argv[1] if len(sys.argv) > 1 else "bp"
 seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 12.0
 device = torch.device("cuda", 0)
-if which == "mf":
+if which in ("mf", "mf_split16"):
+    if which == "mf_split16":
+        sb.set_option("mf.split16", 1)
     cfg = dict(syn.MF_CONFIGS["cfg2"]); cfg["T"] = 100
     tmpl, mv, w, data, _ = bench.mf_inputs_device(cfg, device, 20260928, 0)
     mf = sb.MatchedFilterGPU(device=0); mf.set_data(data)
