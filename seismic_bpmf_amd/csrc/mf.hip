@@ -1363,8 +1363,8 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     if (off_hi <= off_lo) return 0;
     const bool first_piece = !(ranged && t_mf_continue);
     // option mf.split16: the split-precision kernel takes every launch the MFMA kernels would take for templates of
-    // whatever length (in segments of at most 376 samples; not under mf.compat_sqrt_norm: its norm arrays hold energies)
-    const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N) && !sqrt_norm;
+    // whatever length (in segments of at most 376 samples; under mf.compat_sqrt_norm its epilogue divides by sqrtf(E_t * E_d))
+    const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N);
     if (split16 && ranged) {
         set_error("bpmf_mf_run_dev: internal error: a range of lag blocks under mf.split16");
         return -1;
@@ -1411,7 +1411,7 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     if (split16) {
         const size_t nb_cnt = (n_offsets + sp::LAGS_PER_WG - 1) / sp::LAGS_PER_WG;
         if (int rc = sp::run(d_templates, d_moveouts, ws.sp_day, ws.sp_batch, ws.chan_rec, ws.e_d, ws.range, step, L, N, T,
-                             n_ch, n_corr, network_sum, 0, nb_cnt, d_cc_out, stream))
+                             n_ch, n_corr, network_sum, sqrt_norm ? 1 : 0, 0, nb_cnt, d_cc_out, stream))
             return rc;
     } else if (use_mfma) {
         // 8 XCDs x ceil(n_lag_blocks x T / 8) (lag block, template) pairs (mf_tile_of_block)

@@ -260,6 +260,8 @@ __device__ __forceinline__ f16x8 sp_h8(i32x4 v) { return __builtin_bit_cast(f16x
 // chan_rec: the records of mf_prologue_kernel {channel, moveout, weight bits, r_t bits} closed by {-1, ..} x 2;
 // e_d: the reciprocal window norms r_d of the fp32 path; range: valid CC indices per template.
 // cc = (num * 2^-(s_t + s_d)) * (r_t * r_d) where r_t * r_d < 1000, else 0; sum = fmaf(w, cc, sum).
+// `prio`: bits 0-1 the wave priority experiments of the ubench (the library passes 0 there); bit 2: the norms are
+// energies and cc = num / sqrtf(E_t * E_d) where the product exceeds 1e-6, else 0 (option mf.compat_sqrt_norm).
 // ABLATE (tools/ubench/mfma_split16.hip only; the library instantiates 0): 1 = no norms / scaling in the epilogue,
 // 2 = also no staging (the K loop alone, on whatever the LDS holds)
 // SEGMENTED: templates of more than one segment (n_seg > 1); false folds the segment logic away
@@ -496,7 +498,11 @@ __global__ __launch_bounds__(THREADS, 2) void mf_split_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const float num = acc[u][r] * s_td;
                     const float nrm = rt_n * ed[u][r >> 2][r & 3];
-                    float cc = nrm < SP_MAX_NORM ? num * nrm : 0.0f;
+                    float cc;
+                    if (prio & 4)       // mf.compat_sqrt_norm: the stored norms are the energies E_t and E_d
+                        cc = nrm > 1.0e-6f ? num / sqrtf(nrm) : 0.0f;
+                    else
+                        cc = nrm < SP_MAX_NORM ? num * nrm : 0.0f;
                     if (NETWORK_SUM && STEP1 && wave_inside) {
                         sum[u][r] = __fmaf_rn(w, cc, sum[u][r]);
                     } else {

@@ -62,7 +62,7 @@ int prepare_day(const float* d_data, size_t N, size_t n_ch, void* day_region, hi
 
 int run(const float* d_templates, const int32_t* d_moveouts, const void* day_region, void* batch_region,
         const int4* chan_rec, const float* e_d, const int2* range, size_t step, size_t L, size_t N, size_t T,
-        size_t n_ch, size_t n_corr, int network_sum, size_t nb_lo, size_t nb_cnt, float* d_cc_out,
+        size_t n_ch, size_t n_corr, int network_sum, int sqrt_norm, size_t nb_lo, size_t nb_cnt, float* d_cc_out,
         hipStream_t stream)
 {
     const DayRegion r = carve_day(const_cast<void*>(day_region), N, n_ch);
@@ -85,7 +85,8 @@ int run(const float* d_templates, const int32_t* d_moveouts, const void* day_reg
         /* (62 464 bytes of dynamic LDS: below the 64 KB that need no opt-in) */                                     \
         kfn<<<grid, dim3(THREADS), WG_LDS, stream>>>(r.planes, bands, sct, r.scd, chan_rec, e_d, range, (int)L,      \
                                                      (long long)N, (int)T, (int)n_ch, (long long)n_corr, (int)step,   \
-                                                     d_cc_out, (int)nb_cnt, (int)nb_lo, 0, n_seg, seg_len);           \
+                                                     d_cc_out, (int)nb_cnt, (int)nb_lo, sqrt_norm ? 4 : 0, n_seg,     \
+                                                     seg_len);                                                        \
     } while (0)
     if (network_sum && step == 1) BPMF_SP_LAUNCH(true, true);
     else if (network_sum) BPMF_SP_LAUNCH(true, false);

@@ -19,10 +19,11 @@ bool usable(size_t L, size_t N);
 int prepare_day(const float* d_data, size_t N, size_t n_ch, void* day_region, hipStream_t stream);
 
 // one launch over the lag blocks [nb_lo, nb_lo + nb_cnt) of 8192 data offsets: band images, then the kernel.
-// chan_rec / range / e_d: what mf_prologue_kernel and the per-day preparation left in the workspace.
+// chan_rec / range / e_d: what mf_prologue_kernel and the per-day preparation left in the workspace (under
+// sqrt_norm, option mf.compat_sqrt_norm, they hold energies and the epilogue divides by sqrtf(E_t * E_d)).
 int run(const float* d_templates, const int32_t* d_moveouts, const void* day_region, void* batch_region,
         const int4* chan_rec, const float* e_d, const int2* range, size_t step, size_t L, size_t N, size_t T,
-        size_t n_ch, size_t n_corr, int network_sum, size_t nb_lo, size_t nb_cnt, float* d_cc_out,
+        size_t n_ch, size_t n_corr, int network_sum, int sqrt_norm, size_t nb_lo, size_t nb_cnt, float* d_cc_out,
         hipStream_t stream);
 
 constexpr size_t LAGS_PER_WG = 8192;

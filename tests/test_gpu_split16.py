@@ -96,6 +96,39 @@ def test_split16_differs_from_the_exact_path_only_in_the_last_bits(oracle_lib, h
     assert np.array_equal(again, exact)
 
 
+@pytest.mark.parametrize("network_sum", [True, False])
+@pytest.mark.parametrize("L,N", [(100, 30011), (256, 40000), (500, 30000)])
+def test_split16_under_sqrt_norm_and_the_upstream_profile(oracle_lib, split16, network_sum, L, N):
+    """mf.compat_sqrt_norm with mf.split16: the split kernel's epilogue takes num / sqrtf(E_t * E_d) behind the
+    1e-6 guard (the norm arrays hold energies under the switch) -- it used to hand such launches to the exact kernel.
+    Same bar against the oracle under the same switch; then the whole "upstream-recollected" profile on top."""
+    from seismic_bpmf_amd import matched_filter, compat_profile, _lib
+    rng = np.random.default_rng(L + N)
+    tp, mv, w, d = _case(rng, 3, 4, 3, L, N, -70, 900)
+    split16("mf.compat_sqrt_norm", 1)
+    with oracle_lib.compat(oracle_lib.COMPAT_SQRT_NORM):
+        want = oracle_lib.matched_filter(tp, mv, w, d, 1, network_sum)
+    got = matched_filter(tp, mv, w, d, 1, arch="gpu", network_sum=network_sum, check_zeros=False)
+    _check(got, want, w, f"split16 + sqrt_norm L={L} ns={network_sum}", per_channel=not network_sum)
+    # ... and it IS the split kernel that ran: the exact kernel under the switch equals the oracle bit for bit
+    assert not np.array_equal(got, want)
+    split16.reset("mf.compat_sqrt_norm")
+    before = {k: _lib.get_option(k) for k in _lib.COMPAT_SWITCHES}
+    try:
+        compat_profile("upstream-recollected")
+        flags = 0
+        for name in ("SQRT_NORM", "EXCLUSIVE_LAST_LAG", "RANGE_ALL_CHANNELS", "SEQUENTIAL_CSUM"):
+            flags |= getattr(oracle_lib, "COMPAT_" + name)
+        with oracle_lib.compat(flags):
+            want = oracle_lib.matched_filter(tp, mv, w, d, 1, network_sum)
+        got = matched_filter(tp, mv, w, d, 1, arch="gpu", network_sum=network_sum, check_zeros=False)
+        _check(got, want, w, f"split16 + profile L={L} ns={network_sum}", per_channel=not network_sum)
+    finally:
+        compat_profile("build")
+        for k, v in before.items():
+            _lib.set_option(k, v[0] if isinstance(v, tuple) else v)
+
+
 @pytest.mark.parametrize("step", [2, 5])
 def test_split16_steps(oracle_lib, split16, step):
     from seismic_bpmf_amd import matched_filter
@@ -268,10 +301,14 @@ def test_fuzz_split16_random_shapes_signed_moveouts(oracle_lib, split16, seed):
     mv = rng.integers(lo, hi + 1, (T, S, C)).astype(np.int32)
     w = rng.random((T, S, C)).astype(np.float32)
     w[rng.random((T, S, C)) < 0.2] = 0.0
+    # every third seed under mf.compat_sqrt_norm (energies in the norm arrays, the 1e-6 guard: other exact zeros)
+    flags = oracle_lib.COMPAT_SQRT_NORM if seed % 3 == 1 else 0
+    split16("mf.compat_sqrt_norm", 1 if flags else 0)
     for ns in (True, False):
         got = matched_filter(tp, mv, w, data, step, arch="gpu", network_sum=ns, check_zeros=False)
-        want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=ns)
-        what = f"seed {seed} ns={ns} (T={T} S={S} C={C} L={L} N={N} step={step} mv in [{lo},{hi}])"
+        with oracle_lib.compat(flags):
+            want = oracle_lib.matched_filter(tp, mv, w, data, step, network_sum=ns)
+        what = f"seed {seed} ns={ns} flags={flags} (T={T} S={S} C={C} L={L} N={N} step={step} mv in [{lo},{hi}])"
         assert got.shape == want.shape and np.isfinite(got).all(), what
         assert np.array_equal(got == 0.0, want == 0.0), what + f": {((got == 0) != (want == 0)).sum()} exact zeros differ"
         diff = np.abs(got.astype(np.float64) - want)
