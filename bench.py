@@ -829,6 +829,29 @@ def main():
                                             "achieved": round(flop / (kms * 1e-3) / 1e12, 2), "peak": FP32_PEAK_TFLOPS,
                                             "unit": "TFLOP/s", "frac": round(flop / (kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                                             "frac_whole_call": round(flop / wall / 1e12 / FP32_PEAK_TFLOPS, 4)}}
+            # the same shape under the opt-in split-precision path (option mf.split16; weights sum to 1 per template)
+            _lib.set_option("mf.split16", 1)
+            try:
+                mf3 = sb.MatchedFilterGPU(device=local_rank)
+                mf3.set_data(d2)
+                o3 = mf3.run(t2, m2, w2, 1)
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                for _ in range(reps):
+                    mf3.run(t2, m2, w2, 1, out=o3)
+                torch.cuda.synchronize()
+                _lib.profile_enable(False)
+                kms3 = float(np.mean(_lib.profile_times_ms(_lib.KERNEL_MF_MAIN)))
+                pairs = T2 * (-(-(N2 - L2 + 1) // 8192))
+                mf_shapes[name]["split16"] = {"kernel_ms": round(kms3, 4), "speedup_kernel": round(kms / kms3, 3),
+                                              "template_x_8192_lag_block_pairs": pairs,
+                                              "kernel": "mf_split_kernel" if pairs >= 128 else
+                                              "the exact kernel: mf.split16 = 1 leaves launches below 128 pairs to it (latency-bound there, tools/probe_split_small.py)",
+                                              "max_abs_diff_vs_exact_over_sum_w": float((o3 - o2).abs().max().item()),
+                                              "tolerance": 2e-5, "dtype": "f16x3->f32"}
+                del mf3, o3
+            finally:
+                _lib.set_option("mf.split16", 0)
             if name == "tutorial":
                 # the SAME call as a BPMF user makes it (nb8 cell 18: MatchedFilter.compute_cc_time_series ->
                 # fmf.matched_filter, BPMF/similarity_search.py:526-533): through the import shim, NumPy in / out.

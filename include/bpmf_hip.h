@@ -107,7 +107,8 @@ int bpmf_host_call_stats(double *out, int n);
  *   mf.split16 (off by default; CHANGES RESULTS within a stated tolerance: matched-filter numerators on the fp16
  *     matrix pipe from hi/lo splits of data and templates, three products, fp32 accumulation -- csrc/mf_split.h;
  *     |d cc_sum| <= 3e-7 * sum|w| measured, 2e-5 allowed by the north star; x 2.3-2.4 at configs[1]; templates of up
- *     to 2049 samples (in segments of at most 376); composes with the mf.compat_* switches; enlarges
+ *     to 2049 samples (in segments of at most 376); composes with the mf.compat_* switches; 1 leaves launches of fewer
+ *     than 128 (template, 8192-lag block) pairs to the exact kernel (latency-bound there), 2 takes every launch; enlarges
  *     bpmf_mf_workspace_bytes and what a prepared day holds: set it before the day's first call)
  *   and the result-changing upstream-compatibility switches (off by default; every one has
  *   a variant of the CPU oracle and tools/diff_upstream.py tells which combination equals the real packages):

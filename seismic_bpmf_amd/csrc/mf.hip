@@ -1364,7 +1364,12 @@ extern "C" int bpmf_mf_run_dev(const float* d_templates, const int32_t* d_moveou
     const bool first_piece = !(ranged && t_mf_continue);
     // option mf.split16: the split-precision kernel takes every launch the MFMA kernels would take for templates of
     // whatever length (in segments of at most 376 samples; under mf.compat_sqrt_norm its epilogue divides by sqrtf(E_t * E_d))
-    const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N);
+    // mf.split16 = 1 leaves small launches to the exact kernel (below SP_MIN_BLOCKS (template, 8192-lag block) pairs a
+    // wave's chain of per-channel stagings is latency, not rate: configs[0], 88 pairs, ran 0.71x the exact kernel's speed, 176 pairs x 1.1-1.6:
+    // profiles/r06_mf_split16.txt); = 2 takes the split kernel for every launch (the small shapes of the tests)
+    constexpr size_t SP_MIN_BLOCKS = 128;
+    const bool sp_small = option(OPT_MF_SPLIT16) == 1 && T * ((n_offsets + sp::LAGS_PER_WG - 1) / sp::LAGS_PER_WG) < SP_MIN_BLOCKS;
+    const bool split16 = ws.sp_day != nullptr && use_mfma && sp::usable(L, N) && !sp_small;
     if (split16 && ranged) {
         set_error("bpmf_mf_run_dev: internal error: a range of lag blocks under mf.split16");
         return -1;

@@ -67,7 +67,7 @@ const OptionDef OPTION_DEFS[OPT_COUNT] = {
     {"stats.bucketed_median", 2, 0, 2, false},             // MAD threshold, window medians: 2 = one pass each (the elements of a narrow band around the row's centre / around the middle of a side histogram of deviations, ranked in LDS), 1 = two passes (equal-width buckets, the middle bucket ranked in LDS; also the route when a band misses), 0 = three-pass radix select only (the last resort of the others)
     {"stats.row_grid_min_n", 131072, -1, 1 << 30, false},   // row median / MAD: rows at least this long are read twice by workgroups from all over the chip (histogram, then the middle bucket and two bands; exact, verified by ranks) instead of seven times by one workgroup; -1 = never
     {"stats.kurt_full_chunks", 1, 0, 1, false},            // row kurtosis: a full 8192-sample chunk of NumPy's summation is summed by one workgroup through LDS (coalesced reads); 0 = the thread-per-leaf kernels for every chunk
-    {"mf.split16", 0, 0, 1, false},                        // matched filter (every template length the MFMA kernels take): numerators from fp16 hi/lo splits of data and templates (three v_mfma_f32_32x32x16_f16 products, fp32 accumulation; csrc/mf_split.h) instead of the exact-fp32 MFMA chain: |d cc| ~ 2e-7 instead of bit-identity with the oracle, ~2.4x the rate.  Norms, lag ranges, zero rules unchanged.  OFF by default; changes the workspace size and what a prepared day holds
+    {"mf.split16", 0, 0, 2, false},                        // matched filter (every template length the MFMA kernels take): numerators from fp16 hi/lo splits of data and templates (three v_mfma_f32_32x32x16_f16 products, fp32 accumulation; csrc/mf_split.h) instead of the exact-fp32 MFMA chain: |d cc| ~ 2e-7 instead of bit-identity with the oracle, ~2.4x the rate.  Norms, lag ranges, zero rules unchanged.  OFF by default; 1 = launches of at least 128 (template, 8192-lag block) pairs, 2 = every launch; changes the workspace size and what a prepared day holds
     {"debug.fail_peer_copy", 0, 0, 1, false},              // tests: every device-to-device probe of the multi-device hand-over fails (context.hip: peer_copy_works), so the fall-back -- each device uploads the day from the host, with a note in bpmf_last_error -- runs on a one-GPU box
     {"mf.compat_exclusive_last_lag", 0, 0, 1, false},  // last valid data offset i * step < N - L - mv_max (default: <=)
     {"mf.compat_sqrt_norm", 0, 0, 1, false},           // cc = num / sqrtf(E_t * E_d) above 1e-6 (default: num * r_t * r_d)

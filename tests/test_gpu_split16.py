@@ -19,7 +19,9 @@ TOL_CC = 2e-5          # per unit of sum |w|
 
 @pytest.fixture
 def split16(hip_opts):
-    hip_opts("mf.split16", 1)
+    # 2 = the split kernel for EVERY launch: the value a user sets, 1, leaves launches of fewer than 128 (template,
+    # 8192-lag block) pairs -- every small shape of this file -- to the exact kernel (test_split16_small_launches_...)
+    hip_opts("mf.split16", 2)
     return hip_opts
 
 
@@ -87,7 +89,7 @@ def test_split16_differs_from_the_exact_path_only_in_the_last_bits(oracle_lib, h
     exact = matched_filter(tp, mv, w, d, 1, check_zeros=False)
     want = oracle_lib.matched_filter(tp, mv, w, d, 1, True)
     assert np.array_equal(exact, want)
-    hip_opts("mf.split16", 1)
+    hip_opts("mf.split16", 2)
     split = matched_filter(tp, mv, w, d, 1, check_zeros=False)
     hip_opts.reset("mf.split16")
     assert not np.array_equal(split, exact)
@@ -127,6 +129,27 @@ def test_split16_under_sqrt_norm_and_the_upstream_profile(oracle_lib, split16, n
         compat_profile("build")
         for k, v in before.items():
             _lib.set_option(k, v[0] if isinstance(v, tuple) else v)
+
+
+def test_split16_small_launches_stay_with_the_exact_kernel(oracle_lib, hip_opts):
+    """mf.split16 = 1: a launch of fewer than 128 (template, 8192-lag block) pairs is latency-bound in the split kernel
+    (configs[0], 88 pairs: 0.71x the exact kernel's speed; 176 pairs: x 1.1-1.6, tools/probe_split_small.py) and stays
+    with the exact kernel -- the oracle's bits; from 128 pairs on it is the split kernel (= what mf.split16 = 2 gives
+    for every launch)."""
+    from seismic_bpmf_amd.matched_filter import MatchedFilterGPU
+    rng = np.random.default_rng(9)
+    tp, mv, w, d = _case(rng, 16, 3, 2, 64, 70_000, 0, 300)           # 9 blocks of 8192 lags per template
+    eng = MatchedFilterGPU()                                          # (resident: one launch for all T templates; the
+    eng.set_data(d)                                                   #  host-pointer call launches per template batch)
+    for T, is_split in ((14, False), (15, True), (16, True)):         # 126, 135, 144 pairs
+        want = oracle_lib.matched_filter(tp[:T], mv[:T], w[:T], d, 1, True)
+        hip_opts("mf.split16", 2)
+        forced = eng.run(tp[:T], mv[:T], w[:T]).cpu().numpy()
+        hip_opts("mf.split16", 1)
+        got = eng.run(tp[:T], mv[:T], w[:T]).cpu().numpy()
+        assert not np.array_equal(forced, want)
+        assert np.array_equal(got, forced if is_split else want), T
+        _check(got, want, w[:T], f"mf.split16 = 1, T = {T}")
 
 
 @pytest.mark.parametrize("step", [2, 5])
@@ -325,13 +348,13 @@ def test_split16_refuses_a_day_that_was_prepared_without_it(hip_opts):
     tp, mv, w, d = _case(rng, 2, 3, 3, 64, 30_000, 0, 100, scales=False)
     eng = MatchedFilterGPU()
     eng.set_data(d)
-    hip_opts("mf.split16", 1)
+    hip_opts("mf.split16", 2)
     eng.run(tp, mv, w)                               # sizes the workspace for the option and prepares WITH the split
     hip_opts("mf.split16", 0)
     eng.run(tp, mv, w)                               # prepared again, without it
-    hip_opts("mf.split16", 1)
+    hip_opts("mf.split16", 2)
     key = list(eng._prepared_for)
-    key[-1] = 1                                      # pretend the prepared state matched the option
+    key[-1] = 2                                      # pretend the prepared state matched the option
     eng._prepared_for = tuple(key)
     with pytest.raises(_lib.BpmfHipError, match="prepared without it"):
         eng.run(tp, mv, w)
