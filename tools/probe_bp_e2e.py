@@ -4,20 +4,12 @@ kernel, host threads copying the day into the pinned pieces, the wait for the de
    python tools/probe_bp_e2e.py [--hogs N] [--calls K]
 --hogs N: N busy-loop processes beside the calls (the driver's round-5 bench ran at load average 39 on 16 CPUs)."""
 import argparse
-import multiprocessing as mp
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-
-def _hog(stop):
-    x = 0
-    while not stop.is_set():
-        for _ in range(200000):
-            x += 1
 
 
 def main():
@@ -65,15 +57,27 @@ def main():
             pin.copy_(dv, non_blocking=True)
             torch.cuda.synchronize()
         del pin, dv
-    stop = mp.Event()
-    hogs = [mp.Process(target=_hog, args=(stop,), daemon=True) for _ in range(args.hogs)]
-    for h in hogs:
-        h.start()
+    # (fresh interpreters, not forks of this process: a fork after the HIP runtime is up shares its KFD event pages, and
+    # the first blocking wait of the parent then sat out a 10 s timeout -- an artefact of the probe, seen as "plan_ms
+    # 10 000" on the first hogged call)
+    import subprocess
+    import atexit
+    hogs = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(args.hogs)]
+    atexit.register(lambda: [h.kill() for h in hogs if h.poll() is None])
     if hogs:
         time.sleep(2.0)
         print(f"{args.hogs} hogs running, loadavg {os.getloadavg()[0]:.1f}")
+    def throttle():
+        # cgroup v2 cpu.stat of this container: periods in which the quota ran out and every thread of the group --
+        # the calling thread and the copy pool included -- was frozen until the next period
+        try:
+            kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+        except OSError:
+            return 0, 0
     for i in range(args.calls):
         h_new = h_f.copy()
+        th0 = throttle()
         if args.sleep:
             time.sleep(args.sleep)
         t0 = time.perf_counter()
@@ -82,13 +86,17 @@ def main():
         ms = (time.perf_counter() - t0) * 1e3
         st = _lib.host_call_stats()
         ok = bool(np.array_equal(hb, want_b) and np.array_equal(ha, want_a))
-        print(f"call {i}: {ms:.1f} ms (+{ms - resident:.1f} over resident), equal {ok}, library: " +
+        th1 = throttle()
+        print(f"call {i}: {ms:.1f} ms (+{ms - resident:.1f} over resident), equal {ok}, cgroup throttled {th1[0] - th0[0]} periods / {(th1[1] - th0[1]) / 1e3:.1f} ms, library: " +
               ", ".join(f"{k} {v:.1f}" if isinstance(v, float) else f"{k} {v}" for k, v in st.items()), flush=True)
         del h_new
         if i == args.release_after:
             _lib.release_device_memory(-1)
             print('   (device working set and pinned pieces released)')
-    stop.set()
+    for h in hogs:
+        h.kill()
+    for h in hogs:
+        h.wait()
 
 
 if __name__ == "__main__":
