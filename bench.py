@@ -467,6 +467,27 @@ LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
+def cgroup_throttle():
+    """(periods in which this container's CPU quota ran out, milliseconds its threads stood frozen for it, summed over
+    CPUs) so far -- cgroup v2 cpu.stat, v1 cpu.stat as a fallback; (None, None) where neither is readable.  A host-pointer
+    call that overlaps a throttled period stands still on the host side whatever the library does
+    (profiles/r06_bp_e2e.txt)."""
+    for path, key_n, key_t, div in (("/sys/fs/cgroup/cpu.stat", "nr_throttled", "throttled_usec", 1e3),
+                                    ("/sys/fs/cgroup/cpu/cpu.stat", "nr_throttled", "throttled_time", 1e6)):
+        try:
+            kv = dict(ln.split() for ln in open(path))
+            return int(kv[key_n]), float(kv[key_t]) / div
+        except Exception:
+            continue
+    return None, None
+
+
+def throttle_delta(a, b):
+    if a[0] is None or b[0] is None:
+        return None
+    return {"periods": b[0] - a[0], "ms": round(b[1] - a[1], 1)}
+
+
 def merge_rank_stats(ranks_info, per_rank):
     """Per-rank {step time, kernel time, roofline fraction} (all_gather_object of every rank's own numbers) into
     ranks_info["ranks"][i], matched by rank; also the spread of the kernel times (slowest / fastest)."""
@@ -750,16 +771,18 @@ def main():
     e2e = None
     if world == 1 and dist is None and not args.skip_e2e and T * n_corr * 4 < 40e9:
         h_t, h_mv, h_w, h_d = (x.cpu().numpy() for x in (tmpl, mv, w, data))
-        e2e_ms = []
+        e2e_ms, mf_thr = [], []
         h_cc = None
         for _ in range(2):
             del h_cc                       # one 17 GB result array at a time
             h_new = h_d.copy()             # a new day is a NEW array: host memory the runtime has not page-locked before
+            th0 = cgroup_throttle()
             t0 = time.perf_counter()
             h_cc = sb.matched_filter(h_t, h_mv, h_w, h_new, 1, arch="gpu", check_zeros=False,
                                      device=[local_rank])
             e2e_ms.append((time.perf_counter() - t0) * 1e3)
             mf_stats = _lib.host_call_stats()
+            mf_thr.append(throttle_delta(th0, cgroup_throttle()))
             del h_new
         e2e = {"mf_ms": round(min(e2e_ms), 1), "mf_calls_ms": [round(x, 1) for x in e2e_ms],
                "mf_value": round(T * n_corr / (min(e2e_ms) * 1e-3) / 1e6, 1), "unit": "M CC-samples/s",
@@ -767,6 +790,7 @@ def main():
                         "(pageable host memory, a fresh copy of the day per call; pinned staging both ways inside bpmf_mf_run, "
                         "the day arriving in pieces while the first two template batches run)",
                "breakdown_of_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in mf_stats.items()},
+               "cgroup_throttled_by_call": mf_thr,
                "row0_peak_cc": round(float(h_cc[0].max()), 4)}
         # the same drop-in call under option mf.split16 (untimed extra of the untimed extra: one call, the day uploaded in one
         # piece -- a channel's scale is its maximum over the whole day -- then the split kernel; never `value`)
@@ -973,14 +997,16 @@ def main():
         bf.close()
         if world == 1 and dist is None and not args.skip_e2e:
             h_f, h_wp = feat.cpu().numpy(), wp.cpu().numpy()
-            ms, stats = [], []
+            ms, stats, bp_thr = [], [], []
             for _ in range(4):           # the first call builds the plan; the later ones find it in the library's cache
                 h_new = h_f.copy()       # a new day is a NEW array (host memory the runtime has not page-locked before)
+                th0 = cgroup_throttle()
                 t0 = time.perf_counter()
                 hb, ha = sb.beamform(h_new, geo["moveouts"], h_wp, geo["weights_sources"], device="gpu",
                                      reduce="max", out_of_bounds="strict", device_id=[local_rank])
                 ms.append((time.perf_counter() - t0) * 1e3)
                 stats.append(_lib.host_call_stats())
+                bp_thr.append(throttle_delta(th0, cgroup_throttle()))
                 del h_new
             later = sorted(ms[1:])
             med = later[len(later) // 2]
@@ -992,6 +1018,9 @@ def main():
                                     # where the reported call's time went, by the library's own account (bpmf_host_call_stats)
                                     "breakdown_of_reported_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stats[rep].items()},
                                     "pinned_wait_ms_by_call": [round(st.get("pinned_wait_ms", 0.0), 1) for st in stats],
+                                    # periods in which the container's CPU quota ran out during each call (every thread of the
+                                    # group frozen until the next period: the host side of a call stands still, profiles/r06_bp_e2e.txt)
+                                    "cgroup_throttled_by_call": bp_thr,
                                     "breakdown_note": ("first_kernel_start_ms: entry -> first kernel enqueued; host_copy_ms: the copy pool filling the "
                                                        "pinned pieces (overlaps earlier pieces' kernels); pinned_wait_ms: blocked until a piece's previous "
                                                        "H2D had completed (~10 ms over the 17 pieces of a cfg3 day; rounds 4-5 lost 20-40 ms here in the call behind a plan build: "
